@@ -1,0 +1,92 @@
+"""ctypes mirror of include/admm_hip.h (structs + marshalling of a Problem).
+
+Kept free of any library loading so that both the product binding
+(`solver.py` -> libadmm_hip.so) and the test-side oracle wrapper can share one
+definition of the ABI structs.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from .problems import Problem
+
+ABI_VERSION = 1
+
+ADMM_OK = 0
+STATUS_NAMES = {0: "ADMM_OK", 1: "ADMM_ERR_INVALID", 2: "ADMM_ERR_UNSUPPORTED",
+                3: "ADMM_ERR_NO_DEVICE", 4: "ADMM_ERR_HIP", 5: "ADMM_ERR_NUMERIC",
+                6: "ADMM_ERR_ALLOC"}
+
+FLAG_NONE = 0
+FLAG_NO_GRAPH = 1
+
+c_double_p = C.POINTER(C.c_double)
+c_int32_p = C.POINTER(C.c_int32)
+
+
+class CProblem(C.Structure):
+    _fields_ = [("N", C.c_int32), ("n", C.c_int32), ("m", C.c_int32), ("batch", C.c_int32),
+                ("time_varying", C.c_int32), ("stage_bounds", C.c_int32),
+                ("A", c_double_p), ("B", c_double_p), ("Q", c_double_p), ("R", c_double_p),
+                ("QN", c_double_p), ("x0", c_double_p), ("lo", c_double_p), ("hi", c_double_p),
+                ("q", c_double_p)]
+
+
+class COptions(C.Structure):
+    _fields_ = [("rho", C.c_double), ("alpha", C.c_double), ("eps_abs", C.c_double),
+                ("eps_rel", C.c_double), ("max_iter", C.c_int32), ("check_interval", C.c_int32),
+                ("segments", C.c_int32), ("device", C.c_int32), ("zrows", C.c_int32),
+                ("flags", C.c_int32)]
+
+
+class CInfo(C.Structure):
+    _fields_ = [("iters_run", C.c_int32), ("n_converged", C.c_int32),
+                ("max_r", C.c_double), ("max_s", C.c_double), ("solve_ms", C.c_double)]
+
+
+def dptr(a):
+    """double* of a C-contiguous float64 array (None -> NULL)."""
+    if a is None:
+        return c_double_p()
+    assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(c_double_p)
+
+
+def iptr(a):
+    if a is None:
+        return c_int32_p()
+    assert a.dtype == np.int32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(c_int32_p)
+
+
+def _colmajor(mat: np.ndarray) -> np.ndarray:
+    """(..., r, c) row-major matrices -> buffer holding each one column-major."""
+    return np.ascontiguousarray(np.swapaxes(np.asarray(mat, np.float64), -1, -2))
+
+
+def marshal_problem(p: Problem):
+    """Build a CProblem over freshly laid-out arrays.  Returns (cproblem, keepalive)."""
+    p.validate()
+    keep = {
+        "A": _colmajor(p.A), "B": _colmajor(p.B), "Q": _colmajor(p.Q), "R": _colmajor(p.R),
+        "QN": _colmajor(p.QN),
+        "x0": np.ascontiguousarray(p.x0, np.float64),
+        "lo": np.ascontiguousarray(p.lo, np.float64),
+        "hi": np.ascontiguousarray(p.hi, np.float64),
+        "q": None if p.q is None else np.ascontiguousarray(p.q, np.float64),
+    }
+    cp = CProblem(N=p.N, n=p.n, m=p.m, batch=p.batch,
+                  time_varying=int(p.time_varying), stage_bounds=int(p.lo.ndim == 2),
+                  A=dptr(keep["A"]), B=dptr(keep["B"]), Q=dptr(keep["Q"]), R=dptr(keep["R"]),
+                  QN=dptr(keep["QN"]), x0=dptr(keep["x0"]), lo=dptr(keep["lo"]),
+                  hi=dptr(keep["hi"]), q=dptr(keep["q"]))
+    return cp, keep
+
+
+def make_options(rho=0.1, alpha=1.0, eps_abs=1e-6, eps_rel=1e-6, max_iter=4000,
+                 check_interval=10, segments=0, device=-1, zrows=0, flags=0) -> COptions:
+    return COptions(rho=rho, alpha=alpha, eps_abs=eps_abs, eps_rel=eps_rel,
+                    max_iter=max_iter, check_interval=check_interval, segments=segments,
+                    device=device, zrows=zrows, flags=flags)

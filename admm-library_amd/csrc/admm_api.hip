@@ -1,0 +1,659 @@
+// admm_api.hip -- C ABI of libadmm_hip.so (include/admm_hip.h) over the HIP
+// kernels of admm_kernels.hpp.  Solver runtime: device buffer ownership,
+// iteration driver, stopping logic.  No CPU fallback: without a HIP device
+// every compute entry point returns ADMM_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/admm_hip.h"
+#include "admm_factor.hpp"
+#include "admm_kernels.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess)                                                                      \
+      return fail(ADMM_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_) + " (" +     \
+                                    __FILE__ + ":" + std::to_string(__LINE__) + ")");          \
+  } while (0)
+
+}  // namespace
+
+struct admm_handle {
+  int N = 0, n = 0, m = 0, nb = 0, batch = 0, pitch = 0, L = 0;
+  int S = 0, zrows = 0, zchunks = 0;
+  int device = 0;
+  bool has_q = false;
+  admm_options opt{};
+  admm::Factor fac;
+  hipStream_t stream = nullptr;
+  // batch-minor state and work buffers
+  double *w = nullptr, *z = nullptr, *y = nullptr, *q = nullptr, *x0 = nullptr;
+  double *dbuf = nullptr, *tseg = nullptr, *eseg = nullptr, *tin = nullptr, *xin = nullptr;
+  double *part = nullptr, *resid = nullptr, *lo = nullptr, *hi = nullptr;
+  double *recB = nullptr, *recF = nullptr, *recS = nullptr;
+  int *seg_start = nullptr, *status = nullptr, *iters = nullptr, *nconv = nullptr;
+  double* stage = nullptr;      // QP-major staging buffer, L * batch
+  int* h_nconv = nullptr;       // pinned
+  int iters_run = 0;
+  bool resid_valid = false;
+  // captured iterations, replayed by admm_run / admm_solve:
+  //   [0] x-update + plain z step;  [1] x-update + residual z step + finalise (it = 0)
+  hipGraph_t graph[2] = {nullptr, nullptr};
+  hipGraphExec_t graph_exec[2] = {nullptr, nullptr};
+};
+
+namespace {
+
+using admm::XB_THREADS;
+using admm::Z_THREADS;
+
+// (n, m) pairs with compiled x-update kernels.
+#define ADMM_FOR_EACH_DIM(X) \
+  X(2, 1) X(2, 2) X(3, 1) X(4, 1) X(4, 2) X(4, 4) X(6, 2) X(6, 3) X(6, 6) X(8, 4) X(12, 3) X(12, 6)
+
+bool dims_supported(int n, int m) {
+#define X(NX, NU) if (n == NX && m == NU) return true;
+  ADMM_FOR_EACH_DIM(X)
+#undef X
+  return false;
+}
+
+std::string supported_list() {
+  std::string s;
+#define X(NX, NU) s += "(" #NX "," #NU ") ";
+  ADMM_FOR_EACH_DIM(X)
+#undef X
+  return s;
+}
+
+int launch_xb(admm_handle* h) {
+  dim3 grid((h->pitch + XB_THREADS - 1) / XB_THREADS, h->S), block(XB_THREADS);
+#define X(NX, NU)                                                                                   \
+  if (h->n == NX && h->m == NU) {                                                                   \
+    if (h->has_q)                                                                                   \
+      hipLaunchKernelGGL((admm::xb_kernel<NX, NU, true>), grid, block, 0, h->stream, h->z, h->y,    \
+                         h->q, h->recB, h->seg_start, h->dbuf, h->tseg, h->eseg, h->opt.rho,        \
+                         h->pitch);                                                                 \
+    else                                                                                            \
+      hipLaunchKernelGGL((admm::xb_kernel<NX, NU, false>), grid, block, 0, h->stream, h->z, h->y,   \
+                         h->q, h->recB, h->seg_start, h->dbuf, h->tseg, h->eseg, h->opt.rho,        \
+                         h->pitch);                                                                 \
+    return ADMM_OK;                                                                                 \
+  }
+  ADMM_FOR_EACH_DIM(X)
+#undef X
+  return fail(ADMM_ERR_UNSUPPORTED, "no x-update kernel for this (n, m)");
+}
+
+int launch_xscan(admm_handle* h) {
+  dim3 grid((h->pitch + XB_THREADS - 1) / XB_THREADS), block(XB_THREADS);
+  switch (h->n) {
+#define C(NX)                                                                                        \
+  case NX:                                                                                           \
+    hipLaunchKernelGGL((admm::xscan_kernel<NX>), grid, block, 0, h->stream, h->tseg, h->eseg, h->x0, \
+                       h->recS, h->tin, h->xin, h->S, h->pitch);                                     \
+    return ADMM_OK;
+    C(2) C(3) C(4) C(6) C(8) C(12)
+#undef C
+    default:
+      return fail(ADMM_ERR_UNSUPPORTED, "no scan kernel for this n");
+  }
+}
+
+int launch_xf(admm_handle* h) {
+  dim3 grid((h->pitch + XB_THREADS - 1) / XB_THREADS, h->S), block(XB_THREADS);
+#define X(NX, NU)                                                                                 \
+  if (h->n == NX && h->m == NU) {                                                                 \
+    hipLaunchKernelGGL((admm::xf_kernel<NX, NU>), grid, block, 0, h->stream, h->dbuf, h->tin,     \
+                       h->xin, h->recF, h->seg_start, h->w, h->pitch);                            \
+    return ADMM_OK;                                                                               \
+  }
+  ADMM_FOR_EACH_DIM(X)
+#undef X
+  return fail(ADMM_ERR_UNSUPPORTED, "no x-update kernel for this (n, m)");
+}
+
+int launch_z(admm_handle* h, bool resid) {
+  dim3 grid((h->pitch / 2 + Z_THREADS - 1) / Z_THREADS, h->zchunks), block(Z_THREADS);
+  const bool relax = h->opt.alpha != 1.0;
+#define ZL(RS, RX)                                                                                  \
+  hipLaunchKernelGGL((admm::zdual_kernel<RS, RX>), grid, block, 0, h->stream, h->w, h->z, h->y,     \
+                     h->lo, h->hi, h->part, h->opt.alpha, h->L, h->zrows, h->pitch)
+  if (resid) {
+    if (relax) ZL(true, true); else ZL(true, false);
+  } else {
+    if (relax) ZL(false, true); else ZL(false, false);
+  }
+#undef ZL
+  return ADMM_OK;
+}
+
+int launch_finalize(admm_handle* h, int it) {
+  dim3 grid((h->pitch + 255) / 256), block(256);
+  hipLaunchKernelGGL(admm::resid_finalize_kernel, grid, block, 0, h->stream, h->part, h->resid,
+                     h->status, h->iters, h->nconv, h->opt.rho, h->opt.eps_abs, h->opt.eps_rel,
+                     std::sqrt((double)h->L), h->zchunks, h->batch, h->pitch, it);
+  return ADMM_OK;
+}
+
+int step_x(admm_handle* h) {
+  int rc;
+  if ((rc = launch_xb(h))) return rc;
+  if ((rc = launch_xscan(h))) return rc;
+  if ((rc = launch_xf(h))) return rc;
+  return ADMM_OK;
+}
+
+// QP-major host array (batch x rows) -> batch-minor device array (rows x pitch)
+int upload_transposed(admm_handle* h, const double* src, double* dst, int rows) {
+  HIP_TRY(hipMemcpyAsync(h->stage, src, sizeof(double) * (size_t)rows * h->batch, hipMemcpyHostToDevice, h->stream));
+  dim3 grid((rows + admm::T_TILE - 1) / admm::T_TILE, (h->pitch + admm::T_TILE - 1) / admm::T_TILE), block(admm::T_TILE * 8);
+  hipLaunchKernelGGL(admm::to_batch_minor_kernel, grid, block, 0, h->stream, h->stage, dst, h->batch, rows, h->pitch);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return ADMM_OK;
+}
+
+int download_transposed(admm_handle* h, const double* src, double* dst, int rows) {
+  dim3 grid((rows + admm::T_TILE - 1) / admm::T_TILE, (h->pitch + admm::T_TILE - 1) / admm::T_TILE), block(admm::T_TILE * 8);
+  hipLaunchKernelGGL(admm::from_batch_minor_kernel, grid, block, 0, h->stream, src, h->stage, h->batch, rows, h->pitch);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(dst, h->stage, sizeof(double) * (size_t)rows * h->batch, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return ADMM_OK;
+}
+
+bool finite_all(const double* a, size_t cnt) {
+  for (size_t i = 0; i < cnt; ++i)
+    if (!std::isfinite(a[i])) return false;
+  return true;
+}
+
+int validate_options(const admm_options* o) {
+  if (!(o->rho > 0.0) || !std::isfinite(o->rho)) return fail(ADMM_ERR_INVALID, "rho must be positive and finite");
+  if (!(o->alpha > 0.0 && o->alpha < 2.0)) return fail(ADMM_ERR_INVALID, "alpha must lie in (0, 2)");
+  if (!(o->eps_abs >= 0.0) || !(o->eps_rel >= 0.0)) return fail(ADMM_ERR_INVALID, "eps_abs / eps_rel must be >= 0");
+  if (o->max_iter < 1) return fail(ADMM_ERR_INVALID, "max_iter must be >= 1");
+  if (o->check_interval < 1) return fail(ADMM_ERR_INVALID, "check_interval must be >= 1");
+  if (o->segments < 0 || o->zrows < 0) return fail(ADMM_ERR_INVALID, "segments / zrows must be >= 0");
+  return ADMM_OK;
+}
+
+int validate_problem(const admm_problem* p) {
+  if (p->N < 1 || p->n < 1 || p->m < 1 || p->batch < 1) return fail(ADMM_ERR_INVALID, "N, n, m, batch must be positive");
+  if (!p->A || !p->B || !p->Q || !p->R || !p->QN || !p->x0 || !p->lo || !p->hi)
+    return fail(ADMM_ERR_INVALID, "A, B, Q, R, QN, x0, lo, hi must be non-NULL");
+  const int nb = p->n + p->m;
+  const size_t L = (size_t)p->N * nb;
+  if (L * (size_t)p->batch > ((size_t)1 << 40)) return fail(ADMM_ERR_INVALID, "problem too large");
+  if (L > (size_t)0x7fffffff) return fail(ADMM_ERR_INVALID, "L = N (n + m) exceeds 2^31 - 1");
+  const size_t nbnd = (size_t)nb * (p->stage_bounds ? p->N : 1);
+  for (size_t i = 0; i < nbnd; ++i) {
+    if (std::isnan(p->lo[i]) || std::isnan(p->hi[i])) return fail(ADMM_ERR_INVALID, "NaN in bounds");
+    if (p->lo[i] > p->hi[i]) return fail(ADMM_ERR_INVALID, "lo > hi at bound index " + std::to_string(i));
+    if (p->lo[i] == INFINITY || p->hi[i] == -INFINITY) return fail(ADMM_ERR_INVALID, "lo = +inf or hi = -inf");
+  }
+  if (!finite_all(p->x0, (size_t)p->n * p->batch)) return fail(ADMM_ERR_INVALID, "non-finite entry in x0");
+  if (p->q && !finite_all(p->q, L * p->batch)) return fail(ADMM_ERR_INVALID, "non-finite entry in q");
+  return ADMM_OK;
+}
+
+void destroy_graph(admm_handle* h) {
+  for (int v = 0; v < 2; ++v) {
+    if (h->graph_exec[v]) { (void)hipGraphExecDestroy(h->graph_exec[v]); h->graph_exec[v] = nullptr; }
+    if (h->graph[v]) { (void)hipGraphDestroy(h->graph[v]); h->graph[v] = nullptr; }
+  }
+}
+
+void release(admm_handle* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  destroy_graph(h);
+  double** bufs[] = {&h->w, &h->z, &h->y, &h->q, &h->x0, &h->dbuf, &h->tseg, &h->eseg, &h->tin, &h->xin,
+                     &h->part, &h->resid, &h->lo, &h->hi, &h->recB, &h->recF, &h->recS, &h->stage};
+  for (auto b : bufs)
+    if (*b) { (void)hipFree(*b); *b = nullptr; }
+  int** ibufs[] = {&h->seg_start, &h->status, &h->iters, &h->nconv};
+  for (auto b : ibufs)
+    if (*b) { (void)hipFree(*b); *b = nullptr; }
+  if (h->h_nconv) { (void)hipHostFree(h->h_nconv); h->h_nconv = nullptr; }
+  if (h->stream) { (void)hipStreamDestroy(h->stream); h->stream = nullptr; }
+  delete h;
+}
+
+template <typename T>
+int dalloc(T** p, size_t count) {
+  hipError_t e = hipMalloc((void**)p, sizeof(T) * (count ? count : 1));
+  if (e != hipSuccess) return fail(ADMM_ERR_ALLOC, std::string("hipMalloc failed: ") + hipGetErrorString(e));
+  return ADMM_OK;
+}
+
+int capture_iterations(admm_handle* h) {
+  destroy_graph(h);
+  for (int v = 0; v < 2; ++v) {
+    HIP_TRY(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    int rc = step_x(h);
+    if (!rc) rc = launch_z(h, v == 1);
+    if (!rc && v == 1) rc = launch_finalize(h, 0);
+    hipGraph_t g = nullptr;
+    hipError_t e = hipStreamEndCapture(h->stream, &g);
+    if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+    if (e != hipSuccess) return fail(ADMM_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+    h->graph[v] = g;
+    HIP_TRY(hipGraphInstantiate(&h->graph_exec[v], h->graph[v], nullptr, nullptr, 0));
+  }
+  return ADMM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void admm_default_options(admm_options* o) {
+  if (!o) return;
+  o->rho = 0.1;
+  o->alpha = 1.0;
+  o->eps_abs = 1e-6;
+  o->eps_rel = 1e-6;
+  o->max_iter = 4000;
+  o->check_interval = 10;
+  o->segments = 0;
+  o->device = -1;
+  o->zrows = 0;
+  o->flags = ADMM_FLAG_NONE;
+}
+
+const char* admm_last_error(void) { return g_err.c_str(); }
+int admm_abi_version(void) { return ADMM_HIP_ABI_VERSION; }
+
+int admm_device_count(void) {
+  int c = 0;
+  if (hipGetDeviceCount(&c) != hipSuccess) return 0;
+  return c;
+}
+
+int admm_record_sizes(int32_t n, int32_t m, int32_t* rb, int32_t* rf, int32_t* rs) {
+  if (n < 1 || m < 1) return fail(ADMM_ERR_INVALID, "n, m must be positive");
+  if (rb) *rb = admm::rec_b_size(n, m);
+  if (rf) *rf = admm::rec_f_size(n, m);
+  if (rs) *rs = admm::rec_s_size(n);
+  return ADMM_OK;
+}
+
+int admm_host_factor(const admm_problem* p, double rho, int32_t segments, double* K, double* Sinv,
+                     double* recB, double* recF, double* recS, int32_t* seg_start) {
+  if (!p) return fail(ADMM_ERR_INVALID, "NULL problem");
+  admm::Factor f;
+  std::string err;
+  int rc = admm::factorise(*p, rho, segments, f, err);
+  if (rc) return fail(rc, err);
+  if (K) std::memcpy(K, f.K.data(), sizeof(double) * f.K.size());
+  if (Sinv) std::memcpy(Sinv, f.Sinv.data(), sizeof(double) * f.Sinv.size());
+  if (recB) std::memcpy(recB, f.recB.data(), sizeof(double) * f.recB.size());
+  if (recF) std::memcpy(recF, f.recF.data(), sizeof(double) * f.recF.size());
+  if (recS) std::memcpy(recS, f.recS.data(), sizeof(double) * f.recS.size());
+  if (seg_start) std::memcpy(seg_start, f.seg_start.data(), sizeof(int32_t) * f.seg_start.size());
+  return ADMM_OK;
+}
+
+int admm_setup(admm_handle** out, const admm_problem* p, const admm_options* o_in) {
+  if (!out || !p) return fail(ADMM_ERR_INVALID, "NULL argument");
+  *out = nullptr;
+  admm_options o;
+  if (o_in) o = *o_in; else admm_default_options(&o);
+  int rc;
+  if ((rc = validate_options(&o))) return rc;
+  if ((rc = validate_problem(p))) return rc;
+  if (!dims_supported(p->n, p->m))
+    return fail(ADMM_ERR_UNSUPPORTED, "(n, m) = (" + std::to_string(p->n) + ", " + std::to_string(p->m) +
+                                          ") has no compiled kernel; supported: " + supported_list());
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+    return fail(ADMM_ERR_NO_DEVICE, "no HIP device visible: libadmm_hip has no CPU fallback");
+  int dev = o.device;
+  if (dev < 0) HIP_TRY(hipGetDevice(&dev));
+  if (dev >= ndev) return fail(ADMM_ERR_INVALID, "device ordinal out of range");
+  HIP_TRY(hipSetDevice(dev));
+
+  admm_handle* h = new admm_handle();
+  h->device = dev;
+  h->opt = o;
+  h->N = p->N; h->n = p->n; h->m = p->m; h->nb = p->n + p->m; h->batch = p->batch;
+  h->L = p->N * h->nb;
+  h->pitch = ((p->batch + 63) / 64) * 64;
+  h->has_q = p->q != nullptr;
+
+  // x-update segments: enough (column-wave x segment) pairs for >= 2 waves per SIMD.
+  {
+    int S = o.segments;
+    if (S == 0) {
+      const int wave_cols = h->pitch / 64;
+      S = (2048 + wave_cols - 1) / wave_cols;
+      const int max_by_len = h->N >= 16 ? h->N / 8 : 1;
+      if (S > max_by_len) S = max_by_len;
+      if (S > 64) S = 64;
+    }
+    if (S > h->N) S = h->N;
+    if (S < 1) S = 1;
+    h->S = S;
+  }
+  // z-kernel chunking: ~2048 workgroups, rows per chunk a multiple of 4.
+  {
+    int zr = o.zrows;
+    if (zr == 0) {
+      const int col_groups = (h->pitch / 2 + Z_THREADS - 1) / Z_THREADS;
+      int chunks = (2048 + col_groups - 1) / col_groups;
+      zr = (h->L + chunks - 1) / chunks;
+      zr = ((zr + 3) / 4) * 4;
+      if (zr < 4) zr = 4;
+    }
+    h->zrows = zr;
+    h->zchunks = (h->L + zr - 1) / zr;
+  }
+
+  std::string err;
+  rc = admm::factorise(*p, o.rho, h->S, h->fac, err);
+  if (rc) { release(h); return fail(rc, err); }
+  h->S = h->fac.S;
+
+#define TRY_RELEASE(expr) do { int rc_ = (expr); if (rc_) { std::string keep = g_err; release(h); g_err = keep; return rc_; } } while (0)
+#define HIP_TRY_RELEASE(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { release(h); return fail(ADMM_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } } while (0)
+
+  HIP_TRY_RELEASE(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  const size_t P = h->pitch, L = h->L;
+  TRY_RELEASE(dalloc(&h->w, L * P));
+  TRY_RELEASE(dalloc(&h->z, L * P));
+  TRY_RELEASE(dalloc(&h->y, L * P));
+  if (h->has_q) TRY_RELEASE(dalloc(&h->q, L * P));
+  TRY_RELEASE(dalloc(&h->x0, (size_t)h->n * P));
+  TRY_RELEASE(dalloc(&h->dbuf, (size_t)h->N * h->m * P));
+  TRY_RELEASE(dalloc(&h->tseg, (size_t)h->S * h->n * P));
+  TRY_RELEASE(dalloc(&h->eseg, (size_t)h->S * h->n * P));
+  TRY_RELEASE(dalloc(&h->tin, (size_t)h->S * h->n * P));
+  TRY_RELEASE(dalloc(&h->xin, (size_t)h->S * h->n * P));
+  TRY_RELEASE(dalloc(&h->part, (size_t)h->zchunks * 5 * P));
+  TRY_RELEASE(dalloc(&h->resid, 5 * P));
+  TRY_RELEASE(dalloc(&h->lo, L));
+  TRY_RELEASE(dalloc(&h->hi, L));
+  TRY_RELEASE(dalloc(&h->recB, h->fac.recB.size()));
+  TRY_RELEASE(dalloc(&h->recF, h->fac.recF.size()));
+  TRY_RELEASE(dalloc(&h->recS, h->fac.recS.size()));
+  TRY_RELEASE(dalloc(&h->seg_start, h->fac.seg_start.size()));
+  TRY_RELEASE(dalloc(&h->status, P));
+  TRY_RELEASE(dalloc(&h->iters, P));
+  TRY_RELEASE(dalloc(&h->nconv, 1));
+  TRY_RELEASE(dalloc(&h->stage, L * (size_t)h->batch));
+  HIP_TRY_RELEASE(hipHostMalloc((void**)&h->h_nconv, sizeof(int), hipHostMallocDefault));
+
+  HIP_TRY_RELEASE(hipMemsetAsync(h->w, 0, sizeof(double) * L * P, h->stream));
+  HIP_TRY_RELEASE(hipMemsetAsync(h->z, 0, sizeof(double) * L * P, h->stream));
+  HIP_TRY_RELEASE(hipMemsetAsync(h->y, 0, sizeof(double) * L * P, h->stream));
+  HIP_TRY_RELEASE(hipMemsetAsync(h->dbuf, 0, sizeof(double) * (size_t)h->N * h->m * P, h->stream));
+  HIP_TRY_RELEASE(hipMemsetAsync(h->part, 0, sizeof(double) * (size_t)h->zchunks * 5 * P, h->stream));
+  HIP_TRY_RELEASE(hipMemsetAsync(h->resid, 0, sizeof(double) * 5 * P, h->stream));
+  HIP_TRY_RELEASE(hipMemsetAsync(h->status, 0, sizeof(int) * P, h->stream));
+  HIP_TRY_RELEASE(hipMemsetAsync(h->iters, 0, sizeof(int) * P, h->stream));
+
+  // bounds expanded to one entry per stacked row
+  {
+    std::vector<double> lo(L), hi(L);
+    for (size_t e = 0; e < L; ++e) {
+      const size_t blk = e / h->nb, row = e % h->nb;
+      lo[e] = p->lo[(p->stage_bounds ? blk * h->nb : 0) + row];
+      hi[e] = p->hi[(p->stage_bounds ? blk * h->nb : 0) + row];
+    }
+    HIP_TRY_RELEASE(hipMemcpy(h->lo, lo.data(), sizeof(double) * L, hipMemcpyHostToDevice));
+    HIP_TRY_RELEASE(hipMemcpy(h->hi, hi.data(), sizeof(double) * L, hipMemcpyHostToDevice));
+  }
+  HIP_TRY_RELEASE(hipMemcpy(h->recB, h->fac.recB.data(), sizeof(double) * h->fac.recB.size(), hipMemcpyHostToDevice));
+  HIP_TRY_RELEASE(hipMemcpy(h->recF, h->fac.recF.data(), sizeof(double) * h->fac.recF.size(), hipMemcpyHostToDevice));
+  HIP_TRY_RELEASE(hipMemcpy(h->recS, h->fac.recS.data(), sizeof(double) * h->fac.recS.size(), hipMemcpyHostToDevice));
+  HIP_TRY_RELEASE(hipMemcpy(h->seg_start, h->fac.seg_start.data(), sizeof(int32_t) * h->fac.seg_start.size(), hipMemcpyHostToDevice));
+  TRY_RELEASE(upload_transposed(h, p->x0, h->x0, h->n));
+  if (h->has_q) TRY_RELEASE(upload_transposed(h, p->q, h->q, h->L));
+  HIP_TRY_RELEASE(hipStreamSynchronize(h->stream));
+#undef TRY_RELEASE
+#undef HIP_TRY_RELEASE
+  *out = h;
+  return ADMM_OK;
+}
+
+int admm_update_instances(admm_handle* h, const double* x0, const double* q) {
+  if (!h) return fail(ADMM_ERR_INVALID, "NULL handle");
+  HIP_TRY(hipSetDevice(h->device));
+  int rc;
+  if (x0) {
+    if (!finite_all(x0, (size_t)h->n * h->batch)) return fail(ADMM_ERR_INVALID, "non-finite entry in x0");
+    if ((rc = upload_transposed(h, x0, h->x0, h->n))) return rc;
+  }
+  if (q) {
+    if (!h->has_q) return fail(ADMM_ERR_INVALID, "handle was set up without q; cannot add one later");
+    if (!finite_all(q, (size_t)h->L * h->batch)) return fail(ADMM_ERR_INVALID, "non-finite entry in q");
+    if ((rc = upload_transposed(h, q, h->q, h->L))) return rc;
+  }
+  return ADMM_OK;
+}
+
+int admm_set_state(admm_handle* h, const double* w, const double* z, const double* y) {
+  if (!h) return fail(ADMM_ERR_INVALID, "NULL handle");
+  HIP_TRY(hipSetDevice(h->device));
+  int rc;
+  if (w && (rc = upload_transposed(h, w, h->w, h->L))) return rc;
+  if (z && (rc = upload_transposed(h, z, h->z, h->L))) return rc;
+  if (y && (rc = upload_transposed(h, y, h->y, h->L))) return rc;
+  return ADMM_OK;
+}
+
+int admm_step_x(admm_handle* h) {
+  if (!h) return fail(ADMM_ERR_INVALID, "NULL handle");
+  HIP_TRY(hipSetDevice(h->device));
+  int rc = step_x(h);
+  if (rc) return rc;
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return ADMM_OK;
+}
+
+int admm_step_z(admm_handle* h, int32_t residuals) {
+  if (!h) return fail(ADMM_ERR_INVALID, "NULL handle");
+  HIP_TRY(hipSetDevice(h->device));
+  int rc = launch_z(h, residuals != 0);
+  if (rc) return rc;
+  if (residuals) {
+    launch_finalize(h, 0);
+    h->resid_valid = true;
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return ADMM_OK;
+}
+
+int admm_run(admm_handle* h, int32_t iters, int32_t residual_every) {
+  if (!h) return fail(ADMM_ERR_INVALID, "NULL handle");
+  if (iters < 0 || residual_every < 0) return fail(ADMM_ERR_INVALID, "iters / residual_every must be >= 0");
+  HIP_TRY(hipSetDevice(h->device));
+  const bool use_graph = !(h->opt.flags & ADMM_FLAG_NO_GRAPH);
+  if (use_graph && !h->graph_exec[0]) {
+    int rc = capture_iterations(h);
+    if (rc) return rc;
+  }
+  for (int it = 1; it <= iters; ++it) {
+    const bool resid = residual_every > 0 && (it % residual_every == 0);
+    if (use_graph) {
+      HIP_TRY(hipGraphLaunch(h->graph_exec[resid ? 1 : 0], h->stream));
+    } else {
+      int rc = step_x(h);
+      if (!rc) rc = launch_z(h, resid);
+      if (!rc && resid) rc = launch_finalize(h, 0);
+      if (rc) return rc;
+    }
+    if (resid) h->resid_valid = true;
+  }
+  HIP_TRY(hipGetLastError());
+  return ADMM_OK;
+}
+
+int admm_iterate(admm_handle* h, int32_t iters) { return admm_run(h, iters, 0); }
+
+int admm_sync(admm_handle* h) {
+  if (!h) return fail(ADMM_ERR_INVALID, "NULL handle");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return ADMM_OK;
+}
+
+int admm_solve(admm_handle* h, const double* z0, const double* y0, admm_info* info) {
+  if (!h) return fail(ADMM_ERR_INVALID, "NULL handle");
+  HIP_TRY(hipSetDevice(h->device));
+  const auto t0 = std::chrono::steady_clock::now();
+  int rc;
+  if ((rc = admm_set_state(h, nullptr, z0, y0))) return rc;
+  const size_t P = h->pitch;
+  HIP_TRY(hipMemsetAsync(h->status, 0, sizeof(int) * P, h->stream));
+  {
+    std::vector<int> init(P, h->opt.max_iter);
+    HIP_TRY(hipMemcpyAsync(h->iters, init.data(), sizeof(int) * P, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+  }
+  const bool use_graph = !(h->opt.flags & ADMM_FLAG_NO_GRAPH);
+  if (use_graph && !h->graph_exec[0] && (rc = capture_iterations(h))) return rc;
+  int it = 0, nconv = 0;
+  const int ci = h->opt.check_interval;
+  for (it = 1; it <= h->opt.max_iter; ++it) {
+    const bool check = (it % ci == 0) || it == h->opt.max_iter;
+    if (!check && use_graph) {
+      HIP_TRY(hipGraphLaunch(h->graph_exec[0], h->stream));
+      continue;
+    }
+    if ((rc = step_x(h))) return rc;
+    if ((rc = launch_z(h, check))) return rc;
+    if (check) {
+      HIP_TRY(hipMemsetAsync(h->nconv, 0, sizeof(int), h->stream));
+      launch_finalize(h, it);
+      HIP_TRY(hipMemcpyAsync(h->h_nconv, h->nconv, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+      HIP_TRY(hipStreamSynchronize(h->stream));
+      nconv = *h->h_nconv;
+      h->resid_valid = true;
+      if (nconv >= h->batch) break;
+    }
+  }
+  if (it > h->opt.max_iter) it = h->opt.max_iter;
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  h->iters_run = it;
+  if (info) {
+    info->iters_run = it;
+    info->n_converged = nconv;
+    std::vector<double> rs(2 * P);
+    HIP_TRY(hipMemcpy(rs.data(), h->resid, sizeof(double) * 2 * P, hipMemcpyDeviceToHost));
+    double mr = 0, ms = 0;
+    for (int b = 0; b < h->batch; ++b) {
+      if (rs[b] > mr) mr = rs[b];
+      if (rs[P + b] > ms) ms = rs[P + b];
+    }
+    info->max_r = mr;
+    info->max_s = ms;
+    info->solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  }
+  return ADMM_OK;
+}
+
+int admm_get_residuals(admm_handle* h, double* r, double* s, double* nw, double* nz, double* ny) {
+  if (!h) return fail(ADMM_ERR_INVALID, "NULL handle");
+  if (!h->resid_valid) return fail(ADMM_ERR_INVALID, "no residual-evaluating z step has run yet");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  double* dst[5] = {r, s, nw, nz, ny};
+  for (int v = 0; v < 5; ++v)
+    if (dst[v]) HIP_TRY(hipMemcpy(dst[v], h->resid + (size_t)v * h->pitch, sizeof(double) * h->batch, hipMemcpyDeviceToHost));
+  return ADMM_OK;
+}
+
+int admm_get(admm_handle* h, double* w, double* z, double* y) {
+  if (!h) return fail(ADMM_ERR_INVALID, "NULL handle");
+  HIP_TRY(hipSetDevice(h->device));
+  int rc;
+  if (w && (rc = download_transposed(h, h->w, w, h->L))) return rc;
+  if (z && (rc = download_transposed(h, h->z, z, h->L))) return rc;
+  if (y && (rc = download_transposed(h, h->y, y, h->L))) return rc;
+  return ADMM_OK;
+}
+
+int admm_get_info(admm_handle* h, int32_t* iters, int32_t* status, double* r, double* s) {
+  if (!h) return fail(ADMM_ERR_INVALID, "NULL handle");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (iters) HIP_TRY(hipMemcpy(iters, h->iters, sizeof(int32_t) * h->batch, hipMemcpyDeviceToHost));
+  if (status) HIP_TRY(hipMemcpy(status, h->status, sizeof(int32_t) * h->batch, hipMemcpyDeviceToHost));
+  if (r) HIP_TRY(hipMemcpy(r, h->resid, sizeof(double) * h->batch, hipMemcpyDeviceToHost));
+  if (s) HIP_TRY(hipMemcpy(s, h->resid + h->pitch, sizeof(double) * h->batch, hipMemcpyDeviceToHost));
+  return ADMM_OK;
+}
+
+int admm_profile(admm_handle* h, int32_t iters, int32_t residuals, double ms[5]) {
+  if (!h || !ms) return fail(ADMM_ERR_INVALID, "NULL argument");
+  if (iters < 1 || iters > 4096) return fail(ADMM_ERR_INVALID, "iters must lie in [1, 4096]");
+  HIP_TRY(hipSetDevice(h->device));
+  std::vector<hipEvent_t> ev((size_t)iters * 5);
+  for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
+  int rc = ADMM_OK;
+  for (int it = 0; it < iters && !rc; ++it) {
+    hipEvent_t* e = &ev[(size_t)it * 5];
+    HIP_TRY(hipEventRecord(e[0], h->stream));
+    rc = launch_xb(h);
+    HIP_TRY(hipEventRecord(e[1], h->stream));
+    if (!rc) rc = launch_xscan(h);
+    HIP_TRY(hipEventRecord(e[2], h->stream));
+    if (!rc) rc = launch_xf(h);
+    HIP_TRY(hipEventRecord(e[3], h->stream));
+    if (!rc) rc = launch_z(h, residuals != 0);
+    HIP_TRY(hipEventRecord(e[4], h->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  for (int v = 0; v < 5; ++v) ms[v] = 0.0;
+  if (!rc) {
+    for (int it = 0; it < iters; ++it) {
+      hipEvent_t* e = &ev[(size_t)it * 5];
+      for (int v = 0; v < 4; ++v) {
+        float t = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t, e[v], e[v + 1]));
+        ms[v] += t;
+      }
+      float t = 0.f;
+      HIP_TRY(hipEventElapsedTime(&t, e[0], e[4]));
+      ms[4] += t;
+    }
+    for (int v = 0; v < 5; ++v) ms[v] /= iters;
+  }
+  for (auto& e : ev) (void)hipEventDestroy(e);
+  return rc;
+}
+
+int admm_get_geometry(admm_handle* h, int32_t* pitch, int32_t* segs, int32_t* zrows, int32_t* zchunks) {
+  if (!h) return fail(ADMM_ERR_INVALID, "NULL handle");
+  if (pitch) *pitch = h->pitch;
+  if (segs) *segs = h->S;
+  if (zrows) *zrows = h->zrows;
+  if (zchunks) *zchunks = h->zchunks;
+  return ADMM_OK;
+}
+
+void admm_free(admm_handle* h) { release(h); }
+
+}  // extern "C"

@@ -1,0 +1,53 @@
+// admm_factor.hpp -- host-side (fp64) pre-factorisation of the x-update's KKT
+// system and the per-segment transfer matrices of the parallel-in-time sweep.
+// DESIGN.md §2.2 (Riccati form) and §4.2 (segment algebra).  No reference
+// counterpart exists (/root/reference is README.md:1-2 + LICENSE).
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/admm_hip.h"
+
+namespace admm {
+
+// Packed per-stage records, laid out in the order the kernels consume them.
+// All row-major, fp64.
+//
+// Backward record (stage k), RB doubles:
+//   AT  [n][n]   AT[i][l]  = A_k[l][i]
+//   BT  [m][n]   BT[j][i]  = B_k[i][j]
+//   Si  [m][m]   inverse of S_k = R + rho I + B_k' P_{k+1} B_k
+//   KT  [n][m]   KT[i][j]  = K_k[j][i]
+//   Om  [n][m]   Omega_k   = -(Acl_{b-1} ... Acl_{k+1}) B_k     (b = segment end)
+// Forward record (stage k), RF doubles:
+//   Psi [m][n]   Psi_k     = Si_k B_k' (Acl_{b-1} ... Acl_{k+1})'
+//   K   [m][n]
+//   A   [n][n]
+//   B   [n][m]
+// Segment record (segment s), 3 n*n doubles:
+//   Phi [n][n]   (Acl_{b-1} ... Acl_a)'          tail map   t_out = t_out0 + Phi t_in
+//   Xi  [n][n]   sum_k Omega_k Psi_k            x_out += Xi t_in
+//   Th  [n][n]   Acl_{b-1} ... Acl_a            x_out += Th x_in
+struct Factor {
+  int N = 0, n = 0, m = 0, S = 0;
+  int RB = 0, RF = 0, RS = 0;
+  std::vector<int32_t> seg_start;   // S + 1 entries, seg_start[S] = N
+  std::vector<double> recB;         // N * RB
+  std::vector<double> recF;         // N * RF
+  std::vector<double> recS;         // S * RS
+  std::vector<double> K;            // N * m * n (for tests)
+  std::vector<double> Sinv;         // N * m * m (for tests)
+};
+
+inline int rec_b_size(int n, int m) { return n * n + m * n + m * m + n * m + n * m; }
+inline int rec_f_size(int n, int m) { return m * n + m * n + n * n + n * m; }
+inline int rec_s_size(int n) { return 3 * n * n; }
+
+// Validates nothing about the batch; only dynamics/weights.  Returns an
+// admm_status; err receives a message on failure.
+int factorise(const admm_problem& p, double rho, int segments, Factor& out, std::string& err);
+
+}  // namespace admm

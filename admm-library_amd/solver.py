@@ -1,0 +1,264 @@
+"""ctypes binding of libadmm_hip.so and the host-side solver front end.
+
+Mirrors the entry-point surface of include/admm_hip.h one to one
+(`admm_setup` / `admm_solve` / ... keep their C names as methods or module
+functions).  The reference defines no such surface (README.md:1-2 only), so
+the names are this repository's own; a MATLAB caller gets the same surface
+through matlab/admm_mex.cpp.
+
+No CPU fallback: if the shared library is missing this module raises at load
+time, and without a GPU `admm_setup` fails with ADMM_ERR_NO_DEVICE.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import dataclasses
+import os
+from typing import Optional
+
+import numpy as np
+
+from . import _abi
+from ._abi import CInfo, COptions, CProblem, c_double_p, c_int32_p, dptr, iptr
+from .problems import Problem
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+_LIB_NAME = "libadmm_hip.so"
+_lib = None
+
+
+class AdmmError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"{_abi.STATUS_NAMES.get(code, code)}: {msg}")
+        self.code = code
+
+
+def library_path() -> str:
+    return os.path.join(_PKG_DIR, _LIB_NAME)
+
+
+# name -> (restype, argtypes); every symbol include/admm_hip.h declares.
+_SIGNATURES = {
+    "admm_default_options": (None, [C.POINTER(COptions)]),
+    "admm_setup": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(CProblem), C.POINTER(COptions)]),
+    "admm_update_instances": (C.c_int, [C.c_void_p, c_double_p, c_double_p]),
+    "admm_set_state": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p]),
+    "admm_solve": (C.c_int, [C.c_void_p, c_double_p, c_double_p, C.POINTER(CInfo)]),
+    "admm_iterate": (C.c_int, [C.c_void_p, C.c_int32]),
+    "admm_run": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
+    "admm_sync": (C.c_int, [C.c_void_p]),
+    "admm_step_x": (C.c_int, [C.c_void_p]),
+    "admm_step_z": (C.c_int, [C.c_void_p, C.c_int32]),
+    "admm_get_residuals": (C.c_int, [C.c_void_p] + [c_double_p] * 5),
+    "admm_get": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p]),
+    "admm_get_info": (C.c_int, [C.c_void_p, c_int32_p, c_int32_p, c_double_p, c_double_p]),
+    "admm_profile": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, c_double_p]),
+    "admm_get_geometry": (C.c_int, [C.c_void_p] + [c_int32_p] * 4),
+    "admm_free": (None, [C.c_void_p]),
+    "admm_last_error": (C.c_char_p, []),
+    "admm_abi_version": (C.c_int, []),
+    "admm_device_count": (C.c_int, []),
+    "admm_record_sizes": (C.c_int, [C.c_int32, C.c_int32, c_int32_p, c_int32_p, c_int32_p]),
+    "admm_host_factor": (C.c_int, [C.POINTER(CProblem), C.c_double, C.c_int32, c_double_p, c_double_p,
+                                   c_double_p, c_double_p, c_double_p, c_int32_p]),
+}
+
+
+def load_library(path: Optional[str] = None):
+    """Load libadmm_hip.so (built in-tree by __graft_entry__.build()).  Raises if absent."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or library_path()
+    if not os.path.exists(p):
+        raise FileNotFoundError(
+            f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    lib = C.CDLL(p)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)      # AttributeError if a declared symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    if lib.admm_abi_version() != _abi.ABI_VERSION:
+        raise RuntimeError("libadmm_hip.so ABI version mismatch")
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _check(lib, rc: int):
+    if rc != 0:
+        raise AdmmError(rc, lib.admm_last_error().decode())
+
+
+def device_count() -> int:
+    return int(load_library().admm_device_count())
+
+
+@dataclasses.dataclass
+class Options:
+    rho: float = 0.1
+    alpha: float = 1.0
+    eps_abs: float = 1e-6
+    eps_rel: float = 1e-6
+    max_iter: int = 4000
+    check_interval: int = 10
+    segments: int = 0
+    device: int = -1
+    zrows: int = 0
+    flags: int = 0
+
+    def to_c(self) -> COptions:
+        return _abi.make_options(**dataclasses.asdict(self))
+
+
+@dataclasses.dataclass
+class SolveInfo:
+    iters_run: int
+    n_converged: int
+    max_r: float
+    max_s: float
+    solve_ms: float
+    iters: np.ndarray
+    status: np.ndarray
+    r: np.ndarray
+    s: np.ndarray
+
+
+class Solver:
+    """One handle = one batch of QPs on one GPU."""
+
+    def __init__(self, problem: Problem, options: Optional[Options] = None):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        self.problem = problem
+        self.options = options or Options()
+        cp, keep = _abi.marshal_problem(problem)
+        co = self.options.to_c()
+        _check(self._lib, self._lib.admm_setup(C.byref(self._h), C.byref(cp), C.byref(co)))
+        del keep
+        self.batch, self.L = problem.batch, problem.L
+
+    # -- lifetime ---------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.admm_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- helpers ----------------------------------------------------------
+    def _vec(self, a, rows=None):
+        if a is None:
+            return None
+        a = np.ascontiguousarray(a, np.float64)
+        if a.shape != (self.batch, rows or self.L):
+            raise ValueError(f"expected shape {(self.batch, rows or self.L)}, got {a.shape}")
+        return a
+
+    # -- C ABI, one method per entry point -------------------------------
+    def update_instances(self, x0=None, q=None):
+        x0 = self._vec(x0, self.problem.n)
+        q = self._vec(q)
+        _check(self._lib, self._lib.admm_update_instances(self._h, dptr(x0), dptr(q)))
+
+    def set_state(self, w=None, z=None, y=None):
+        w, z, y = self._vec(w), self._vec(z), self._vec(y)
+        _check(self._lib, self._lib.admm_set_state(self._h, dptr(w), dptr(z), dptr(y)))
+
+    def solve(self, z0=None, y0=None) -> SolveInfo:
+        z0, y0 = self._vec(z0), self._vec(y0)
+        ci = CInfo()
+        _check(self._lib, self._lib.admm_solve(self._h, dptr(z0), dptr(y0), C.byref(ci)))
+        iters = np.empty(self.batch, np.int32)
+        status = np.empty(self.batch, np.int32)
+        r = np.empty(self.batch)
+        s = np.empty(self.batch)
+        _check(self._lib, self._lib.admm_get_info(self._h, iptr(iters), iptr(status), dptr(r), dptr(s)))
+        return SolveInfo(ci.iters_run, ci.n_converged, ci.max_r, ci.max_s, ci.solve_ms, iters, status, r, s)
+
+    def iterate(self, iters: int, sync: bool = True):
+        _check(self._lib, self._lib.admm_iterate(self._h, int(iters)))
+        if sync:
+            self.sync()
+
+    def run(self, iters: int, residual_every: int = 0, sync: bool = True):
+        _check(self._lib, self._lib.admm_run(self._h, int(iters), int(residual_every)))
+        if sync:
+            self.sync()
+
+    def sync(self):
+        _check(self._lib, self._lib.admm_sync(self._h))
+
+    def step_x(self):
+        _check(self._lib, self._lib.admm_step_x(self._h))
+
+    def step_z(self, residuals: bool = False):
+        _check(self._lib, self._lib.admm_step_z(self._h, int(bool(residuals))))
+
+    def residuals(self):
+        out = [np.empty(self.batch) for _ in range(5)]
+        _check(self._lib, self._lib.admm_get_residuals(self._h, *[dptr(o) for o in out]))
+        return tuple(out)
+
+    def get(self, w=True, z=True, y=True):
+        outs = [np.empty((self.batch, self.L)) if f else None for f in (w, z, y)]
+        _check(self._lib, self._lib.admm_get(self._h, *[dptr(o) for o in outs]))
+        return tuple(outs)
+
+    def profile(self, iters: int, residuals: bool = True):
+        ms = np.zeros(5)
+        _check(self._lib, self._lib.admm_profile(self._h, int(iters), int(bool(residuals)), dptr(ms)))
+        return {"xb_ms": ms[0], "xscan_ms": ms[1], "xf_ms": ms[2], "zdual_ms": ms[3], "iter_ms": ms[4]}
+
+    def geometry(self):
+        v = [C.c_int32() for _ in range(4)]
+        _check(self._lib, self._lib.admm_get_geometry(self._h, *[C.byref(x) for x in v]))
+        return {"pitch": v[0].value, "segments": v[1].value, "zrows": v[2].value, "zchunks": v[3].value}
+
+
+def admm_setup(problem: Problem, options: Optional[Options] = None) -> Solver:
+    """admm_setup of the C ABI: validate, factor the KKT system, upload."""
+    return Solver(problem, options)
+
+
+def admm_solve(problem_or_solver, options: Optional[Options] = None, z0=None, y0=None):
+    """One-call front end: setup (if given a Problem) + solve + read-out.
+    Returns (w, z, y, info)."""
+    own = not isinstance(problem_or_solver, Solver)
+    s = Solver(problem_or_solver, options) if own else problem_or_solver
+    try:
+        info = s.solve(z0, y0)
+        w, z, y = s.get()
+    finally:
+        if own:
+            s.close()
+    return w, z, y, info
+
+
+def host_factor(problem: Problem, rho: float, segments: int):
+    """Host-only: the packed factor records exactly as admm_setup uploads them
+    (no GPU needed).  Used by the CPU tests of the segment algebra."""
+    lib = load_library()
+    cp, keep = _abi.marshal_problem(problem)
+    N, n, m = problem.N, problem.n, problem.m
+    S = max(1, min(segments, N))
+    rb, rf, rs = C.c_int32(), C.c_int32(), C.c_int32()
+    _check(lib, lib.admm_record_sizes(n, m, C.byref(rb), C.byref(rf), C.byref(rs)))
+    K = np.empty((N, m, n)); Sinv = np.empty((N, m, m))
+    recB = np.empty((N, rb.value)); recF = np.empty((N, rf.value)); recS = np.empty((S, rs.value))
+    seg = np.empty(S + 1, np.int32)
+    _check(lib, lib.admm_host_factor(C.byref(cp), float(rho), S, dptr(K), dptr(Sinv), dptr(recB),
+                                     dptr(recF), dptr(recS), iptr(seg)))
+    del keep
+    return {"K": K, "Sinv": Sinv, "recB": recB, "recF": recF, "recS": recS, "seg_start": seg}

@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""bench.py -- ADMM iterations/sec on the BASELINE.json workload.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (config.workload): BASELINE.json configs[2] -- a batch of 4096
+independent N=1000, n=6, m=3 Clohessy-Wiltshire rendezvous QPs per GPU, fp64,
+synthetic inputs from admm_library_amd.cw_rendezvous (seeded), resident in HBM
+before the timed region.  For N > 1 GPUs the global batch is 4096 * N QPs,
+sharded contiguously (weak scaling, no data-path collective: QPs are
+independent).
+
+A "step" = one batch-iteration over the rank's shard: x-update (backward
+sweep, segment scan, forward rollout) + the fused z-update / dual ascent /
+residual-partials kernel + the residual finalise kernel -- i.e. every
+iteration evaluates the residuals on the device (check_interval = 1), which is
+the most expensive honest form of the iteration.  `value` = QP-iterations/s
+summed over all ranks.
+
+Extra objects on the JSON line:
+  roofline     -- the fused z/dual/residual kernel: 40 B per stacked element
+                  (3 reads + 2 writes, fp64) x L x pitch per launch, divided by
+                  its average launch duration measured with HIP events on the
+                  library's own stream (admm_profile).
+  cpu_baseline -- the C/OpenMP CPU oracle (kind "port": the reference ships no
+                  code) on a bounded sample of the same workload, rank 0, N=1.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
+BYTES_PER_ELEM_ZDUAL = 40       # w, y, z read; z+, y+ written; fp64
+BYTES_PER_ELEM_ZPLAIN = 32      # non-residual form: w, y read; z+, y+ written
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=4096, help="QPs per GPU")
+    ap.add_argument("--horizon", type=int, default=1000)
+    ap.add_argument("--segments", type=int, default=0)
+    ap.add_argument("--zrows", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(N, target_s):
+    """Time the CPU oracle (C/OpenMP restatement) on a bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import admm_library_amd as pkg
+    import oracle_c
+    cores = oracle_c.max_threads()
+    sample_batch = max(cores * 4, 16)
+    p = pkg.cw_rendezvous(N=N, batch=sample_batch)
+    t0 = time.perf_counter()
+    oracle_c.solve(p, rho=0.05, max_iter=2, check_interval=1, stop=False, nthreads=cores)
+    t_cal = (time.perf_counter() - t0) / 2
+    iters = int(max(5, min(2000, target_s / max(t_cal, 1e-6))))
+    t0 = time.perf_counter()
+    oracle_c.solve(p, rho=0.05, max_iter=iters, check_interval=1, stop=False, nthreads=cores)
+    dt = time.perf_counter() - t0
+    return {"value": sample_batch * iters / dt, "unit": "QP-iterations/s", "cores": cores, "kind": "port",
+            "sample": f"{iters} iterations of {sample_batch} QPs (N={N}, n=6, m=3), C/OpenMP oracle, "
+                      f"residuals every iteration, {dt:.1f} s"}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    import numpy as np
+    import torch
+    import admm_library_amd as pkg
+
+    import __graft_entry__ as ge
+    if not os.path.exists(pkg.library_path()):
+        ge.build()
+    pkg.load_library()
+    if pkg.device_count() < 1:
+        raise SystemExit("bench.py: no HIP device visible; the solver has no CPU fallback")
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # global problem = batch * world QPs; this rank's contiguous shard
+    gbatch = a.batch * world
+    lo_i, hi_i = pkg.shard_bounds(gbatch, world, rank)
+    full = pkg.cw_rendezvous(N=a.horizon, batch=hi_i - lo_i, seed0=pkg.SEED0 + lo_i)
+    opt = pkg.Options(rho=0.05, check_interval=1, segments=a.segments, zrows=a.zrows, device=local_rank)
+    solver = pkg.Solver(full, opt)
+    geo = solver.geometry()
+
+    solver.run(a.warmup, residual_every=1)
+    barrier()
+    t0 = time.perf_counter()
+    solver.run(a.steps, residual_every=1, sync=True)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    ms_per_step = dt / a.steps * 1e3
+    value = gbatch * a.steps / dt
+
+    # per-kernel timing on the library's stream (HIP events), residual form and plain form
+    prof = solver.profile(min(a.steps, 100), residuals=True)
+    prof_plain = solver.profile(min(a.steps, 100), residuals=False)
+    L = full.L
+    elems = L * geo["pitch"]
+    z_ms = prof["zdual_ms"]
+    achieved = BYTES_PER_ELEM_ZDUAL * elems / (z_ms * 1e-3) / 1e9
+    roofline = {"kernel": "zdual_kernel<RESID=true>", "bound": "hbm", "achieved": achieved,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "bytes_per_launch": BYTES_PER_ELEM_ZDUAL * elems, "avg_launch_ms": z_ms}
+
+    # mixed mode a solver would normally run: residuals every 10th iteration
+    solver.run(10, residual_every=10)
+    barrier()
+    t0 = time.perf_counter()
+    solver.run(a.steps, residual_every=10, sync=True)
+    barrier()
+    dt10 = time.perf_counter() - t0
+
+    if rank == 0:
+        out = {
+            "metric": "ADMM iterations/sec (fp64) at N=1000 n=6 batch=4096",
+            "value": value, "unit": "QP-iterations/s",
+            "batch_iterations_per_s": a.steps / dt,
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"configs[2]: batch of {a.batch} independent N={a.horizon} n=6 m=3 "
+                                   f"Clohessy-Wiltshire QPs per GPU, residuals every iteration",
+                       "N": a.horizon, "n": 6, "m": 3, "batch_per_gpu": a.batch, "global_batch": gbatch,
+                       "rho": 0.05, "sharding": f"batch/{world}, no collective in the iteration",
+                       **geo},
+            "roofline": roofline,
+            "kernels_ms": {**{k: round(v, 5) for k, v in prof.items()},
+                           "zdual_plain_ms": round(prof_plain["zdual_ms"], 5),
+                           "zdual_plain_GBs": BYTES_PER_ELEM_ZPLAIN * elems / (prof_plain["zdual_ms"] * 1e-3) / 1e9},
+            "check_interval_10": {"batch_iterations_per_s": a.steps / dt10,
+                                  "QP_iterations_per_s": a.batch * a.steps / dt10},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.horizon, a.cpu_seconds)
+        print(json.dumps(out))
+    solver.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

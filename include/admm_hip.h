@@ -1,0 +1,172 @@
+/* admm_hip.h -- C ABI of libadmm_hip.so: batched ADMM for box-constrained
+ * optimal-control QPs on MI355X (gfx950).
+ *
+ * Reference interface replaced: NONE EXISTS.  The reference snapshot is
+ * /root/reference/README.md:1-2 ("Implementation of Alternating Direction
+ * Method of Multipliers for astrodynamics problems") plus a LICENSE; it defines
+ * no MATLAB entry point, MEX gateway or FFI for this path.
+ * Every entry point below is therefore this repository's own specification of
+ * the "problem-setup / solver entry-point surface" BASELINE.json's north_star
+ * asks for; INTEGRATION.md shows the MEX and ctypes bindings over it.
+ *
+ * Conventions
+ *   - Plain C, no C++ or torch types cross this boundary.
+ *   - All real arrays are fp64.  Matrices are column-major (MATLAB-native).
+ *   - Per-QP vectors are "L x batch column-major": QP b occupies
+ *     [b*L, (b+1)*L).  The stacked variable of one QP is
+ *       w = (u_0, x_1, u_1, x_2, ..., u_{N-1}, x_N),  L = N*(n+m),
+ *     block k = (u_k, x_{k+1}).
+ *   - Every function returns an admm_status (0 = ok); admm_last_error() gives
+ *     a thread-local message for the last non-zero return.  No exceptions, no
+ *     exit().
+ *   - The library never keeps caller pointers after a call returns.
+ *   - A handle is bound to one GPU and is not thread-safe; distinct handles are.
+ */
+#ifndef ADMM_HIP_H
+#define ADMM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ADMM_HIP_ABI_VERSION 1
+
+typedef enum admm_status {
+  ADMM_OK = 0,
+  ADMM_ERR_INVALID = 1,      /* bad argument / problem data (NaN, lo > hi, sizes) */
+  ADMM_ERR_UNSUPPORTED = 2,  /* (n, m) outside the compiled kernel set, etc. */
+  ADMM_ERR_NO_DEVICE = 3,    /* no HIP device: the product path has no CPU fallback */
+  ADMM_ERR_HIP = 4,          /* a HIP runtime call failed */
+  ADMM_ERR_NUMERIC = 5,      /* factorisation failed (S_k not SPD) */
+  ADMM_ERR_ALLOC = 6
+} admm_status;
+
+/* minimise  1/2 sum_k [u_k' R u_k + x_{k+1}' Q_{k+1} x_{k+1}] + q' w
+ * s.t.      x_{k+1} = A_k x_k + B_k u_k,  x_0 given,   lo <= w <= hi
+ * Dynamics, weights and the box are shared by the whole batch; x0 and q are
+ * per instance. */
+typedef struct admm_problem {
+  int32_t N;              /* horizon (stages) */
+  int32_t n;              /* state dimension */
+  int32_t m;              /* control dimension */
+  int32_t batch;          /* number of independent QPs */
+  int32_t time_varying;   /* 0: A is n*n, B is n*m;  1: A is n*n*N, B is n*m*N */
+  int32_t stage_bounds;   /* 0: lo/hi are (m+n);     1: lo/hi are (m+n)*N */
+  const double* A;
+  const double* B;
+  const double* Q;        /* n*n symmetric PSD */
+  const double* R;        /* m*m symmetric PSD (R + rho I must be PD) */
+  const double* QN;       /* n*n symmetric PSD, terminal weight */
+  const double* x0;       /* n*batch */
+  const double* lo;       /* block order (u then x); -inf allowed */
+  const double* hi;       /* +inf allowed */
+  const double* q;        /* L*batch linear cost, or NULL for q = 0 */
+} admm_problem;
+
+typedef struct admm_options {
+  double rho;             /* > 0 */
+  double alpha;           /* over-relaxation in (0, 2); 1 = none */
+  double eps_abs;
+  double eps_rel;
+  int32_t max_iter;
+  int32_t check_interval; /* residuals + stop test every this many iterations */
+  int32_t segments;       /* parallel-in-time segments of the x-update; 0 = auto */
+  int32_t device;         /* HIP device ordinal; -1 = current device */
+  int32_t zrows;          /* rows per workgroup chunk in the z/dual kernel; 0 = auto */
+  int32_t flags;          /* ADMM_FLAG_* */
+} admm_options;
+
+#define ADMM_FLAG_NONE 0
+#define ADMM_FLAG_NO_GRAPH 1   /* launch kernels directly instead of replaying a hipGraph */
+
+typedef struct admm_info {
+  int32_t iters_run;      /* batch iterations executed by the last admm_solve */
+  int32_t n_converged;    /* QPs that met the stopping rule */
+  double  max_r;          /* max over the batch of the last checked primal residual */
+  double  max_s;          /* ... dual residual */
+  double  solve_ms;       /* wall time of the last admm_solve (host clock) */
+} admm_info;
+
+typedef struct admm_handle admm_handle;
+
+/* Defaults: rho 0.1, alpha 1, eps 1e-6/1e-6, max_iter 4000, check_interval 10. */
+void admm_default_options(admm_options* o);
+
+/* Validate, factor the x-update's KKT system on the host (fp64 Riccati sweep),
+ * allocate device memory, upload.  State starts at z = y = w = 0. */
+int admm_setup(admm_handle** out, const admm_problem* p, const admm_options* o);
+
+/* Replace the per-instance data (x0: n*batch, q: L*batch or NULL = keep) of an
+ * existing handle without refactoring. */
+int admm_update_instances(admm_handle* h, const double* x0, const double* q);
+
+/* Warm start / test hook: overwrite device state.  Any pointer may be NULL
+ * (left unchanged).  Each is L*batch. */
+int admm_set_state(admm_handle* h, const double* w, const double* z, const double* y);
+
+/* Run until every QP met the rule at a checked iteration, or max_iter.
+ * z0/y0 (L*batch) may be NULL: continue from the handle's current state. */
+int admm_solve(admm_handle* h, const double* z0, const double* y0, admm_info* info);
+
+/* Run exactly `iters` iterations, no residuals, no stop test (benchmark and
+ * iterate-parity path).  Asynchronous on the handle's stream; admm_sync waits. */
+int admm_iterate(admm_handle* h, int32_t iters);
+/* As admm_iterate, but every `residual_every`-th iteration (0 = never) runs the
+ * residual-evaluating form of the fused z kernel plus the residual finalise
+ * kernel on the device; still no host synchronisation and no early exit.
+ * residual_every = 1 is the benchmark's "step": x-update + fused
+ * z/dual/residual-partials + finalise, every iteration. */
+int admm_run(admm_handle* h, int32_t iters, int32_t residual_every);
+int admm_sync(admm_handle* h);
+
+/* Single steps, for kernel-level parity tests. */
+int admm_step_x(admm_handle* h);                    /* w <- x-update(z, y) */
+int admm_step_z(admm_handle* h, int32_t residuals); /* (z, y) <- z/dual update; residual partials if != 0 */
+
+/* Residual norms of the last residual-evaluating z-step: each array is `batch`
+ * long and may be NULL.  r = |w - z+|, s = rho |z+ - z|, nw = |w|, nz = |z+|,
+ * ny = rho |y+|. */
+int admm_get_residuals(admm_handle* h, double* r, double* s, double* nw, double* nz, double* ny);
+
+/* Copy out the state; any pointer may be NULL.  Each is L*batch. */
+int admm_get(admm_handle* h, double* w, double* z, double* y);
+
+/* Per-QP results of the last admm_solve: first checked iteration at which the
+ * rule held (max_iter if never), status (1 converged / 0 not), last r and s. */
+int admm_get_info(admm_handle* h, int32_t* iters, int32_t* status, double* r, double* s);
+
+/* Timing hook for bench.py: runs `iters` iterations with HIP events recorded
+ * on the handle's stream around each kernel.  ms[0..3] = average duration of
+ * {x-update backward, segment scan, x-update forward, fused z/dual/residual}
+ * per launch; ms[4] = average whole iteration.  `residuals` selects the
+ * residual-evaluating form of the z kernel. */
+int admm_profile(admm_handle* h, int32_t iters, int32_t residuals, double ms[5]);
+
+/* Geometry chosen at setup, for roofline accounting: pitch = padded batch,
+ * segs = x-update segments, zrows = rows per z-kernel chunk, zchunks. */
+int admm_get_geometry(admm_handle* h, int32_t* pitch, int32_t* segs, int32_t* zrows, int32_t* zchunks);
+
+void admm_free(admm_handle* h);
+
+/* Host-only helpers (no GPU needed): the fp64 pre-factorisation exactly as
+ * admm_setup uploads it, exposed so that the host logic can be tested on a
+ * CPU-only machine.  admm_record_sizes gives the per-stage / per-segment record
+ * lengths in doubles; admm_host_factor fills K (N*m*n), Sinv (N*m*m), both
+ * row-major, the packed backward / forward / segment records (N*rb, N*rf,
+ * segments*rs doubles; layouts in csrc/admm_factor.hpp) and seg_start
+ * (segments + 1).  Any output pointer may be NULL. */
+int admm_record_sizes(int32_t n, int32_t m, int32_t* rb, int32_t* rf, int32_t* rs);
+int admm_host_factor(const admm_problem* p, double rho, int32_t segments, double* K, double* Sinv,
+                     double* recB, double* recF, double* recS, int32_t* seg_start);
+
+const char* admm_last_error(void);
+int admm_abi_version(void);
+/* Number of HIP devices visible (0 if none / no driver). */
+int admm_device_count(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ADMM_HIP_H */

@@ -1,0 +1,83 @@
+"""ctypes wrapper of oracle/liboracle.so (the C/OpenMP CPU restatement).
+
+TEST INFRASTRUCTURE ONLY -- see the header of admm_oracle.c.  PARITY UNPINNED:
+the reference holds no source or fixture for this path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+import admm_library_amd as pkg
+from admm_library_amd import _abi
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    path = os.path.join(_DIR, "liboracle.so")
+    if force or not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(os.path.join(_DIR, "admm_oracle.c")):
+        subprocess.run(["make", "-C", _DIR, "-B" if force else "-s", "liboracle.so"], check=True,
+                       stdout=subprocess.DEVNULL)
+    return path
+
+
+def load():
+    global _lib
+    if _lib is None:
+        lib = C.CDLL(build())
+        lib.oracle_solve.restype = C.c_int
+        lib.oracle_solve.argtypes = [C.POINTER(_abi.CProblem), C.POINTER(_abi.COptions), C.c_int32,
+                                     _abi.c_double_p, _abi.c_double_p, _abi.c_double_p,
+                                     _abi.c_int32_p, _abi.c_int32_p, _abi.c_double_p, _abi.c_double_p,
+                                     _abi.c_int32_p, C.c_int32]
+        lib.oracle_factor.restype = C.c_int
+        lib.oracle_factor.argtypes = [C.POINTER(_abi.CProblem), C.c_double, _abi.c_double_p, _abi.c_double_p]
+        lib.oracle_max_threads.restype = C.c_int
+        _lib = lib
+    return _lib
+
+
+def max_threads() -> int:
+    return int(load().oracle_max_threads())
+
+
+def solve(p: pkg.Problem, rho=0.1, alpha=1.0, eps_abs=1e-6, eps_rel=1e-6, max_iter=4000,
+          check_interval=10, z0=None, y0=None, stop=True, nthreads=0):
+    """Returns dict(w, z, y, iters_run, iters, status, r, s)."""
+    lib = load()
+    cp, keep = _abi.marshal_problem(p)
+    co = _abi.make_options(rho=rho, alpha=alpha, eps_abs=eps_abs, eps_rel=eps_rel, max_iter=max_iter,
+                           check_interval=check_interval)
+    B, L = p.batch, p.L
+    z = np.zeros((B, L)) if z0 is None else np.array(z0, np.float64).reshape(B, L).copy()
+    y = np.zeros((B, L)) if y0 is None else np.array(y0, np.float64).reshape(B, L).copy()
+    w = np.zeros((B, L))
+    iters = np.zeros(B, np.int32)
+    status = np.zeros(B, np.int32)
+    r = np.full(B, np.inf)
+    s = np.full(B, np.inf)
+    run = C.c_int32(0)
+    rc = lib.oracle_solve(C.byref(cp), C.byref(co), int(bool(stop)), _abi.dptr(z), _abi.dptr(y), _abi.dptr(w),
+                          _abi.iptr(iters), _abi.iptr(status), _abi.dptr(r), _abi.dptr(s), C.byref(run),
+                          int(nthreads))
+    del keep
+    if rc != 0:
+        raise RuntimeError("oracle_solve failed (bad input or S_k not SPD)")
+    return dict(w=w, z=z, y=y, iters_run=int(run.value), iters=iters, status=status, r=r, s=s)
+
+
+def factor(p: pkg.Problem, rho: float):
+    lib = load()
+    cp, keep = _abi.marshal_problem(p)
+    K = np.empty((p.N, p.m, p.n))
+    Sinv = np.empty((p.N, p.m, p.m))
+    rc = lib.oracle_factor(C.byref(cp), float(rho), _abi.dptr(K), _abi.dptr(Sinv))
+    del keep
+    if rc != 0:
+        raise RuntimeError("oracle_factor failed")
+    return K, Sinv

@@ -1,0 +1,217 @@
+"""GPU parity tests: the HIP path, called through the C ABI (ctypes), against
+the CPU oracle on the same seeded inputs.
+
+Tolerance: 1e-10 absolute on fp64 iterates (BASELINE.json north_star), with
+variables scaled to O(1).  The oracle is the build's own CPU restatement
+(PARITY UNPINNED: the reference ships no code or fixtures), and it
+uses the plain sequential Riccati sweep, not the segmented form of the kernels.
+"""
+import numpy as np
+import pytest
+
+import admm_library_amd as pkg
+import admm_ref as ar
+import oracle_c as oc
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+
+def _g(p, z, y, rho):
+    g = -rho * (z - y)
+    return g if p.q is None else g + p.q
+
+
+CASES = [
+    # (factory, rho, segments)
+    (lambda: pkg.double_integrator(N=50, batch=1), 1.0, 0),
+    (lambda: pkg.double_integrator(N=50, batch=130), 1.0, 7),
+    (lambda: pkg.cw_rendezvous(N=200, batch=3), 0.05, 0),
+    (lambda: pkg.cw_rendezvous(N=1000, batch=65), 0.05, 0),
+    (lambda: pkg.cw_rendezvous(N=1000, batch=1), 0.05, 1),
+    (lambda: pkg.random_ltv(N=37, n=4, m=2, batch=70, seed=2), 0.3, 5),
+    (lambda: pkg.random_ltv(N=16, n=6, m=6, batch=5, seed=4), 0.5, 3),
+    (lambda: pkg.random_ltv(N=24, n=12, m=6, batch=3, seed=6), 0.4, 4),
+    (lambda: pkg.random_ltv(N=9, n=2, m=2, batch=2, seed=8, with_q=False), 0.4, 9),
+    (lambda: pkg.random_ltv(N=30, n=8, m=4, batch=64, seed=10), 0.2, 0),
+    (lambda: pkg.random_ltv(N=11, n=3, m=1, batch=4, seed=12), 0.2, 2),
+    (lambda: pkg.random_ltv(N=11, n=4, m=1, batch=4, seed=13), 0.2, 2),
+    (lambda: pkg.random_ltv(N=11, n=4, m=4, batch=4, seed=14), 0.2, 2),
+    (lambda: pkg.random_ltv(N=11, n=6, m=2, batch=4, seed=15), 0.2, 2),
+    (lambda: pkg.random_ltv(N=11, n=12, m=3, batch=4, seed=16), 0.2, 2),
+]
+
+
+@pytest.mark.parametrize("idx", range(len(CASES)))
+def test_x_update_kernels(gpu, idx):
+    """T5: xb + xscan + xf on random (z, y) vs the oracle's sequential sweep."""
+    make, rho, segs = CASES[idx]
+    p = make()
+    rng = np.random.default_rng(100 + idx)
+    z = rng.standard_normal((p.batch, p.L))
+    y = rng.standard_normal((p.batch, p.L))
+    with pkg.Solver(p, pkg.Options(rho=rho, segments=segs)) as s:
+        s.set_state(z=z, y=y)
+        s.step_x()
+        w, z2, y2 = s.get()
+    np.testing.assert_array_equal(z2, z)     # layout round trip is exact
+    np.testing.assert_array_equal(y2, y)
+    f = ar.factor(p.A, p.B, p.Q, p.R, p.QN, rho, p.N)
+    w_ref = ar.x_update(f, _g(p, z, y, rho), p.x0)
+    scale = max(1.0, np.abs(w_ref).max())
+    assert np.abs(w - w_ref).max() <= TOL * scale
+
+
+@pytest.mark.parametrize("alpha", [1.0, 1.7])
+@pytest.mark.parametrize("resid", [False, True])
+def test_zdual_kernel(gpu, alpha, resid):
+    """T5: fused z/dual/residual kernel, incl. elements exactly on bounds and
+    +-inf bounds; z+, y+ must be BIT-exact (no reassociation is involved)."""
+    p = pkg.random_ltv(N=41, n=4, m=2, batch=67, seed=21)
+    rho = 0.35
+    rng = np.random.default_rng(5)
+    lo, hi = ar.expand_bounds(p.lo, p.hi, p.N, p.nb)
+    w = rng.standard_normal((p.batch, p.L))
+    z = rng.standard_normal((p.batch, p.L))
+    y = 0.5 * rng.standard_normal((p.batch, p.L))
+    fin = np.isfinite(hi)
+    y[:, ::5] = 0.0
+    w[:, ::5] = np.where(fin, hi, 0.25)[None, ::5]        # exactly on the upper bound
+    with pkg.Solver(p, pkg.Options(rho=rho, alpha=alpha, zrows=8)) as s:
+        s.set_state(w=w, z=z, y=y)
+        s.step_z(residuals=resid)
+        w2, zn, yn = s.get()
+        if resid:
+            r, sd, nw, nz, ny = s.residuals()
+    zr, yr = ar.z_update(w, z, y, lo, hi, alpha)
+    np.testing.assert_array_equal(w2, w)
+    if alpha == 1.0:
+        np.testing.assert_array_equal(zn, zr)
+        np.testing.assert_array_equal(yn, yr)
+    else:   # fma(alpha, w, (1-alpha) z) vs two roundings
+        assert np.abs(zn - zr).max() < 1e-14 and np.abs(yn - yr).max() < 1e-14
+    if resid:
+        rr = ar.residuals(w, z, zr, yr, rho)
+        for got, ref in zip((r, sd, nw, nz, ny), rr):
+            assert np.abs(got - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("idx", [0, 1, 3, 5, 7, 9])
+def test_iterate_parity(gpu, idx):
+    """T4: iterates of the full loop vs the C oracle after 1, 2, 10, 40 iterations."""
+    make, rho, segs = CASES[idx]
+    p = make()
+    with pkg.Solver(p, pkg.Options(rho=rho, segments=segs)) as s:
+        done = 0
+        for upto in (1, 2, 10, 40):
+            s.iterate(upto - done)
+            done = upto
+            w, z, y = s.get()
+            ref = oc.solve(p, rho=rho, max_iter=upto, stop=False)
+            for a, b in ((w, ref["w"]), (z, ref["z"]), (y, ref["y"])):
+                assert np.abs(a - b).max() <= TOL * max(1.0, np.abs(b).max()), (upto,)
+
+
+def test_graph_and_direct_launch_agree(gpu):
+    p = pkg.cw_rendezvous(N=100, batch=66)
+    outs = []
+    for flags in (0, 1):
+        with pkg.Solver(p, pkg.Options(rho=0.05, flags=flags)) as s:
+            s.iterate(17)
+            outs.append(s.get())
+    for a, b in zip(*outs):
+        np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("alpha", [1.0, 1.5])
+def test_solve_matches_oracle(gpu, alpha):
+    """Full admm_solve: stopping rule, per-QP iteration counts, warm start."""
+    p = pkg.double_integrator(N=50, batch=37)
+    kw = dict(rho=1.0, alpha=alpha, eps_abs=1e-7, eps_rel=1e-7, max_iter=3000, check_interval=10)
+    ref = oc.solve(p, **kw)
+    with pkg.Solver(p, pkg.Options(**kw)) as s:
+        info = s.solve()
+        w, z, y = s.get()
+        assert info.iters_run == ref["iters_run"]
+        assert info.n_converged == int(ref["status"].sum()) == p.batch
+        # a stop decision may flip by one check near the threshold (reduction order)
+        assert (np.abs(info.iters - ref["iters"]) <= kw["check_interval"]).all()
+        assert (info.iters == ref["iters"]).mean() > 0.9
+        for a, b in ((w, ref["w"]), (z, ref["z"]), (y, ref["y"])):
+            assert np.abs(a - b).max() <= TOL * max(1.0, np.abs(b).max())
+        # warm start from the solution converges at the first check
+        info2 = s.solve(z0=z, y0=y)
+        assert info2.iters_run == kw["check_interval"]
+
+
+def test_solve_max_iter_and_unconverged(gpu):
+    p = pkg.cw_rendezvous(N=150, batch=5)
+    kw = dict(rho=0.05, eps_abs=1e-12, eps_rel=1e-12, max_iter=23, check_interval=10)
+    ref = oc.solve(p, **kw)
+    with pkg.Solver(p, pkg.Options(**kw)) as s:
+        info = s.solve()
+        assert info.iters_run == 23 == ref["iters_run"]
+        assert info.n_converged == 0
+        np.testing.assert_array_equal(info.status, ref["status"])
+        np.testing.assert_array_equal(info.iters, np.full(5, 23, np.int32))
+        assert np.abs(info.r - ref["r"]).max() < 1e-10 and np.abs(info.s - ref["s"]).max() < 1e-10
+
+
+def test_update_instances(gpu):
+    """New x0 on an existing handle = fresh setup with that x0."""
+    p = pkg.cw_rendezvous(N=80, batch=10)
+    p2 = pkg.cw_rendezvous(N=80, batch=10, seed0=999)
+    with pkg.Solver(p, pkg.Options(rho=0.05)) as s:
+        s.iterate(5)
+        s.update_instances(x0=p2.x0)
+        s.set_state(z=np.zeros((10, p.L)), y=np.zeros((10, p.L)))
+        s.iterate(12)
+        _, z, _ = s.get()
+    ref = oc.solve(p2, rho=0.05, max_iter=12, stop=False)
+    assert np.abs(z - ref["z"]).max() <= TOL
+
+
+def test_properties_at_full_size(gpu):
+    """BASELINE.json configs[2] shape (N=1000, n=6, m=3, batch=4096): size-independent
+    properties instead of a full oracle run.
+      - dynamics feasibility of w: x_{k+1} = A x_k + B u_k to rounding;
+      - z inside the box, y complementary (y_i != 0 only where z_i sits on a bound);
+      - z/dual step is idempotent on its own fixed point structure: v = w + y = z+ + y+;
+      - a 64-QP slice matches the oracle run on that slice alone (QPs are independent)."""
+    p = pkg.cw_rendezvous(N=1000, batch=4096)
+    rho = 0.05
+    with pkg.Solver(p, pkg.Options(rho=rho)) as s:
+        s.iterate(8)
+        w0, z0, y0 = s.get()
+        s.step_x()
+        w, _, _ = s.get(True, False, False)
+        s.step_z(residuals=True)
+        _, z, y = s.get(False, True, True)
+        r, sd, nw, nz, ny = s.residuals()
+    A, B = p.A, p.B
+    wb = w.reshape(p.batch, p.N, 9)
+    xprev = np.concatenate([p.x0[:, None, :], wb[:, :-1, 3:]], axis=1)
+    dyn = wb[:, :, 3:] - (xprev @ A.T + wb[:, :, :3] @ B.T)
+    assert np.abs(dyn).max() < 1e-12 * max(1.0, np.abs(wb).max())
+    lo, hi = ar.expand_bounds(p.lo, p.hi, p.N, p.nb)
+    assert (z >= lo).all() and (z <= hi).all()
+    on_bound = (z == lo) | (z == hi)
+    assert (y[~on_bound] == 0).all()
+    assert np.abs((z + y) - (w + y0)).max() < 1e-14 * max(1.0, np.abs(w).max())   # z+ + y+ = w + y
+    assert np.abs(r - np.sqrt(((w - z) ** 2).sum(1))).max() < 1e-10
+    assert np.abs(sd - rho * np.sqrt(((z - z0) ** 2).sum(1))).max() < 1e-10
+    sl = slice(2048 - 32, 2048 + 32)
+    ref = oc.solve(p.slice(sl.start, sl.stop), rho=rho, max_iter=9, stop=False)
+    assert np.abs(z[sl] - ref["z"]).max() <= TOL and np.abs(y[sl] - ref["y"]).max() <= TOL
+    assert np.abs(w[sl] - ref["w"]).max() <= TOL * max(1.0, np.abs(ref["w"]).max())
+
+
+def test_errors_are_loud(gpu):
+    p = pkg.random_ltv(N=5, n=5, m=2, batch=2)
+    with pytest.raises(pkg.AdmmError) as e:
+        pkg.Solver(p)
+    assert e.value.code == 2            # ADMM_ERR_UNSUPPORTED: (5, 2) not compiled
+    p = pkg.double_integrator(N=10)
+    with pytest.raises(pkg.AdmmError) as e:
+        pkg.Solver(p, pkg.Options(rho=-1.0))
+    assert e.value.code == 1
