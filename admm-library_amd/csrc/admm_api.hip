@@ -52,6 +52,7 @@ struct admm_handle {
   int* h_nconv = nullptr;       // pinned
   int iters_run = 0;
   bool resid_valid = false;
+  bool w_stale = false;         // fused iterations do not store w; admm_get re-materialises it
   // captured iterations, replayed by admm_run / admm_solve:
   //   [0] x-update + plain z step;  [1] x-update + residual z step + finalise (it = 0)
   hipGraph_t graph[2] = {nullptr, nullptr};
@@ -102,7 +103,7 @@ int launch_xb(admm_handle* h) {
 }
 
 int launch_xscan(admm_handle* h) {
-  dim3 grid((h->pitch + XB_THREADS - 1) / XB_THREADS), block(XB_THREADS);
+  dim3 grid(h->pitch / 64), block(64);
   switch (h->n) {
 #define C(NX)                                                                                        \
   case NX:                                                                                           \
@@ -129,6 +130,26 @@ int launch_xf(admm_handle* h) {
   return fail(ADMM_ERR_UNSUPPORTED, "no x-update kernel for this (n, m)");
 }
 
+// fused forward rollout + z/dual (+ residual partials per segment)
+int launch_xfz(admm_handle* h, bool resid) {
+  dim3 grid((h->pitch + XB_THREADS - 1) / XB_THREADS, h->S), block(XB_THREADS);
+  const bool relax = h->opt.alpha != 1.0;
+#define XFZ(NX, NU, RS, RX)                                                                          \
+  hipLaunchKernelGGL((admm::xfz_kernel<NX, NU, RS, RX>), grid, block, 0, h->stream, h->dbuf, h->tin, \
+                     h->xin, h->recF, h->seg_start, h->z, h->y, h->lo, h->hi, h->part,               \
+                     h->opt.alpha, h->pitch)
+#define X(NX, NU)                                                        \
+  if (h->n == NX && h->m == NU) {                                        \
+    if (resid) { if (relax) XFZ(NX, NU, true, true); else XFZ(NX, NU, true, false); }   \
+    else       { if (relax) XFZ(NX, NU, false, true); else XFZ(NX, NU, false, false); } \
+    return ADMM_OK;                                                      \
+  }
+  ADMM_FOR_EACH_DIM(X)
+#undef X
+#undef XFZ
+  return fail(ADMM_ERR_UNSUPPORTED, "no x-update kernel for this (n, m)");
+}
+
 int launch_z(admm_handle* h, bool resid) {
   dim3 grid((h->pitch / 2 + Z_THREADS - 1) / Z_THREADS, h->zchunks), block(Z_THREADS);
   const bool relax = h->opt.alpha != 1.0;
@@ -144,11 +165,35 @@ int launch_z(admm_handle* h, bool resid) {
   return ADMM_OK;
 }
 
-int launch_finalize(admm_handle* h, int it) {
-  dim3 grid((h->pitch + 255) / 256), block(256);
+// nchunks = zchunks after the standalone z kernel, S after the fused xfz kernel
+int launch_finalize(admm_handle* h, int it, int nchunks) {
+  dim3 grid(h->pitch / admm::FIN_COLS), block(admm::FIN_COLS * admm::FIN_GROUPS);
   hipLaunchKernelGGL(admm::resid_finalize_kernel, grid, block, 0, h->stream, h->part, h->resid,
                      h->status, h->iters, h->nconv, h->opt.rho, h->opt.eps_abs, h->opt.eps_rel,
-                     std::sqrt((double)h->L), h->zchunks, h->batch, h->pitch, it);
+                     std::sqrt((double)h->L), nchunks, h->batch, h->pitch, it);
+  return ADMM_OK;
+}
+
+bool fused(const admm_handle* h) { return !(h->opt.flags & ADMM_FLAG_UNFUSED); }
+
+// One full iteration on the stream: x-update + z/dual (+ residual partials).
+int enqueue_iteration(admm_handle* h, bool resid) {
+  int rc;
+  if ((rc = launch_xb(h))) return rc;
+  if ((rc = launch_xscan(h))) return rc;
+  if (fused(h)) return launch_xfz(h, resid);
+  if ((rc = launch_xf(h))) return rc;
+  return launch_z(h, resid);
+}
+
+int chunks_of_iteration(const admm_handle* h) { return fused(h) ? h->S : h->zchunks; }
+
+// w of the last x-update, if the fused path skipped storing it
+int ensure_w(admm_handle* h) {
+  if (!h->w_stale) return ADMM_OK;
+  int rc = launch_xf(h);
+  if (rc) return rc;
+  h->w_stale = false;
   return ADMM_OK;
 }
 
@@ -248,9 +293,8 @@ int capture_iterations(admm_handle* h) {
   destroy_graph(h);
   for (int v = 0; v < 2; ++v) {
     HIP_TRY(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-    int rc = step_x(h);
-    if (!rc) rc = launch_z(h, v == 1);
-    if (!rc && v == 1) rc = launch_finalize(h, 0);
+    int rc = enqueue_iteration(h, v == 1);
+    if (!rc && v == 1) rc = launch_finalize(h, 0, chunks_of_iteration(h));
     hipGraph_t g = nullptr;
     hipError_t e = hipStreamEndCapture(h->stream, &g);
     if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
@@ -387,7 +431,8 @@ int admm_setup(admm_handle** out, const admm_problem* p, const admm_options* o_i
   TRY_RELEASE(dalloc(&h->eseg, (size_t)h->S * h->n * P));
   TRY_RELEASE(dalloc(&h->tin, (size_t)h->S * h->n * P));
   TRY_RELEASE(dalloc(&h->xin, (size_t)h->S * h->n * P));
-  TRY_RELEASE(dalloc(&h->part, (size_t)h->zchunks * 5 * P));
+  const size_t part_chunks = (size_t)(h->zchunks > h->S ? h->zchunks : h->S);
+  TRY_RELEASE(dalloc(&h->part, part_chunks * 5 * P));
   TRY_RELEASE(dalloc(&h->resid, 5 * P));
   TRY_RELEASE(dalloc(&h->lo, L));
   TRY_RELEASE(dalloc(&h->hi, L));
@@ -405,7 +450,7 @@ int admm_setup(admm_handle** out, const admm_problem* p, const admm_options* o_i
   HIP_TRY_RELEASE(hipMemsetAsync(h->z, 0, sizeof(double) * L * P, h->stream));
   HIP_TRY_RELEASE(hipMemsetAsync(h->y, 0, sizeof(double) * L * P, h->stream));
   HIP_TRY_RELEASE(hipMemsetAsync(h->dbuf, 0, sizeof(double) * (size_t)h->N * h->m * P, h->stream));
-  HIP_TRY_RELEASE(hipMemsetAsync(h->part, 0, sizeof(double) * (size_t)h->zchunks * 5 * P, h->stream));
+  HIP_TRY_RELEASE(hipMemsetAsync(h->part, 0, sizeof(double) * part_chunks * 5 * P, h->stream));
   HIP_TRY_RELEASE(hipMemsetAsync(h->resid, 0, sizeof(double) * 5 * P, h->stream));
   HIP_TRY_RELEASE(hipMemsetAsync(h->status, 0, sizeof(int) * P, h->stream));
   HIP_TRY_RELEASE(hipMemsetAsync(h->iters, 0, sizeof(int) * P, h->stream));
@@ -454,7 +499,10 @@ int admm_set_state(admm_handle* h, const double* w, const double* z, const doubl
   if (!h) return fail(ADMM_ERR_INVALID, "NULL handle");
   HIP_TRY(hipSetDevice(h->device));
   int rc;
-  if (w && (rc = upload_transposed(h, w, h->w, h->L))) return rc;
+  if (w) {
+    if ((rc = upload_transposed(h, w, h->w, h->L))) return rc;
+    h->w_stale = false;
+  }
   if (z && (rc = upload_transposed(h, z, h->z, h->L))) return rc;
   if (y && (rc = upload_transposed(h, y, h->y, h->L))) return rc;
   return ADMM_OK;
@@ -465,6 +513,7 @@ int admm_step_x(admm_handle* h) {
   HIP_TRY(hipSetDevice(h->device));
   int rc = step_x(h);
   if (rc) return rc;
+  h->w_stale = false;
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(h->stream));
   return ADMM_OK;
@@ -473,10 +522,11 @@ int admm_step_x(admm_handle* h) {
 int admm_step_z(admm_handle* h, int32_t residuals) {
   if (!h) return fail(ADMM_ERR_INVALID, "NULL handle");
   HIP_TRY(hipSetDevice(h->device));
-  int rc = launch_z(h, residuals != 0);
+  int rc = ensure_w(h);
+  if (!rc) rc = launch_z(h, residuals != 0);
   if (rc) return rc;
   if (residuals) {
-    launch_finalize(h, 0);
+    launch_finalize(h, 0, h->zchunks);
     h->resid_valid = true;
   }
   HIP_TRY(hipGetLastError());
@@ -498,13 +548,13 @@ int admm_run(admm_handle* h, int32_t iters, int32_t residual_every) {
     if (use_graph) {
       HIP_TRY(hipGraphLaunch(h->graph_exec[resid ? 1 : 0], h->stream));
     } else {
-      int rc = step_x(h);
-      if (!rc) rc = launch_z(h, resid);
-      if (!rc && resid) rc = launch_finalize(h, 0);
+      int rc = enqueue_iteration(h, resid);
+      if (!rc && resid) rc = launch_finalize(h, 0, chunks_of_iteration(h));
       if (rc) return rc;
     }
     if (resid) h->resid_valid = true;
   }
+  if (iters > 0 && fused(h)) h->w_stale = true;
   HIP_TRY(hipGetLastError());
   return ADMM_OK;
 }
@@ -541,11 +591,10 @@ int admm_solve(admm_handle* h, const double* z0, const double* y0, admm_info* in
       HIP_TRY(hipGraphLaunch(h->graph_exec[0], h->stream));
       continue;
     }
-    if ((rc = step_x(h))) return rc;
-    if ((rc = launch_z(h, check))) return rc;
+    if ((rc = enqueue_iteration(h, check))) return rc;
     if (check) {
       HIP_TRY(hipMemsetAsync(h->nconv, 0, sizeof(int), h->stream));
-      launch_finalize(h, it);
+      launch_finalize(h, it, chunks_of_iteration(h));
       HIP_TRY(hipMemcpyAsync(h->h_nconv, h->nconv, sizeof(int), hipMemcpyDeviceToHost, h->stream));
       HIP_TRY(hipStreamSynchronize(h->stream));
       nconv = *h->h_nconv;
@@ -554,6 +603,7 @@ int admm_solve(admm_handle* h, const double* z0, const double* y0, admm_info* in
     }
   }
   if (it > h->opt.max_iter) it = h->opt.max_iter;
+  if (fused(h)) h->w_stale = true;
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(h->stream));
   h->iters_run = it;
@@ -589,6 +639,7 @@ int admm_get(admm_handle* h, double* w, double* z, double* y) {
   if (!h) return fail(ADMM_ERR_INVALID, "NULL handle");
   HIP_TRY(hipSetDevice(h->device));
   int rc;
+  if (w && (rc = ensure_w(h))) return rc;
   if (w && (rc = download_transposed(h, h->w, w, h->L))) return rc;
   if (z && (rc = download_transposed(h, h->z, z, h->L))) return rc;
   if (y && (rc = download_transposed(h, h->y, y, h->L))) return rc;
@@ -606,40 +657,46 @@ int admm_get_info(admm_handle* h, int32_t* iters, int32_t* status, double* r, do
   return ADMM_OK;
 }
 
-int admm_profile(admm_handle* h, int32_t iters, int32_t residuals, double ms[5]) {
+int admm_profile(admm_handle* h, int32_t iters, int32_t residuals, int32_t fused_path, double ms[6]) {
   if (!h || !ms) return fail(ADMM_ERR_INVALID, "NULL argument");
   if (iters < 1 || iters > 4096) return fail(ADMM_ERR_INVALID, "iters must lie in [1, 4096]");
   HIP_TRY(hipSetDevice(h->device));
-  std::vector<hipEvent_t> ev((size_t)iters * 5);
+  constexpr int NE = 6;     // events per iteration
+  std::vector<hipEvent_t> ev((size_t)iters * NE);
   for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
   int rc = ADMM_OK;
+  const bool res = residuals != 0;
   for (int it = 0; it < iters && !rc; ++it) {
-    hipEvent_t* e = &ev[(size_t)it * 5];
+    hipEvent_t* e = &ev[(size_t)it * NE];
     HIP_TRY(hipEventRecord(e[0], h->stream));
     rc = launch_xb(h);
     HIP_TRY(hipEventRecord(e[1], h->stream));
     if (!rc) rc = launch_xscan(h);
     HIP_TRY(hipEventRecord(e[2], h->stream));
-    if (!rc) rc = launch_xf(h);
+    if (!rc) rc = fused_path ? launch_xfz(h, res) : launch_xf(h);
     HIP_TRY(hipEventRecord(e[3], h->stream));
-    if (!rc) rc = launch_z(h, residuals != 0);
+    if (!rc && !fused_path) rc = launch_z(h, res);
     HIP_TRY(hipEventRecord(e[4], h->stream));
+    if (!rc && res) rc = launch_finalize(h, 0, fused_path ? h->S : h->zchunks);
+    HIP_TRY(hipEventRecord(e[5], h->stream));
   }
+  if (fused_path) h->w_stale = true;
+  if (res) h->resid_valid = true;
   HIP_TRY(hipStreamSynchronize(h->stream));
-  for (int v = 0; v < 5; ++v) ms[v] = 0.0;
+  for (int v = 0; v < 6; ++v) ms[v] = 0.0;
   if (!rc) {
     for (int it = 0; it < iters; ++it) {
-      hipEvent_t* e = &ev[(size_t)it * 5];
-      for (int v = 0; v < 4; ++v) {
+      hipEvent_t* e = &ev[(size_t)it * NE];
+      for (int v = 0; v < 5; ++v) {
         float t = 0.f;
         HIP_TRY(hipEventElapsedTime(&t, e[v], e[v + 1]));
         ms[v] += t;
       }
       float t = 0.f;
-      HIP_TRY(hipEventElapsedTime(&t, e[0], e[4]));
-      ms[4] += t;
+      HIP_TRY(hipEventElapsedTime(&t, e[0], e[5]));
+      ms[5] += t;
     }
-    for (int v = 0; v < 5; ++v) ms[v] /= iters;
+    for (int v = 0; v < 6; ++v) ms[v] /= iters;
   }
   for (auto& e : ev) (void)hipEventDestroy(e);
   return rc;

@@ -143,60 +143,137 @@ __global__ __launch_bounds__(XB_THREADS) void xb_kernel(
 // ---------------------------------------------------------------------------
 // Segment scan.  One lane = one QP, all segments, sequential in S (S is small):
 //     t_in(S-1) = 0;   t_in(s-1) = tseg(s) + Phi_s t_in(s)
-//     x_in(0)  = x0;   x_in(s+1) = eseg(s) + Xi_s t_in(s) + Th_s x_in(s)
-// Touches only 4 S n rows: negligible HBM traffic; latency-bound by design.
+//     e'(s)     = eseg(s) + Xi_s t_in(s)                     (in place in eseg)
+//     x_in(0)   = x0;  x_in(s+1) = e'(s) + Th_s x_in(s)
+// Touches only 4 S n rows: negligible HBM traffic, but a dependent chain of
+// 2 S small mat-vecs run by only pitch/64 waves, so every exposed latency
+// counts twice S times.  Two measures keep the chain at ALU latency:
+//   - the vector operands of step s (tseg / eseg rows) do not depend on the
+//     chain, so they are prefetched D steps ahead into a register ring;
+//   - the segment matrices (3 n^2 doubles per segment) are staged into LDS once
+//     (SCAN_LDS_DOUBLES at a time) and read back as wave-uniform broadcasts:
+//     with one wave per CU a scalar-cache miss per step would not be hidden.
 // ---------------------------------------------------------------------------
+constexpr int SCAN_LDS_DOUBLES = 6144;   // 48 KiB of segment matrices per refill
+
 template <int NX>
-__global__ __launch_bounds__(XB_THREADS) void xscan_kernel(
-    const double* __restrict__ tseg, const double* __restrict__ eseg, const double* __restrict__ x0,
-    const double* __restrict__ recS_, double* __restrict__ tin, double* __restrict__ xin,
+__global__ __launch_bounds__(64) void xscan_kernel(
+    const double* __restrict__ tseg, double* __restrict__ eseg, const double* __restrict__ x0,
+    const double* __restrict__ recS, double* __restrict__ tin, double* __restrict__ xin,
     int S, int pitch) {
   constexpr int RS = 3 * NX * NX;
-  const int col = blockIdx.x * XB_THREADS + threadIdx.x;
-  if (col >= pitch) return;
+  constexpr int D = (NX <= 4) ? 8 : (NX <= 8 ? 6 : 4);     // prefetch depth (register ring)
+  constexpr int CS = (SCAN_LDS_DOUBLES / RS / D) * D;      // segments per LDS refill, multiple of D
+  static_assert(CS >= D, "segment records do not fit the LDS staging buffer");
+  __shared__ double mats[CS * RS];
+  const int col = blockIdx.x * 64 + threadIdx.x;           // pitch is a multiple of 64
   const size_t P = (size_t)pitch;
   double t[NX], x[NX];
+  double rt[D][NX], re[D][NX];
+
+  // ---- backward chain over s = S-1 .. 0, in LDS refills of CS segments ----
 #pragma unroll
-  for (int i = 0; i < NX; ++i) t[i] = 0.0;
-  for (int s = S - 1; s >= 0; --s) {
-    const size_t o = (size_t)s * NX * P + col;
-#pragma unroll
-    for (int i = 0; i < NX; ++i) tin[o + i * P] = t[i];
-    if (s == 0) break;
-    cdouble_p rs = as_const(recS_) + (size_t)s * RS;
-    double tn[NX];
+  for (int j = 0; j < D; ++j) {
+    const int sj = S - 1 - j;
+    const size_t o = (size_t)(sj > 0 ? sj : 0) * NX * P + col;
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
-      double a = tseg[o + i * P];
-#pragma unroll
-      for (int l = 0; l < NX; ++l) a = fma(rs[i * NX + l], t[l], a);
-      tn[i] = a;
+      rt[j][i] = tseg[o + i * P];
+      re[j][i] = eseg[o + i * P];
     }
+  }
 #pragma unroll
-    for (int i = 0; i < NX; ++i) t[i] = tn[i];
+  for (int i = 0; i < NX; ++i) t[i] = 0.0;
+  for (int hi_s = S - 1; hi_s >= 0; hi_s -= CS) {
+    const int lo_s = (hi_s - CS + 1 > 0) ? hi_s - CS + 1 : 0;     // this refill covers [lo_s, hi_s]
+    __syncthreads();
+    for (int i = threadIdx.x; i < (hi_s - lo_s + 1) * RS; i += 64) mats[i] = recS[(size_t)lo_s * RS + i];
+    __syncthreads();
+    for (int base = hi_s; base >= lo_s; base -= D) {
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        const int s = base - j;
+        if (s >= lo_s) {
+          const size_t o = (size_t)s * NX * P + col;
+          const double* rs = mats + (s - lo_s) * RS;
+          double tn[NX], en[NX];
+#pragma unroll
+          for (int i = 0; i < NX; ++i) {
+            double a = rt[j][i], b = re[j][i];
+#pragma unroll
+            for (int l = 0; l < NX; ++l) {
+              a = fma(rs[i * NX + l], t[l], a);
+              b = fma(rs[NX * NX + i * NX + l], t[l], b);
+            }
+            tn[i] = a;
+            en[i] = b;
+          }
+#pragma unroll
+          for (int i = 0; i < NX; ++i) {
+            tin[o + i * P] = t[i];       // t_in(s)
+            eseg[o + i * P] = en[i];     // e'(s)
+            t[i] = tn[i];                // t_out(s) = t_in(s-1)
+          }
+          const int sn = s - D;          // refill this ring slot
+          if (sn >= 0) {
+            const size_t on = (size_t)sn * NX * P + col;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+              rt[j][i] = tseg[on + i * P];
+              re[j][i] = eseg[on + i * P];
+            }
+          }
+        }
+      }
+    }
+  }
+
+  // ---- forward chain over s = 0 .. S-1 (reads the e' this lane just wrote) ----
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+    const int sj = (j < S) ? j : S - 1;
+    const size_t o = (size_t)sj * NX * P + col;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) re[j][i] = eseg[o + i * P];
   }
 #pragma unroll
   for (int i = 0; i < NX; ++i) x[i] = x0[(size_t)i * P + col];
-  for (int s = 0; s < S; ++s) {
-    const size_t o = (size_t)s * NX * P + col;
-#pragma unroll
-    for (int i = 0; i < NX; ++i) xin[o + i * P] = x[i];
-    if (s == S - 1) break;
-    cdouble_p rs = as_const(recS_) + (size_t)s * RS;
-    double ts[NX], xn[NX];
-#pragma unroll
-    for (int i = 0; i < NX; ++i) ts[i] = tin[o + i * P];
-#pragma unroll
-    for (int i = 0; i < NX; ++i) {
-      double a = eseg[o + i * P];
-#pragma unroll
-      for (int l = 0; l < NX; ++l) a = fma(rs[NX * NX + i * NX + l], ts[l], a);
-#pragma unroll
-      for (int l = 0; l < NX; ++l) a = fma(rs[2 * NX * NX + i * NX + l], x[l], a);
-      xn[i] = a;
+  for (int lo_s = 0; lo_s < S; lo_s += CS) {
+    const int hi_s = (lo_s + CS - 1 < S - 1) ? lo_s + CS - 1 : S - 1;
+    if (S > CS) {      // otherwise the one refill of the backward chain still holds every segment
+      __syncthreads();
+      for (int i = threadIdx.x; i < (hi_s - lo_s + 1) * RS; i += 64) mats[i] = recS[(size_t)lo_s * RS + i];
+      __syncthreads();
     }
+    for (int base = lo_s; base <= hi_s; base += D) {
 #pragma unroll
-    for (int i = 0; i < NX; ++i) x[i] = xn[i];
+      for (int j = 0; j < D; ++j) {
+        const int s = base + j;
+        if (s <= hi_s) {
+          const size_t o = (size_t)s * NX * P + col;
+          const double* rs = mats + (s - lo_s) * RS + 2 * NX * NX;
+          double xn[NX];
+#pragma unroll
+          for (int i = 0; i < NX; ++i) {
+            double a = re[j][i];
+#pragma unroll
+            for (int l = 0; l < NX; ++l) a = fma(rs[i * NX + l], x[l], a);
+            xn[i] = a;
+          }
+#pragma unroll
+          for (int i = 0; i < NX; ++i) {
+            xin[o + i * P] = x[i];       // x_in(s)
+            x[i] = xn[i];                // x_in(s+1)
+          }
+          const int sn = s + D;
+          if (sn < S) {
+            const size_t on = (size_t)sn * NX * P + col;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) re[j][i] = eseg[on + i * P];
+          }
+        }
+      }
+    }
   }
 }
 
@@ -275,6 +352,135 @@ __global__ __launch_bounds__(XB_THREADS) void xf_kernel(
       x[i] = xn[i];
       w[r0 + (NU + i) * P] = xn[i];
     }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Fused forward rollout + z-update + dual ascent + residual partials (the
+// default iteration path).  Same rollout as xf_kernel, but block k of w is
+// consumed in registers instead of being written to HBM and re-read:
+//     wh = alpha w + (1 - alpha) z       (RELAX only)
+//     v  = wh + y;  z+ = min(max(v, lo), hi);  y+ = v - z+        (in place)
+//     RESID: per-QP sums over the segment's rows of (w - z+)^2, (z+ - z)^2,
+//            w^2, z+^2, y+^2  -> part[segment][5][pitch]
+// w itself is not stored (nothing in the next iteration reads it; admm_get
+// re-materialises it with xf_kernel from the same d / t_in / x_in).
+// Algorithmic HBM bytes per stacked element, fp64:
+//     RESID or RELAX: d 8 m/(n+m) + z, y read 16 + z+, y+ written 16
+//     plain:          d 8 m/(n+m) + y read 8     + z+, y+ written 16
+// ---------------------------------------------------------------------------
+template <int NX, int NU, bool RESID, bool RELAX>
+__global__ __launch_bounds__(XB_THREADS) void xfz_kernel(
+    const double* __restrict__ dbuf, const double* __restrict__ tin, const double* __restrict__ xin,
+    const double* __restrict__ recF_, const int* __restrict__ seg_start_,
+    double* __restrict__ z, double* __restrict__ y, const double* __restrict__ lo_,
+    const double* __restrict__ hi_, double* __restrict__ part, double alpha, int pitch) {
+  constexpr int NB = NX + NU;
+  constexpr int RF = NU * NX + NU * NX + NX * NX + NX * NU;
+  constexpr int O_PSI = 0, O_K = NU * NX, O_A = O_K + NU * NX, O_B = O_A + NX * NX;
+  constexpr bool NEEDZ = RESID || RELAX;
+  const int col = blockIdx.x * XB_THREADS + threadIdx.x;
+  const int s = blockIdx.y;
+  if (col >= pitch) return;
+  cint_p seg_start = as_const(seg_start_);
+  const int k0 = seg_start[s], k1 = seg_start[s + 1];
+  const size_t P = (size_t)pitch;
+  cdouble_p lo = as_const(lo_);
+  cdouble_p hi = as_const(hi_);
+  double t[NX], x[NX];
+  {
+    const size_t o = (size_t)s * NX * P + col;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      t[i] = tin[o + i * P];
+      x[i] = xin[o + i * P];
+    }
+  }
+  double ld[NU], lz[NB], ly[NB];
+  {
+    const size_t d0 = (size_t)k0 * NU * P + col;
+#pragma unroll
+    for (int j = 0; j < NU; ++j) ld[j] = dbuf[d0 + j * P];
+    const size_t r0 = (size_t)k0 * NB * P + col;
+#pragma unroll
+    for (int r = 0; r < NB; ++r) {
+      ly[r] = y[r0 + r * P];
+      if (NEEDZ) lz[r] = z[r0 + r * P];
+    }
+  }
+  double a_r = 0, a_s = 0, a_w = 0, a_z = 0, a_y = 0;
+  for (int k = k0; k < k1; ++k) {
+    double d[NU], zc[NB], yc[NB];
+#pragma unroll
+    for (int j = 0; j < NU; ++j) d[j] = ld[j];
+#pragma unroll
+    for (int r = 0; r < NB; ++r) {
+      yc[r] = ly[r];
+      if (NEEDZ) zc[r] = lz[r];
+    }
+    {  // prefetch the next stage (clamped: the last one is a harmless re-read of
+       // rows this lane is about to overwrite -- same lane, program order)
+      const int kn = (k + 1 < k1) ? k + 1 : k;
+      const size_t d0 = (size_t)kn * NU * P + col;
+#pragma unroll
+      for (int j = 0; j < NU; ++j) ld[j] = dbuf[d0 + j * P];
+      const size_t r0 = (size_t)kn * NB * P + col;
+#pragma unroll
+      for (int r = 0; r < NB; ++r) {
+        ly[r] = y[r0 + r * P];
+        if (NEEDZ) lz[r] = z[r0 + r * P];
+      }
+    }
+    cdouble_p rf = as_const(recF_) + (size_t)k * RF;
+    double wv[NB];
+#pragma unroll
+    for (int j = 0; j < NU; ++j) {
+      double a = d[j];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) a = fma(rf[O_PSI + j * NX + i], t[i], a);
+#pragma unroll
+      for (int i = 0; i < NX; ++i) a = fma(rf[O_K + j * NX + i], x[i], a);
+      wv[j] = -a;
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      double a = 0.0;
+#pragma unroll
+      for (int l = 0; l < NX; ++l) a = fma(rf[O_A + i * NX + l], x[l], a);
+#pragma unroll
+      for (int j = 0; j < NU; ++j) a = fma(rf[O_B + i * NU + j], wv[j], a);
+      wv[NU + i] = a;
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) x[i] = wv[NU + i];
+    const size_t r0 = (size_t)k * NB * P + col;
+#pragma unroll
+    for (int r = 0; r < NB; ++r) {
+      const double l = lo[k * NB + r], h = hi[k * NB + r];
+      double wh = wv[r];
+      if (RELAX) wh = fma(alpha, wv[r], (1.0 - alpha) * zc[r]);
+      const double v = wh + yc[r];
+      const double zn = fmin(fmax(v, l), h);
+      const double yn = v - zn;
+      z[r0 + r * P] = zn;
+      y[r0 + r * P] = yn;
+      if (RESID) {
+        const double dr = wv[r] - zn, ds = zn - zc[r];
+        a_r = fma(dr, dr, a_r);
+        a_s = fma(ds, ds, a_s);
+        a_w = fma(wv[r], wv[r], a_w);
+        a_z = fma(zn, zn, a_z);
+        a_y = fma(yn, yn, a_y);
+      }
+    }
+  }
+  if (RESID) {
+    const size_t o = (size_t)s * 5 * P + col;
+    part[o + 0 * P] = a_r;
+    part[o + 1 * P] = a_s;
+    part[o + 2 * P] = a_w;
+    part[o + 3 * P] = a_z;
+    part[o + 4 * P] = a_y;
   }
 }
 
@@ -387,34 +593,51 @@ __global__ __launch_bounds__(Z_THREADS) void zdual_kernel(
 }
 
 // ---------------------------------------------------------------------------
-// Residual finalise + stopping rule.  One lane = one QP: sums the chunk
-// partials in chunk order (bitwise reproducible), takes square roots, applies
+// Residual finalise + stopping rule.  A workgroup = 64 QPs x 16 chunk groups:
+// each lane sums its group's chunk partials, the groups are combined through
+// LDS in a fixed order (bitwise reproducible), then one wave takes square roots, applies
 //   r <= sqrt(L) eps_abs + eps_rel max(|w|, |z|),  s <= sqrt(L) eps_abs + eps_rel rho |y|
 // records the first iteration at which the QP met it, and counts converged QPs
 // of the real batch (wave-shuffle reduction, one atomic per wave).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void resid_finalize_kernel(
+constexpr int FIN_COLS = 64;     // columns (QPs) per finalise workgroup: one wave wide
+constexpr int FIN_GROUPS = 16;   // chunk groups per workgroup (one wave each)
+
+__global__ __launch_bounds__(FIN_COLS * FIN_GROUPS) void resid_finalize_kernel(
     const double* __restrict__ part, double* __restrict__ resid, int* __restrict__ status,
     int* __restrict__ iters, int* __restrict__ nconv, double rho, double eps_abs, double eps_rel,
-    double sqrtL, int zchunks, int batch, int pitch, int it) {
-  const int col = blockIdx.x * 256 + threadIdx.x;
-  int ok_now = 0;
-  if (col < pitch) {
-    const size_t P = (size_t)pitch;
-    double a[5] = {0, 0, 0, 0, 0};
-    for (int c = 0; c < zchunks; ++c) {
-      const size_t o = (size_t)c * 5 * P + col;
+    double sqrtL, int nchunks, int batch, int pitch, int it) {
+  __shared__ double red[FIN_GROUPS][5][FIN_COLS];
+  const int lane = threadIdx.x & (FIN_COLS - 1), g = threadIdx.x / FIN_COLS;
+  const int col = blockIdx.x * FIN_COLS + lane;      // pitch is a multiple of 64
+  const size_t P = (size_t)pitch;
+  double a[5] = {0, 0, 0, 0, 0};
+  for (int c = g; c < nchunks; c += FIN_GROUPS) {
+    const size_t o = (size_t)c * 5 * P + col;
 #pragma unroll
-      for (int v = 0; v < 5; ++v) a[v] += part[o + v * P];
-    }
-    const double r = sqrt(a[0]), s = rho * sqrt(a[1]);
-    const double nw = sqrt(a[2]), nz = sqrt(a[3]), ny = rho * sqrt(a[4]);
-    resid[0 * P + col] = r;
-    resid[1 * P + col] = s;
-    resid[2 * P + col] = nw;
-    resid[3 * P + col] = nz;
-    resid[4 * P + col] = ny;
-    if (col < batch && it > 0) {
+    for (int v = 0; v < 5; ++v) a[v] += part[o + v * P];
+  }
+#pragma unroll
+  for (int v = 0; v < 5; ++v) red[g][v][lane] = a[v];
+  __syncthreads();
+  if (g != 0) return;
+  // fixed combination order (group 0, 1, ...): bitwise reproducible run to run
+#pragma unroll
+  for (int v = 0; v < 5; ++v) {
+    double t = red[0][v][lane];
+    for (int gg = 1; gg < FIN_GROUPS; ++gg) t += red[gg][v][lane];
+    a[v] = t;
+  }
+  const double r = sqrt(a[0]), s = rho * sqrt(a[1]);
+  const double nw = sqrt(a[2]), nz = sqrt(a[3]), ny = rho * sqrt(a[4]);
+  resid[0 * P + col] = r;
+  resid[1 * P + col] = s;
+  resid[2 * P + col] = nw;
+  resid[3 * P + col] = nz;
+  resid[4 * P + col] = ny;
+  if (it > 0) {
+    int ok_now = 0;
+    if (col < batch) {
       const double e_pri = sqrtL * eps_abs + eps_rel * fmax(nw, nz);
       const double e_dua = sqrtL * eps_abs + eps_rel * ny;
       int st = status[col];
@@ -425,13 +648,11 @@ __global__ __launch_bounds__(256) void resid_finalize_kernel(
       }
       ok_now = st;
     }
-  }
-  if (it > 0) {
-    // wave64 reduction of the converged count, then one atomic per wave
+    // wave64 shuffle reduction of the converged count, then one atomic per wave
     int v = ok_now;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    if ((threadIdx.x & 63) == 0 && v) atomicAdd(nconv, v);
+    if (lane == 0 && v) atomicAdd(nconv, v);
   }
 }
 

@@ -52,7 +52,7 @@ _SIGNATURES = {
     "admm_get_residuals": (C.c_int, [C.c_void_p] + [c_double_p] * 5),
     "admm_get": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p]),
     "admm_get_info": (C.c_int, [C.c_void_p, c_int32_p, c_int32_p, c_double_p, c_double_p]),
-    "admm_profile": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, c_double_p]),
+    "admm_profile": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, c_double_p]),
     "admm_get_geometry": (C.c_int, [C.c_void_p] + [c_int32_p] * 4),
     "admm_free": (None, [C.c_void_p]),
     "admm_last_error": (C.c_char_p, []),
@@ -216,10 +216,13 @@ class Solver:
         _check(self._lib, self._lib.admm_get(self._h, *[dptr(o) for o in outs]))
         return tuple(outs)
 
-    def profile(self, iters: int, residuals: bool = True):
-        ms = np.zeros(5)
-        _check(self._lib, self._lib.admm_profile(self._h, int(iters), int(bool(residuals)), dptr(ms)))
-        return {"xb_ms": ms[0], "xscan_ms": ms[1], "xf_ms": ms[2], "zdual_ms": ms[3], "iter_ms": ms[4]}
+    def profile(self, iters: int, residuals: bool = True, fused: bool = True):
+        ms = np.zeros(6)
+        _check(self._lib, self._lib.admm_profile(self._h, int(iters), int(bool(residuals)), int(bool(fused)), dptr(ms)))
+        if fused:
+            return {"xb_ms": ms[0], "xscan_ms": ms[1], "xfz_ms": ms[2], "finalize_ms": ms[4], "iter_ms": ms[5]}
+        return {"xb_ms": ms[0], "xscan_ms": ms[1], "xf_ms": ms[2], "zdual_ms": ms[3], "finalize_ms": ms[4],
+                "iter_ms": ms[5]}
 
     def geometry(self):
         v = [C.c_int32() for _ in range(4)]

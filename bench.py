@@ -10,18 +10,22 @@ before the timed region.  For N > 1 GPUs the global batch is 4096 * N QPs,
 sharded contiguously (weak scaling, no data-path collective: QPs are
 independent).
 
-A "step" = one batch-iteration over the rank's shard: x-update (backward
-sweep, segment scan, forward rollout) + the fused z-update / dual ascent /
-residual-partials kernel + the residual finalise kernel -- i.e. every
-iteration evaluates the residuals on the device (check_interval = 1), which is
-the most expensive honest form of the iteration.  `value` = QP-iterations/s
-summed over all ranks.
+A "step" = one batch-iteration over the rank's shard on the default (fused)
+path: x-update backward sweep (xb), segment scan (xscan), then the forward
+rollout fused with z-update / dual ascent / residual partials (xfz), then the
+residual finalise kernel -- i.e. every iteration evaluates the residuals on the
+device (check_interval = 1), which is the most expensive honest form of the
+iteration.  `value` = QP-iterations/s summed over all ranks.
 
 Extra objects on the JSON line:
-  roofline     -- the fused z/dual/residual kernel: 40 B per stacked element
-                  (3 reads + 2 writes, fp64) x L x pitch per launch, divided by
-                  its average launch duration measured with HIP events on the
-                  library's own stream (admm_profile).
+  roofline     -- the dominant kernel, xfz<RESID>: 8 m/(n+m) + 32 = 34.67 B per
+                  stacked element (d, z, y read; z+, y+ written; fp64) x L x
+                  pitch per launch, divided by its average launch duration
+                  measured with HIP events on the library's own stream
+                  (admm_profile).
+  roofline_zdual_standalone -- the standalone fused z/dual/residual kernel of
+                  the ADMM_FLAG_UNFUSED path (40 B per element),
+                  measured the same way in the same run.
   cpu_baseline -- the C/OpenMP CPU oracle (kind "port": the reference ships no
                   code) on a bounded sample of the same workload, rank 0, N=1.
 """
@@ -63,10 +67,11 @@ def cpu_baseline(N, target_s):
     cores = oracle_c.max_threads()
     sample_batch = max(cores * 4, 16)
     p = pkg.cw_rendezvous(N=N, batch=sample_batch)
+    oracle_c.solve(p, rho=0.05, max_iter=2, check_interval=1, stop=False, nthreads=cores)   # spin up threads
     t0 = time.perf_counter()
-    oracle_c.solve(p, rho=0.05, max_iter=2, check_interval=1, stop=False, nthreads=cores)
-    t_cal = (time.perf_counter() - t0) / 2
-    iters = int(max(5, min(2000, target_s / max(t_cal, 1e-6))))
+    oracle_c.solve(p, rho=0.05, max_iter=10, check_interval=1, stop=False, nthreads=cores)
+    t_cal = (time.perf_counter() - t0) / 10
+    iters = int(max(10, min(100000, target_s / max(t_cal, 1e-6))))
     t0 = time.perf_counter()
     oracle_c.solve(p, rho=0.05, max_iter=iters, check_interval=1, stop=False, nthreads=cores)
     dt = time.perf_counter() - t0
@@ -127,16 +132,29 @@ def main():
     ms_per_step = dt / a.steps * 1e3
     value = gbatch * a.steps / dt
 
-    # per-kernel timing on the library's stream (HIP events), residual form and plain form
-    prof = solver.profile(min(a.steps, 100), residuals=True)
-    prof_plain = solver.profile(min(a.steps, 100), residuals=False)
+    # per-kernel timing on the library's stream (HIP events)
+    npf = min(a.steps, 100)
+    prof = solver.profile(npf, residuals=True, fused=True)           # the timed path
+    prof_plain = solver.profile(npf, residuals=False, fused=True)
+    prof_unf = solver.profile(npf, residuals=True, fused=False)      # standalone z/dual kernel
     L = full.L
     elems = L * geo["pitch"]
-    z_ms = prof["zdual_ms"]
-    achieved = BYTES_PER_ELEM_ZDUAL * elems / (z_ms * 1e-3) / 1e9
-    roofline = {"kernel": "zdual_kernel<RESID=true>", "bound": "hbm", "achieved": achieved,
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "bytes_per_launch": BYTES_PER_ELEM_ZDUAL * elems, "avg_launch_ms": z_ms}
+    n_, m_ = full.n, full.m
+    b_xfz = 8.0 * m_ / (n_ + m_) + 32.0          # d read + z, y read + z+, y+ written
+    xfz_ms = prof["xfz_ms"]
+    achieved = b_xfz * elems / (xfz_ms * 1e-3) / 1e9
+    roofline = {"kernel": "xfz_kernel<6,3,RESID=true> (forward rollout fused with z-update + dual ascent + residual partials)",
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "bytes_per_launch": b_xfz * elems, "bytes_per_element": b_xfz, "avg_launch_ms": xfz_ms}
+    zs_ms = prof_unf["zdual_ms"]
+    zs = BYTES_PER_ELEM_ZDUAL * elems / (zs_ms * 1e-3) / 1e9
+    standalone = {"kernel": "zdual_kernel<RESID=true> (standalone fused z-update + dual + residual, ADMM_FLAG_UNFUSED path)",
+                  "bound": "hbm", "achieved": zs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": zs / HBM_PEAK_GBS,
+                  "bytes_per_launch": BYTES_PER_ELEM_ZDUAL * elems, "bytes_per_element": BYTES_PER_ELEM_ZDUAL,
+                  "avg_launch_ms": zs_ms}
+    b_xb = 16.0 + 8.0 * m_ / (n_ + m_)
+    xb_gbs = b_xb * elems / (prof["xb_ms"] * 1e-3) / 1e9
 
     # mixed mode a solver would normally run: residuals every 10th iteration
     solver.run(10, residual_every=10)
@@ -160,9 +178,11 @@ def main():
                        "rho": 0.05, "sharding": f"batch/{world}, no collective in the iteration",
                        **geo},
             "roofline": roofline,
-            "kernels_ms": {**{k: round(v, 5) for k, v in prof.items()},
-                           "zdual_plain_ms": round(prof_plain["zdual_ms"], 5),
-                           "zdual_plain_GBs": BYTES_PER_ELEM_ZPLAIN * elems / (prof_plain["zdual_ms"] * 1e-3) / 1e9},
+            "roofline_zdual_standalone": standalone,
+            "kernels_ms": {"fused_resid": {k: round(v, 5) for k, v in prof.items()},
+                           "fused_plain": {k: round(v, 5) for k, v in prof_plain.items()},
+                           "unfused_resid": {k: round(v, 5) for k, v in prof_unf.items()},
+                           "xb_GBs": xb_gbs},
             "check_interval_10": {"batch_iterations_per_s": a.steps / dt10,
                                   "QP_iterations_per_s": a.batch * a.steps / dt10},
         }

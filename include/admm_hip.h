@@ -80,6 +80,8 @@ typedef struct admm_options {
 
 #define ADMM_FLAG_NONE 0
 #define ADMM_FLAG_NO_GRAPH 1   /* launch kernels directly instead of replaying a hipGraph */
+#define ADMM_FLAG_UNFUSED 2    /* iterate with separate forward-rollout and z/dual kernels (w stored
+                                  every iteration) instead of the fused xfz kernel */
 
 typedef struct admm_info {
   int32_t iters_run;      /* batch iterations executed by the last admm_solve */
@@ -138,11 +140,16 @@ int admm_get(admm_handle* h, double* w, double* z, double* y);
 int admm_get_info(admm_handle* h, int32_t* iters, int32_t* status, double* r, double* s);
 
 /* Timing hook for bench.py: runs `iters` iterations with HIP events recorded
- * on the handle's stream around each kernel.  ms[0..3] = average duration of
- * {x-update backward, segment scan, x-update forward, fused z/dual/residual}
- * per launch; ms[4] = average whole iteration.  `residuals` selects the
- * residual-evaluating form of the z kernel. */
-int admm_profile(admm_handle* h, int32_t iters, int32_t residuals, double ms[5]);
+ * on the handle's stream around each kernel launch and returns average
+ * durations in ms.  fused_path != 0 (the default iteration path):
+ *   ms = {xb, xscan, xfz, 0, finalise, whole iteration}
+ * fused_path == 0 (ADMM_FLAG_UNFUSED path):
+ *   ms = {xb, xscan, xf, zdual, finalise, whole iteration}
+ * xb = x-update backward sweep, xscan = segment scan, xf = forward rollout,
+ * zdual = standalone fused z/dual/residual kernel, xfz = forward rollout fused
+ * with z/dual/residual.  `residuals` selects the residual-evaluating kernel
+ * forms (+ the finalise kernel). */
+int admm_profile(admm_handle* h, int32_t iters, int32_t residuals, int32_t fused_path, double ms[6]);
 
 /* Geometry chosen at setup, for roofline accounting: pitch = padded batch,
  * segs = x-update segments, zrows = rows per z-kernel chunk, zchunks. */

@@ -96,12 +96,15 @@ def test_zdual_kernel(gpu, alpha, resid):
             assert np.abs(got - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize("flags", [0, 2], ids=["fused", "unfused"])
 @pytest.mark.parametrize("idx", [0, 1, 3, 5, 7, 9])
-def test_iterate_parity(gpu, idx):
-    """T4: iterates of the full loop vs the C oracle after 1, 2, 10, 40 iterations."""
+def test_iterate_parity(gpu, idx, flags):
+    """T4: iterates of the full loop vs the C oracle after 1, 2, 10, 40 iterations,
+    on the default fused path (xb, xscan, xfz) and on the ADMM_FLAG_UNFUSED path
+    (xb, xscan, xf, zdual).  w is re-materialised by admm_get on the fused path."""
     make, rho, segs = CASES[idx]
     p = make()
-    with pkg.Solver(p, pkg.Options(rho=rho, segments=segs)) as s:
+    with pkg.Solver(p, pkg.Options(rho=rho, segments=segs, flags=flags)) as s:
         done = 0
         for upto in (1, 2, 10, 40):
             s.iterate(upto - done)
@@ -110,6 +113,20 @@ def test_iterate_parity(gpu, idx):
             ref = oc.solve(p, rho=rho, max_iter=upto, stop=False)
             for a, b in ((w, ref["w"]), (z, ref["z"]), (y, ref["y"])):
                 assert np.abs(a - b).max() <= TOL * max(1.0, np.abs(b).max()), (upto,)
+
+
+def test_fused_relaxed_with_residuals(gpu):
+    """Fused path with over-relaxation and residuals every iteration (admm_run)."""
+    p = pkg.random_ltv(N=33, n=6, m=3, batch=69, seed=31)
+    rho, alpha = 0.3, 1.6
+    with pkg.Solver(p, pkg.Options(rho=rho, alpha=alpha, segments=4)) as s:
+        s.run(12, residual_every=1)
+        w, z, y = s.get()
+        r, sd, nw, nz, ny = s.residuals()
+    ref = oc.solve(p, rho=rho, alpha=alpha, max_iter=12, check_interval=1, eps_abs=0, eps_rel=0, stop=False)
+    for a, b in ((w, ref["w"]), (z, ref["z"]), (y, ref["y"])):
+        assert np.abs(a - b).max() <= TOL * max(1.0, np.abs(b).max())
+    assert np.abs(r - ref["r"]).max() <= 1e-10 and np.abs(sd - ref["s"]).max() <= 1e-10
 
 
 def test_graph_and_direct_launch_agree(gpu):
@@ -123,13 +140,14 @@ def test_graph_and_direct_launch_agree(gpu):
         np.testing.assert_array_equal(a, b)
 
 
+@pytest.mark.parametrize("flags", [0, 2], ids=["fused", "unfused"])
 @pytest.mark.parametrize("alpha", [1.0, 1.5])
-def test_solve_matches_oracle(gpu, alpha):
+def test_solve_matches_oracle(gpu, alpha, flags):
     """Full admm_solve: stopping rule, per-QP iteration counts, warm start."""
     p = pkg.double_integrator(N=50, batch=37)
     kw = dict(rho=1.0, alpha=alpha, eps_abs=1e-7, eps_rel=1e-7, max_iter=3000, check_interval=10)
     ref = oc.solve(p, **kw)
-    with pkg.Solver(p, pkg.Options(**kw)) as s:
+    with pkg.Solver(p, pkg.Options(flags=flags, **kw)) as s:
         info = s.solve()
         w, z, y = s.get()
         assert info.iters_run == ref["iters_run"]
