@@ -27,3 +27,32 @@ def shard_bounds(batch: int, world_size: int, rank: int) -> Tuple[int, int]:
 def shard_problem(problem: Problem, world_size: int, rank: int) -> Problem:
     start, stop = shard_bounds(problem.batch, world_size, rank)
     return problem.slice(start, stop)
+
+
+def gather_batch(local, batch: int, group=None):
+    """All-gather per-QP rows (first axis = this rank's shard) into the full
+    batch on every rank.  Works on CPU tensors over gloo and on GPU tensors over
+    RCCL (backend "nccl").  Shards may differ in size by one QP (shard_bounds),
+    so rows are padded to the largest shard for the collective and trimmed after.
+    Off the hot loop: used once per solve to collect results."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    sizes = [shard_bounds(batch, world, r) for r in range(world)]
+    max_rows = max(b - a for a, b in sizes)
+    t = torch.as_tensor(local)
+    pad = torch.zeros((max_rows,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    pad[: t.shape[0]] = t
+    out = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(out, pad, group=group)
+    return torch.cat([o[: b - a] for o, (a, b) in zip(out, sizes)], dim=0)
+
+
+def global_residual_max(r_max: float, s_max: float, device="cpu", group=None):
+    """One MAX all-reduce of two doubles: the global stop decision of a sharded
+    solve.  Latency-bound, once per convergence check."""
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([r_max, s_max], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return float(t[0]), float(t[1])
