@@ -1,0 +1,176 @@
+// admm_mex.cpp -- MEX gateway: marshals mxArray <-> the C ABI of libadmm_hip.so
+// (include/admm_hip.h).  It contains no arithmetic.
+//
+// STATUS: written against the documented MEX C API (mex.h / matrix.h), compile-
+// checked only against a minimal declaration shim (tests/mex_shim/mex.h); it has
+// NEVER been linked against libmx/libmex or executed: no MATLAB, Octave, mex or
+// mex.h exists in the build image or on the GPU box.  The
+// reference defines no MEX interface to mirror (README.md:1-2 only), so the
+// command set below is this repository's own.
+//
+// Build (on a machine with MATLAB + ROCm):
+//   mex -I../include admm_mex.cpp -L../admm-library_amd -ladmm_hip
+//
+// Usage from MATLAB (see admm_setup.m / admm_solve.m / admm_get.m / admm_free.m):
+//   h    = admm_mex('setup', problem, options)   % uint64 scalar handle
+//   info = admm_mex('solve', h, z0, y0)          % z0, y0 optional / []
+//   [w, z, y] = admm_mex('get', h)
+//   admm_mex('iterate', h, iters)
+//   admm_mex('free', h)
+//
+// MATLAB arrays are column-major doubles, exactly the ABI's layout: A (n x n or
+// n x n x N), B (n x m [x N]), x0 (n x batch), q (L x batch), lo/hi ((m+n) x 1 or
+// (m+n) x N) are passed by pointer, no copies.
+#include <cstdint>
+#include <cstring>
+
+#include "mex.h"
+
+#include "admm_hip.h"
+
+namespace {
+
+void fail(const char* id, const char* msg) { mexErrMsgIdAndTxt(id, "%s", msg); }
+
+void check(int rc) {
+  if (rc != ADMM_OK) mexErrMsgIdAndTxt("admm:library", "libadmm_hip error %d: %s", rc, admm_last_error());
+}
+
+const mxArray* field(const mxArray* s, const char* name, bool required) {
+  const mxArray* f = mxGetField(s, 0, name);
+  if (!f && required) mexErrMsgIdAndTxt("admm:input", "problem field '%s' is missing", name);
+  return f;
+}
+
+const double* dbl(const mxArray* a, const char* name) {
+  if (!a || mxIsEmpty(a)) return nullptr;
+  if (!mxIsDouble(a) || mxIsComplex(a) || mxIsSparse(a))
+    mexErrMsgIdAndTxt("admm:input", "'%s' must be a full real double array", name);
+  return mxGetPr(a);
+}
+
+double scalar_or(const mxArray* s, const char* name, double dflt) {
+  const mxArray* f = s ? mxGetField(s, 0, name) : nullptr;
+  return (f && !mxIsEmpty(f)) ? mxGetScalar(f) : dflt;
+}
+
+admm_handle* handle_of(const mxArray* a) {
+  if (!a || !mxIsUint64(a) || mxGetNumberOfElements(a) != 1) fail("admm:input", "handle must be a uint64 scalar");
+  admm_handle* h = reinterpret_cast<admm_handle*>(static_cast<uintptr_t>(*static_cast<const uint64_t*>(mxGetData(a))));
+  if (!h) fail("admm:input", "handle is null (already freed?)");
+  return h;
+}
+
+// sizes remembered per handle so that 'get' can size its outputs
+struct Dims { admm_handle* h; int L, batch; };
+Dims g_dims[64];
+int g_ndims = 0;
+
+void remember(admm_handle* h, int L, int batch) {
+  for (int i = 0; i < g_ndims; ++i) if (!g_dims[i].h) { g_dims[i] = {h, L, batch}; return; }
+  if (g_ndims < 64) g_dims[g_ndims++] = {h, L, batch};
+  else fail("admm:limit", "too many live handles (64)");
+}
+Dims* lookup(admm_handle* h) {
+  for (int i = 0; i < g_ndims; ++i) if (g_dims[i].h == h) return &g_dims[i];
+  fail("admm:input", "unknown handle");
+  return nullptr;
+}
+
+}  // namespace
+
+void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
+  if (nrhs < 1 || !mxIsChar(prhs[0])) fail("admm:input", "first argument must be a command string");
+  char cmd[32];
+  mxGetString(prhs[0], cmd, sizeof cmd);
+
+  if (!std::strcmp(cmd, "setup")) {
+    if (nrhs < 2 || !mxIsStruct(prhs[1])) fail("admm:input", "setup needs a problem struct");
+    const mxArray* P = prhs[1];
+    const mxArray* O = (nrhs > 2 && mxIsStruct(prhs[2])) ? prhs[2] : nullptr;
+    const mxArray *A = field(P, "A", true), *B = field(P, "B", true), *x0 = field(P, "x0", true);
+    const mxArray *lo = field(P, "lo", true), *hi = field(P, "hi", true), *q = field(P, "q", false);
+    admm_problem p;
+    std::memset(&p, 0, sizeof p);
+    p.N = static_cast<int32_t>(mxGetScalar(field(P, "N", true)));
+    p.n = static_cast<int32_t>(mxGetM(B));
+    const mwSize* bd = mxGetDimensions(B);
+    p.m = static_cast<int32_t>(bd[1]);
+    p.batch = static_cast<int32_t>(mxGetN(x0));
+    p.time_varying = mxGetNumberOfDimensions(A) == 3 ? 1 : 0;
+    p.stage_bounds = mxGetN(lo) > 1 ? 1 : 0;
+    if (static_cast<int32_t>(mxGetM(x0)) != p.n) fail("admm:input", "x0 must be n x batch");
+    if (static_cast<int32_t>(mxGetM(lo)) != p.n + p.m || static_cast<int32_t>(mxGetM(hi)) != p.n + p.m)
+      fail("admm:input", "lo/hi must have m+n rows (u block, then x block)");
+    if (p.stage_bounds && static_cast<int32_t>(mxGetN(lo)) != p.N) fail("admm:input", "per-stage bounds need N columns");
+    if (p.time_varying && static_cast<int32_t>(mxGetDimensions(A)[2]) != p.N) fail("admm:input", "time-varying A needs N pages");
+    p.A = dbl(A, "A"); p.B = dbl(B, "B");
+    p.Q = dbl(field(P, "Q", true), "Q"); p.R = dbl(field(P, "R", true), "R"); p.QN = dbl(field(P, "QN", true), "QN");
+    p.x0 = dbl(x0, "x0"); p.lo = dbl(lo, "lo"); p.hi = dbl(hi, "hi");
+    p.q = dbl(q, "q");
+    const int L = p.N * (p.n + p.m);
+    if (p.q && (static_cast<int>(mxGetM(q)) != L || static_cast<int32_t>(mxGetN(q)) != p.batch)) fail("admm:input", "q must be L x batch");
+    admm_options o;
+    admm_default_options(&o);
+    o.rho = scalar_or(O, "rho", o.rho);
+    o.alpha = scalar_or(O, "alpha", o.alpha);
+    o.eps_abs = scalar_or(O, "eps_abs", o.eps_abs);
+    o.eps_rel = scalar_or(O, "eps_rel", o.eps_rel);
+    o.max_iter = static_cast<int32_t>(scalar_or(O, "max_iter", o.max_iter));
+    o.check_interval = static_cast<int32_t>(scalar_or(O, "check_interval", o.check_interval));
+    o.segments = static_cast<int32_t>(scalar_or(O, "segments", 0));
+    o.device = static_cast<int32_t>(scalar_or(O, "device", -1));
+    o.flags = static_cast<int32_t>(scalar_or(O, "flags", 0));
+    admm_handle* h = nullptr;
+    check(admm_setup(&h, &p, &o));
+    remember(h, L, p.batch);
+    plhs[0] = mxCreateNumericMatrix(1, 1, mxUINT64_CLASS, mxREAL);
+    *static_cast<uint64_t*>(mxGetData(plhs[0])) = static_cast<uint64_t>(reinterpret_cast<uintptr_t>(h));
+    return;
+  }
+
+  if (nrhs < 2) fail("admm:input", "this command needs a handle");
+  admm_handle* h = handle_of(prhs[1]);
+  Dims* d = lookup(h);
+
+  if (!std::strcmp(cmd, "solve")) {
+    const double* z0 = nrhs > 2 ? dbl(prhs[2], "z0") : nullptr;
+    const double* y0 = nrhs > 3 ? dbl(prhs[3], "y0") : nullptr;
+    if (z0 && mxGetNumberOfElements(prhs[2]) != static_cast<size_t>(d->L) * d->batch) fail("admm:input", "z0 must be L x batch");
+    if (y0 && mxGetNumberOfElements(prhs[3]) != static_cast<size_t>(d->L) * d->batch) fail("admm:input", "y0 must be L x batch");
+    admm_info info;
+    check(admm_solve(h, z0, y0, &info));
+    const char* names[] = {"iters_run", "n_converged", "max_r", "max_s", "solve_ms", "iters", "status", "r", "s"};
+    plhs[0] = mxCreateStructMatrix(1, 1, 9, names);
+    mxSetField(plhs[0], 0, "iters_run", mxCreateDoubleScalar(info.iters_run));
+    mxSetField(plhs[0], 0, "n_converged", mxCreateDoubleScalar(info.n_converged));
+    mxSetField(plhs[0], 0, "max_r", mxCreateDoubleScalar(info.max_r));
+    mxSetField(plhs[0], 0, "max_s", mxCreateDoubleScalar(info.max_s));
+    mxSetField(plhs[0], 0, "solve_ms", mxCreateDoubleScalar(info.solve_ms));
+    mxArray* it = mxCreateNumericMatrix(d->batch, 1, mxINT32_CLASS, mxREAL);
+    mxArray* st = mxCreateNumericMatrix(d->batch, 1, mxINT32_CLASS, mxREAL);
+    mxArray* r = mxCreateDoubleMatrix(d->batch, 1, mxREAL);
+    mxArray* s = mxCreateDoubleMatrix(d->batch, 1, mxREAL);
+    check(admm_get_info(h, static_cast<int32_t*>(mxGetData(it)), static_cast<int32_t*>(mxGetData(st)), mxGetPr(r), mxGetPr(s)));
+    mxSetField(plhs[0], 0, "iters", it);
+    mxSetField(plhs[0], 0, "status", st);
+    mxSetField(plhs[0], 0, "r", r);
+    mxSetField(plhs[0], 0, "s", s);
+  } else if (!std::strcmp(cmd, "get")) {
+    double* out[3] = {nullptr, nullptr, nullptr};
+    for (int i = 0; i < 3 && i < (nlhs > 0 ? nlhs : 1); ++i) {
+      plhs[i] = mxCreateDoubleMatrix(d->L, d->batch, mxREAL);
+      out[i] = mxGetPr(plhs[i]);
+    }
+    check(admm_get(h, out[0], out[1], out[2]));
+  } else if (!std::strcmp(cmd, "iterate")) {
+    if (nrhs < 3) fail("admm:input", "iterate needs an iteration count");
+    check(admm_iterate(h, static_cast<int32_t>(mxGetScalar(prhs[2]))));
+    check(admm_sync(h));
+  } else if (!std::strcmp(cmd, "free")) {
+    d->h = nullptr;
+    admm_free(h);
+  } else {
+    mexErrMsgIdAndTxt("admm:input", "unknown command '%s'", cmd);
+  }
+}
