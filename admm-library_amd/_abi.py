@@ -22,6 +22,7 @@ STATUS_NAMES = {0: "ADMM_OK", 1: "ADMM_ERR_INVALID", 2: "ADMM_ERR_UNSUPPORTED",
 FLAG_NONE = 0
 FLAG_NO_GRAPH = 1
 FLAG_UNFUSED = 2
+FLAG_SCAN_CHAIN = 4
 
 c_double_p = C.POINTER(C.c_double)
 c_int32_p = C.POINTER(C.c_int32)

@@ -47,6 +47,8 @@ struct admm_handle {
   double *dbuf = nullptr, *tseg = nullptr, *eseg = nullptr, *tin = nullptr, *xin = nullptr;
   double *part = nullptr, *resid = nullptr, *lo = nullptr, *hi = nullptr;
   double *recB = nullptr, *recF = nullptr, *recS = nullptr;
+  double *scan_in = nullptr, *scan_out = nullptr, *scanWp = nullptr;   // tseg|x0|eseg and t_in|x_in live inside these
+  int* scan_range = nullptr;
   int *seg_start = nullptr, *status = nullptr, *iters = nullptr, *nconv = nullptr;
   double* stage = nullptr;      // QP-major staging buffer, L * batch
   int* h_nconv = nullptr;       // pinned
@@ -102,7 +104,18 @@ int launch_xb(admm_handle* h) {
   return fail(ADMM_ERR_UNSUPPORTED, "no x-update kernel for this (n, m)");
 }
 
+static_assert(admm::SCAN_KALIGN == 2 * admm::SCAN_U, "host range alignment must match the kernel's batch");
+
+int launch_xscan_mfma(admm_handle* h) {
+  const int mtiles = h->fac.scanM / 16, ngroups = mtiles / admm::SCAN_MT;
+  dim3 grid(h->pitch / 16, (ngroups + 3) / 4), block(256);
+  hipLaunchKernelGGL((admm::xscan_mfma_kernel<admm::SCAN_MT>), grid, block, 0, h->stream, h->scanWp,
+                     h->scan_in, h->scan_out, h->scan_range, mtiles, ngroups, h->pitch);
+  return ADMM_OK;
+}
+
 int launch_xscan(admm_handle* h) {
+  if (!(h->opt.flags & ADMM_FLAG_SCAN_CHAIN)) return launch_xscan_mfma(h);
   dim3 grid(h->pitch / 64), block(64);
   switch (h->n) {
 #define C(NX)                                                                                        \
@@ -270,11 +283,11 @@ void release(admm_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   destroy_graph(h);
-  double** bufs[] = {&h->w, &h->z, &h->y, &h->q, &h->x0, &h->dbuf, &h->tseg, &h->eseg, &h->tin, &h->xin,
+  double** bufs[] = {&h->w, &h->z, &h->y, &h->q, &h->dbuf, &h->scan_in, &h->scan_out, &h->scanWp,
                      &h->part, &h->resid, &h->lo, &h->hi, &h->recB, &h->recF, &h->recS, &h->stage};
   for (auto b : bufs)
     if (*b) { (void)hipFree(*b); *b = nullptr; }
-  int** ibufs[] = {&h->seg_start, &h->status, &h->iters, &h->nconv};
+  int** ibufs[] = {&h->seg_start, &h->status, &h->iters, &h->nconv, &h->scan_range};
   for (auto b : ibufs)
     if (*b) { (void)hipFree(*b); *b = nullptr; }
   if (h->h_nconv) { (void)hipHostFree(h->h_nconv); h->h_nconv = nullptr; }
@@ -356,6 +369,20 @@ int admm_host_factor(const admm_problem* p, double rho, int32_t segments, double
   return ADMM_OK;
 }
 
+int admm_host_scan_matrix(const admm_problem* p, double rho, int32_t segments, double* W, int32_t* M,
+                          int32_t* Mt, int32_t* K) {
+  if (!p) return fail(ADMM_ERR_INVALID, "NULL problem");
+  admm::Factor f;
+  std::string err;
+  int rc = admm::factorise(*p, rho, segments, f, err);
+  if (rc) return fail(rc, err);
+  if (M) *M = f.scanM;
+  if (Mt) *Mt = f.scanMt;
+  if (K) *K = f.scanK;
+  if (W) std::memcpy(W, f.scanW.data(), sizeof(double) * f.scanW.size());
+  return ADMM_OK;
+}
+
 int admm_setup(admm_handle** out, const admm_problem* p, const admm_options* o_in) {
   if (!out || !p) return fail(ADMM_ERR_INVALID, "NULL argument");
   *out = nullptr;
@@ -425,12 +452,21 @@ int admm_setup(admm_handle** out, const admm_problem* p, const admm_options* o_i
   TRY_RELEASE(dalloc(&h->z, L * P));
   TRY_RELEASE(dalloc(&h->y, L * P));
   if (h->has_q) TRY_RELEASE(dalloc(&h->q, L * P));
-  TRY_RELEASE(dalloc(&h->x0, (size_t)h->n * P));
   TRY_RELEASE(dalloc(&h->dbuf, (size_t)h->N * h->m * P));
-  TRY_RELEASE(dalloc(&h->tseg, (size_t)h->S * h->n * P));
-  TRY_RELEASE(dalloc(&h->eseg, (size_t)h->S * h->n * P));
-  TRY_RELEASE(dalloc(&h->tin, (size_t)h->S * h->n * P));
-  TRY_RELEASE(dalloc(&h->xin, (size_t)h->S * h->n * P));
+  {  // scan operands: in = tseg | x0 | eseg | pad,  out = t_in | pad | x_in | pad  (admm_factor.hpp)
+    const size_t Sn = (size_t)h->S * h->n;
+    TRY_RELEASE(dalloc(&h->scan_in, (size_t)h->fac.scanK * P));
+    TRY_RELEASE(dalloc(&h->scan_out, (size_t)h->fac.scanM * P));
+    HIP_TRY_RELEASE(hipMemsetAsync(h->scan_in, 0, sizeof(double) * (size_t)h->fac.scanK * P, h->stream));
+    HIP_TRY_RELEASE(hipMemsetAsync(h->scan_out, 0, sizeof(double) * (size_t)h->fac.scanM * P, h->stream));
+    h->tseg = h->scan_in;
+    h->x0 = h->scan_in + Sn * P;
+    h->eseg = h->scan_in + (Sn + h->n) * P;
+    h->tin = h->scan_out;
+    h->xin = h->scan_out + (size_t)h->fac.scanMt * P;
+    TRY_RELEASE(dalloc(&h->scanWp, h->fac.scanWp.size()));
+    TRY_RELEASE(dalloc(&h->scan_range, h->fac.scanRange.size()));
+  }
   const size_t part_chunks = (size_t)(h->zchunks > h->S ? h->zchunks : h->S);
   TRY_RELEASE(dalloc(&h->part, part_chunks * 5 * P));
   TRY_RELEASE(dalloc(&h->resid, 5 * P));
@@ -469,6 +505,8 @@ int admm_setup(admm_handle** out, const admm_problem* p, const admm_options* o_i
   HIP_TRY_RELEASE(hipMemcpy(h->recB, h->fac.recB.data(), sizeof(double) * h->fac.recB.size(), hipMemcpyHostToDevice));
   HIP_TRY_RELEASE(hipMemcpy(h->recF, h->fac.recF.data(), sizeof(double) * h->fac.recF.size(), hipMemcpyHostToDevice));
   HIP_TRY_RELEASE(hipMemcpy(h->recS, h->fac.recS.data(), sizeof(double) * h->fac.recS.size(), hipMemcpyHostToDevice));
+  HIP_TRY_RELEASE(hipMemcpy(h->scanWp, h->fac.scanWp.data(), sizeof(double) * h->fac.scanWp.size(), hipMemcpyHostToDevice));
+  HIP_TRY_RELEASE(hipMemcpy(h->scan_range, h->fac.scanRange.data(), sizeof(int32_t) * h->fac.scanRange.size(), hipMemcpyHostToDevice));
   HIP_TRY_RELEASE(hipMemcpy(h->seg_start, h->fac.seg_start.data(), sizeof(int32_t) * h->fac.seg_start.size(), hipMemcpyHostToDevice));
   TRY_RELEASE(upload_transposed(h, p->x0, h->x0, h->n));
   if (h->has_q) TRY_RELEASE(upload_transposed(h, p->q, h->q, h->L));

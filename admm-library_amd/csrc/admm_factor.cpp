@@ -200,6 +200,78 @@ int factorise(const admm_problem& p, double rho, int segments, Factor& f, std::s
     for (int i = 0; i < f.RS; ++i)
       if (!std::isfinite(rs[i])) { err = "segment transfer matrices overflowed; use more segments"; return ADMM_ERR_NUMERIC; }
   }
+
+  // ---- scan matrix ----
+  {
+    const int Sn = S * n;
+    auto round_up = [](int v, int q) { return ((v + q - 1) / q) * q; };
+    const int Mt = round_up(Sn, 16 * SCAN_MT);          // rows of the t_in half (padded)
+    const int M = 2 * Mt;
+    const int K = round_up(2 * Sn + n, 4 * SCAN_KALIGN);
+    f.scanM = M; f.scanMt = Mt; f.scanK = K;
+    f.scanW.assign((size_t)M * K, 0.0);
+    auto W = [&](int r, int c) -> double& { return f.scanW[(size_t)r * K + c]; };
+    auto blk = [&](const double* rs, int which) { return Mat(rs + (size_t)which * n * n, rs + (size_t)(which + 1) * n * n); };
+    std::vector<Mat> Phi(S), Xi(S), Th(S);
+    for (int s = 0; s < S; ++s) {
+      const double* rs = &f.recS[(size_t)s * f.RS];
+      Phi[s] = blk(rs, 0); Xi[s] = blk(rs, 1); Th[s] = blk(rs, 2);
+    }
+    const int c_t = 0, c_x0 = Sn, c_e = Sn + n;           // column offsets of tseg | x0 | eseg
+    const int r_t = 0, r_x = Mt;                          // row offsets of t_in | x_in
+    // t_in(s) = sum_{s' > s} [Phi_{s+1} ... Phi_{s'-1}] tseg(s')
+    std::vector<std::vector<Mat>> MtB(S, std::vector<Mat>(S));   // MtB[s][s'] (s' > s)
+    for (int s = 0; s < S; ++s) {
+      Mat P = eye(n);
+      for (int sp = s + 1; sp < S; ++sp) {
+        MtB[s][sp] = P;
+        for (int i = 0; i < n; ++i)
+          for (int j = 0; j < n; ++j) W(r_t + s * n + i, c_t + sp * n + j) = P[(size_t)i * n + j];
+        P = mul(P, Phi[sp], n, n, n);
+      }
+    }
+    // x_in(s) = [Th_{s-1}...Th_0] x0 + sum_{s' < s} [Th_{s-1}...Th_{s'+1}] (eseg(s') + Xi_{s'} t_in(s'))
+    for (int s = 0; s < S; ++s) {
+      Mat P = eye(n);
+      for (int sp = s - 1; sp >= 0; --sp) {
+        for (int i = 0; i < n; ++i)
+          for (int j = 0; j < n; ++j) W(r_x + s * n + i, c_e + sp * n + j) = P[(size_t)i * n + j];
+        const Mat PX = mul(P, Xi[sp], n, n, n);            // U(s, s') Xi_{s'}
+        for (int spp = sp + 1; spp < S; ++spp) {           // ... times Mt(s', s'')
+          const Mat G = mul(PX, MtB[sp][spp], n, n, n);
+          for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j) W(r_x + s * n + i, c_t + spp * n + j) += G[(size_t)i * n + j];
+        }
+        P = mul(P, Th[sp], n, n, n);
+      }
+      for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) W(r_x + s * n + i, c_x0 + j) = P[(size_t)i * n + j];
+    }
+    for (double v : f.scanW)
+      if (!std::isfinite(v)) { err = "scan matrix overflowed; use more segments"; return ADMM_ERR_NUMERIC; }
+    // pack in MFMA A-fragment order and find each M-group's non-zero k-step range
+    const int mtiles = M / 16, ksteps = K / 4, groups = mtiles / SCAN_MT;
+    f.scanWp.assign((size_t)ksteps * mtiles * 64, 0.0);
+    for (int ks = 0; ks < ksteps; ++ks)
+      for (int mt = 0; mt < mtiles; ++mt)
+        for (int lane = 0; lane < 64; ++lane)
+          f.scanWp[((size_t)ks * mtiles + mt) * 64 + lane] = W(16 * mt + (lane & 15), 4 * ks + (lane >> 4));
+    f.scanRange.assign((size_t)2 * groups, 0);
+    for (int g = 0; g < groups; ++g) {
+      int kb = ksteps, ke = 0;
+      for (int r = g * SCAN_MT * 16; r < (g + 1) * SCAN_MT * 16; ++r)
+        for (int c = 0; c < K; ++c)
+          if (W(r, c) != 0.0) {
+            if (c / 4 < kb) kb = c / 4;
+            if (c / 4 + 1 > ke) ke = c / 4 + 1;
+          }
+      if (ke < kb) { kb = 0; ke = 0; }
+      kb = (kb / SCAN_KALIGN) * SCAN_KALIGN;            // W is zero outside the true range, so
+      ke = round_up(ke, SCAN_KALIGN);                   // widening it to the batch size is harmless
+      f.scanRange[2 * g] = kb;
+      f.scanRange[2 * g + 1] = ke;
+    }
+  }
   return ADMM_OK;
 }
 

@@ -40,7 +40,22 @@ struct Factor {
   std::vector<double> recS;         // S * RS
   std::vector<double> K;            // N * m * n (for tests)
   std::vector<double> Sinv;         // N * m * m (for tests)
+
+  // Segment scan as ONE dense product  out = W * in  per QP:
+  //   in  rows: tseg(0..S-1) [S n] | x0 [n] | eseg(0..S-1) [S n] | zero pad      -> scanK rows
+  //   out rows: t_in(0..S-1) [S n] | pad to scanMt | x_in(0..S-1) [S n] | pad    -> scanM rows
+  // scanW is dense row-major scanM x scanK; scanWp is the same matrix packed in
+  // v_mfma_f64_16x16x4 A-fragment order: Wp[kstep][mtile][lane] =
+  // W[16 mtile + (lane & 15)][4 kstep + (lane >> 4)].  scanRange holds, per group of
+  // SCAN_MT M-tiles, the [begin, end) k-step range outside which that group's rows of W
+  // are identically zero (block-triangular structure).
+  int scanM = 0, scanMt = 0, scanK = 0;
+  std::vector<double> scanW, scanWp;
+  std::vector<int32_t> scanRange;   // 2 * (scanM / 16 / SCAN_MT)
 };
+
+constexpr int SCAN_MT = 4;          // M-tiles (of 16 rows) per wave in xscan_mfma_kernel
+constexpr int SCAN_KALIGN = 16;     // k-step ranges and K/4 are padded to this (= 2 * SCAN_U of the kernel)
 
 inline int rec_b_size(int n, int m) { return n * n + m * n + m * m + n * m + n * m; }
 inline int rec_f_size(int n, int m) { return m * n + m * n + n * n + n * m; }

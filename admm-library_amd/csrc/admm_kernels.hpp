@@ -278,6 +278,79 @@ __global__ __launch_bounds__(64) void xscan_kernel(
 }
 
 // ---------------------------------------------------------------------------
+// Segment scan as a dense fp64 GEMM on the matrix cores (the default scan).
+// Both chains of xscan_kernel are linear with batch-shared matrices, so their
+// composition is one constant matrix W (built on the host, admm_factor.cpp):
+//     [t_in(0..S-1); x_in(0..S-1)] = W [tseg(0..S-1); x0; eseg(0..S-1)]
+// i.e. out[M][pitch] = W[M][K] * in[K][pitch] with M = 2 S n (padded), K = (2S+1) n
+// (padded) -- for S = 32, n = 6: 384 x 392 times a 392 x 4096 panel.  The
+// batch-minor layout IS the row-major B operand.  This trades 2S dependent
+// latency-bound steps for one pass of v_mfma_f64_16x16x4_f64.
+//   wave  = one 16-column N-tile x SCAN_MT M-tiles (4 accumulators: covers the MFMA
+//           dependent-issue latency); workgroup = 4 waves = 4 M-groups of one N-tile
+//   A     = W pre-packed on the host in fragment order (one coalesced 512-B load
+//           per fragment, L2-resident: 1.2 MB); B = in[4 ks + (lane>>4)][n0 + (lane&15)]
+//   sparsity: per M-group the [k_begin, k_end) step range outside which its rows of
+//           W vanish (block-triangular structure) comes from the host; ~50 % skipped.
+// f64 MFMA operand maps (cdna_hip_programming.md §3): A[i = lane&15][k = lane>>4],
+// B[k = lane>>4][j = lane&15], D: col = lane&15, row = (lane>>4) + 4 reg.
+// ---------------------------------------------------------------------------
+typedef double mfma_d4 __attribute__((ext_vector_type(4)));
+
+constexpr int SCAN_U = 8;   // k-steps per register batch; host pads K and the ranges to 2 * SCAN_U steps
+
+template <int MT>
+__global__ __launch_bounds__(256) void xscan_mfma_kernel(
+    const double* __restrict__ Wp, const double* __restrict__ in, double* __restrict__ out,
+    const int* __restrict__ krange_, int mtiles, int ngroups, int pitch) {
+  constexpr int U = SCAN_U;
+  const int lane = threadIdx.x & 63;
+  const int group = blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform
+  if (group >= ngroups) return;
+  cint_p krange = as_const(krange_);
+  const int kb = krange[2 * group], ke = krange[2 * group + 1];    // multiples of 2 U
+  const size_t P = (size_t)pitch;
+  const int n0 = blockIdx.x * 16;
+  const double* bptr = in + (size_t)(lane >> 4) * P + n0 + (lane & 15);
+  const double* aptr = Wp + (size_t)group * MT * 64 + lane;
+  const size_t astep = (size_t)mtiles * 64, bstep = 4 * P;
+  mfma_d4 acc[MT];
+#pragma unroll
+  for (int t = 0; t < MT; ++t) acc[t] = mfma_d4{0.0, 0.0, 0.0, 0.0};
+  // Two register batches in ping-pong: while the MFMAs of one batch issue, the loads
+  // of the next are in flight.  Written as an explicit A/B body so that no register
+  // copy (and hence no vmcnt(0)) sits on the loop back-edge.
+  double a0[U][MT], b0[U], a1[U][MT], b1[U];
+#define SCAN_LOAD(A_, B_, KS_)                                   \
+  _Pragma("unroll") for (int u = 0; u < U; ++u) {                \
+    B_[u] = bptr[(size_t)((KS_) + u) * bstep];                   \
+    _Pragma("unroll") for (int t = 0; t < MT; ++t) A_[u][t] = aptr[(size_t)((KS_) + u) * astep + t * 64]; \
+  }
+#define SCAN_MMA(A_, B_)                                         \
+  _Pragma("unroll") for (int u = 0; u < U; ++u) {                \
+    _Pragma("unroll") for (int t = 0; t < MT; ++t)               \
+      acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(A_[u][t], B_[u], acc[t], 0, 0, 0); \
+  }
+  if (kb < ke) {
+    SCAN_LOAD(a0, b0, kb)
+    for (int ks = kb; ks < ke; ks += 2 * U) {
+      SCAN_LOAD(a1, b1, ks + U)
+      SCAN_MMA(a0, b0)
+      if (ks + 2 * U < ke) { SCAN_LOAD(a0, b0, ks + 2 * U) }
+      SCAN_MMA(a1, b1)
+    }
+  }
+#undef SCAN_LOAD
+#undef SCAN_MMA
+#pragma unroll
+  for (int t = 0; t < MT; ++t) {
+    const int row0 = (group * MT + t) * 16 + (lane >> 4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[(size_t)(row0 + 4 * r) * P + n0 + (lane & 15)] = acc[t][r];
+  }
+}
+
+// ---------------------------------------------------------------------------
 // x-update, forward rollout (segment-local, exact once t_in/x_in are known).
 //     d   = d0_k + Psi_k t_in
 //     u   = -K_k x - d

@@ -59,6 +59,8 @@ _SIGNATURES = {
     "admm_abi_version": (C.c_int, []),
     "admm_device_count": (C.c_int, []),
     "admm_record_sizes": (C.c_int, [C.c_int32, C.c_int32, c_int32_p, c_int32_p, c_int32_p]),
+    "admm_host_scan_matrix": (C.c_int, [C.POINTER(CProblem), C.c_double, C.c_int32, c_double_p, c_int32_p,
+                                        c_int32_p, c_int32_p]),
     "admm_host_factor": (C.c_int, [C.POINTER(CProblem), C.c_double, C.c_int32, c_double_p, c_double_p,
                                    c_double_p, c_double_p, c_double_p, c_int32_p]),
 }
@@ -263,5 +265,10 @@ def host_factor(problem: Problem, rho: float, segments: int):
     seg = np.empty(S + 1, np.int32)
     _check(lib, lib.admm_host_factor(C.byref(cp), float(rho), S, dptr(K), dptr(Sinv), dptr(recB),
                                      dptr(recF), dptr(recS), iptr(seg)))
+    M, Mt, Kd = C.c_int32(), C.c_int32(), C.c_int32()
+    _check(lib, lib.admm_host_scan_matrix(C.byref(cp), float(rho), S, None, C.byref(M), C.byref(Mt), C.byref(Kd)))
+    W = np.empty((M.value, Kd.value))
+    _check(lib, lib.admm_host_scan_matrix(C.byref(cp), float(rho), S, dptr(W), None, None, None))
     del keep
-    return {"K": K, "Sinv": Sinv, "recB": recB, "recF": recF, "recS": recS, "seg_start": seg}
+    return {"K": K, "Sinv": Sinv, "recB": recB, "recF": recF, "recS": recS, "seg_start": seg,
+            "scanW": W, "scanMt": Mt.value}

@@ -80,6 +80,8 @@ typedef struct admm_options {
 
 #define ADMM_FLAG_NONE 0
 #define ADMM_FLAG_NO_GRAPH 1   /* launch kernels directly instead of replaying a hipGraph */
+#define ADMM_FLAG_SCAN_CHAIN 4 /* segment scan as the sequential per-QP chain (xscan_kernel) instead of
+                                  the fp64-MFMA GEMM form (xscan_mfma_kernel) */
 #define ADMM_FLAG_UNFUSED 2    /* iterate with separate forward-rollout and z/dual kernels (w stored
                                   every iteration) instead of the fused xfz kernel */
 
@@ -167,6 +169,11 @@ void admm_free(admm_handle* h);
 int admm_record_sizes(int32_t n, int32_t m, int32_t* rb, int32_t* rf, int32_t* rs);
 int admm_host_factor(const admm_problem* p, double rho, int32_t segments, double* K, double* Sinv,
                      double* recB, double* recF, double* recS, int32_t* seg_start);
+/* The dense segment-scan matrix W (row-major M x K) of the MFMA scan kernel:
+ *   [t_in(0..S-1) | pad to Mt | x_in(0..S-1) | pad] = W [tseg(0..S-1) | x0 | eseg(0..S-1) | pad]
+ * Call with W = NULL to query M, Mt, K first. */
+int admm_host_scan_matrix(const admm_problem* p, double rho, int32_t segments, double* W, int32_t* M,
+                          int32_t* Mt, int32_t* K);
 
 const char* admm_last_error(void);
 int admm_abi_version(void);

@@ -30,8 +30,10 @@ def unpack(rec, n, m):
     return dict(AT=AT, BT=BT, SI=SI, KT=KT, OM=OM, PSI=PSI, K=K, A=A, B=B, PHI=PHI, XI=XI, TH=TH)
 
 
-def x_update_segmented(rec, n, m, g, x0):
-    """g: (batch, L) linear term, x0: (batch, n).  Returns w (batch, L)."""
+def x_update_segmented(rec, n, m, g, x0, scan="chain", return_parts=False):
+    """g: (batch, L) linear term, x0: (batch, n).  Returns w (batch, L).
+    scan = "chain": xscan_kernel's sequential recurrences;  "gemm": xscan_mfma_kernel's
+    single dense product with the host-built matrix rec["scanW"]."""
     u = unpack(rec, n, m)
     seg = rec["seg_start"]
     S = len(seg) - 1
@@ -54,6 +56,15 @@ def x_update_segmented(rec, n, m, g, x0):
             t = p @ u["AT"][k].T - h @ u["KT"][k].T
             e = e + d @ u["OM"][k].T
         tseg[s], eseg[s] = t, e
+    if scan == "gemm":
+        Wm, Mt = rec["scanW"], rec["scanMt"]
+        cin = np.zeros((Wm.shape[1], batch))
+        cin[:S * n] = tseg.transpose(0, 2, 1).reshape(S * n, batch)
+        cin[S * n:S * n + n] = np.asarray(x0, np.float64).T
+        cin[S * n + n:2 * S * n + n] = eseg.transpose(0, 2, 1).reshape(S * n, batch)
+        out = Wm @ cin
+        tin_g = out[:S * n].reshape(S, n, batch).transpose(0, 2, 1)
+        xin_g = out[Mt:Mt + S * n].reshape(S, n, batch).transpose(0, 2, 1)
     # xscan_kernel
     tin = np.zeros((S, batch, n))
     t = np.zeros((batch, n))
@@ -69,6 +80,9 @@ def x_update_segmented(rec, n, m, g, x0):
         if s == S - 1:
             break
         x = eseg[s] + tin[s] @ u["XI"][s].T + x @ u["TH"][s].T
+    if scan == "gemm":
+        chain = (tin, xin)
+        tin, xin = tin_g, xin_g
     # xf_kernel
     w = np.zeros((batch, N, nb))
     for s in range(S):
@@ -79,4 +93,6 @@ def x_update_segmented(rec, n, m, g, x0):
             x = x @ u["A"][k].T + uu @ u["B"][k].T
             w[:, k, :m] = uu
             w[:, k, m:] = x
+    if return_parts:
+        return w.reshape(batch, N * nb), dict(tin=tin, xin=xin, chain=chain if scan == "gemm" else None)
     return w.reshape(batch, N * nb)

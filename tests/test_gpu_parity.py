@@ -42,15 +42,17 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("flags", [0, 4], ids=["scan_mfma", "scan_chain"])
 @pytest.mark.parametrize("idx", range(len(CASES)))
-def test_x_update_kernels(gpu, idx):
-    """T5: xb + xscan + xf on random (z, y) vs the oracle's sequential sweep."""
+def test_x_update_kernels(gpu, idx, flags):
+    """T5: xb + xscan + xf on random (z, y) vs the oracle's sequential sweep, with the
+    segment scan as the fp64-MFMA GEMM (default) and as the sequential chain."""
     make, rho, segs = CASES[idx]
     p = make()
     rng = np.random.default_rng(100 + idx)
     z = rng.standard_normal((p.batch, p.L))
     y = rng.standard_normal((p.batch, p.L))
-    with pkg.Solver(p, pkg.Options(rho=rho, segments=segs)) as s:
+    with pkg.Solver(p, pkg.Options(rho=rho, segments=segs, flags=flags)) as s:
         s.set_state(z=z, y=y)
         s.step_x()
         w, z2, y2 = s.get()

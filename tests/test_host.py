@@ -94,8 +94,15 @@ def test_segment_algebra_reproduces_sequential_sweep(lib, make, rho, segs):
     g = np.random.default_rng(7).standard_normal((p.batch, p.L))
     f = ar.factor(p.A, p.B, p.Q, p.R, p.QN, rho, p.N)
     w_ref = ar.x_update(f, g, p.x0)
-    w_seg = x_update_segmented(host_factor(p, rho, segs), p.n, p.m, g, p.x0)
+    rec = host_factor(p, rho, segs)
+    w_seg = x_update_segmented(rec, p.n, p.m, g, p.x0)
     assert np.abs(w_ref - w_seg).max() <= 1e-12 * max(1.0, np.abs(w_ref).max())
+    # the scan as one dense product with the host-built matrix W (xscan_mfma_kernel's form)
+    w_gemm, parts = x_update_segmented(rec, p.n, p.m, g, p.x0, scan="gemm", return_parts=True)
+    tin_c, xin_c = parts["chain"]
+    assert np.abs(parts["tin"] - tin_c).max() <= 1e-12 * max(1.0, np.abs(tin_c).max())
+    assert np.abs(parts["xin"] - xin_c).max() <= 1e-12 * max(1.0, np.abs(xin_c).max())
+    assert np.abs(w_ref - w_gemm).max() <= 1e-12 * max(1.0, np.abs(w_ref).max())
 
 
 def _setup_rc(lib, p, opt=None):
