@@ -43,7 +43,7 @@ struct admm_handle {
   admm::Factor fac;
   hipStream_t stream = nullptr;
   // batch-minor state and work buffers
-  double *w = nullptr, *z = nullptr, *y = nullptr, *q = nullptr, *x0 = nullptr;
+  double *w = nullptr, *z = nullptr, *y = nullptr, *v = nullptr, *q = nullptr, *x0 = nullptr;
   double *dbuf = nullptr, *tseg = nullptr, *eseg = nullptr, *tin = nullptr, *xin = nullptr;
   double *part = nullptr, *resid = nullptr, *lo = nullptr, *hi = nullptr;
   double *recB = nullptr, *recF = nullptr, *recS = nullptr;
@@ -55,6 +55,9 @@ struct admm_handle {
   int iters_run = 0;
   bool resid_valid = false;
   bool w_stale = false;         // fused iterations do not store w; admm_get re-materialises it
+  // State form: the fused path keeps v = z + y only; z, y are rebuilt on demand.
+  bool v_valid = false;         // h->v holds the current state
+  bool zy_valid = true;         // h->z, h->y hold the current state
   // captured iterations, replayed by admm_run / admm_solve:
   //   [0] x-update + plain z step;  [1] x-update + residual z step + finalise (it = 0)
   hipGraph_t graph[2] = {nullptr, nullptr};
@@ -85,22 +88,23 @@ std::string supported_list() {
   return s;
 }
 
-int launch_xb(admm_handle* h) {
+// vform: read the state from h->v (z = clip(v), y = v - z rebuilt in registers)
+int launch_xb(admm_handle* h, bool vform) {
   dim3 grid((h->pitch + XB_THREADS - 1) / XB_THREADS, h->S), block(XB_THREADS);
-#define X(NX, NU)                                                                                   \
-  if (h->n == NX && h->m == NU) {                                                                   \
-    if (h->has_q)                                                                                   \
-      hipLaunchKernelGGL((admm::xb_kernel<NX, NU, true>), grid, block, 0, h->stream, h->z, h->y,    \
-                         h->q, h->recB, h->seg_start, h->dbuf, h->tseg, h->eseg, h->opt.rho,        \
-                         h->pitch);                                                                 \
-    else                                                                                            \
-      hipLaunchKernelGGL((admm::xb_kernel<NX, NU, false>), grid, block, 0, h->stream, h->z, h->y,   \
-                         h->q, h->recB, h->seg_start, h->dbuf, h->tseg, h->eseg, h->opt.rho,        \
-                         h->pitch);                                                                 \
-    return ADMM_OK;                                                                                 \
+#define XB(NX, NU, HQ, VF)                                                                           \
+  hipLaunchKernelGGL((admm::xb_kernel<NX, NU, HQ, VF>), grid, block, 0, h->stream,                   \
+                     (const double*)(VF ? h->v : h->z), (const double*)h->y, (const double*)h->q,    \
+                     h->recB, h->seg_start, h->lo, h->hi, h->dbuf, h->tseg, h->eseg, h->opt.rho,     \
+                     h->pitch)
+#define X(NX, NU)                                                          \
+  if (h->n == NX && h->m == NU) {                                          \
+    if (h->has_q) { if (vform) XB(NX, NU, true, true); else XB(NX, NU, true, false); }    \
+    else          { if (vform) XB(NX, NU, false, true); else XB(NX, NU, false, false); }  \
+    return ADMM_OK;                                                        \
   }
   ADMM_FOR_EACH_DIM(X)
 #undef X
+#undef XB
   return fail(ADMM_ERR_UNSUPPORTED, "no x-update kernel for this (n, m)");
 }
 
@@ -143,24 +147,37 @@ int launch_xf(admm_handle* h) {
   return fail(ADMM_ERR_UNSUPPORTED, "no x-update kernel for this (n, m)");
 }
 
-// fused forward rollout + z/dual (+ residual partials per segment)
-int launch_xfz(admm_handle* h, bool resid) {
+// fused forward rollout + z/dual (+ residual partials per segment); writes v+ into h->v.
+// vin: previous state read from h->v, otherwise from h->z / h->y.
+int launch_xfz(admm_handle* h, bool resid, bool vin) {
   dim3 grid((h->pitch + XB_THREADS - 1) / XB_THREADS, h->S), block(XB_THREADS);
   const bool relax = h->opt.alpha != 1.0;
-#define XFZ(NX, NU, RS, RX)                                                                          \
-  hipLaunchKernelGGL((admm::xfz_kernel<NX, NU, RS, RX>), grid, block, 0, h->stream, h->dbuf, h->tin, \
-                     h->xin, h->recF, h->seg_start, h->z, h->y, h->lo, h->hi, h->part,               \
-                     h->opt.alpha, h->pitch)
+#define XFZ(NX, NU, RS, RX, VI)                                                                          \
+  hipLaunchKernelGGL((admm::xfz_kernel<NX, NU, RS, RX, VI>), grid, block, 0, h->stream, h->dbuf, h->tin, \
+                     h->xin, h->recF, h->seg_start, (const double*)h->z, (const double*)h->y, h->v,      \
+                     h->lo, h->hi, h->part, h->opt.alpha, h->pitch)
+#define XFZ2(NX, NU, RS, RX) do { if (vin) XFZ(NX, NU, RS, RX, true); else XFZ(NX, NU, RS, RX, false); } while (0)
 #define X(NX, NU)                                                        \
   if (h->n == NX && h->m == NU) {                                        \
-    if (resid) { if (relax) XFZ(NX, NU, true, true); else XFZ(NX, NU, true, false); }   \
-    else       { if (relax) XFZ(NX, NU, false, true); else XFZ(NX, NU, false, false); } \
+    if (resid) { if (relax) XFZ2(NX, NU, true, true); else XFZ2(NX, NU, true, false); }   \
+    else       { if (relax) XFZ2(NX, NU, false, true); else XFZ2(NX, NU, false, false); } \
     return ADMM_OK;                                                      \
   }
   ADMM_FOR_EACH_DIM(X)
 #undef X
+#undef XFZ2
 #undef XFZ
   return fail(ADMM_ERR_UNSUPPORTED, "no x-update kernel for this (n, m)");
+}
+
+// z = clip(v), y = v - z into the z / y arrays (read-out and mode switches)
+int ensure_zy(admm_handle* h) {
+  if (h->zy_valid) return ADMM_OK;
+  dim3 grid((h->pitch / 2 + Z_THREADS - 1) / Z_THREADS, h->zchunks), block(Z_THREADS);
+  hipLaunchKernelGGL(admm::v_to_zy_kernel, grid, block, 0, h->stream, (const double*)h->v, h->z, h->y,
+                     h->lo, h->hi, h->L, h->zrows, h->pitch);
+  h->zy_valid = true;
+  return ADMM_OK;
 }
 
 int launch_z(admm_handle* h, bool resid) {
@@ -190,13 +207,27 @@ int launch_finalize(admm_handle* h, int it, int nchunks) {
 bool fused(const admm_handle* h) { return !(h->opt.flags & ADMM_FLAG_UNFUSED); }
 
 // One full iteration on the stream: x-update + z/dual (+ residual partials).
-int enqueue_iteration(admm_handle* h, bool resid) {
+// Fused path: state in = h->v if use_v else h->z / h->y; state out = h->v.
+// Unfused path: state in and out = h->z / h->y (caller has made them valid).
+// Pure enqueue: the caller updates v_valid / zy_valid / w_stale (graph capture replays this).
+int enqueue_iteration(admm_handle* h, bool resid, bool use_v) {
   int rc;
-  if ((rc = launch_xb(h))) return rc;
+  if (fused(h)) {
+    if ((rc = launch_xb(h, use_v))) return rc;
+    if ((rc = launch_xscan(h))) return rc;
+    return launch_xfz(h, resid, use_v);
+  }
+  if ((rc = launch_xb(h, false))) return rc;
   if ((rc = launch_xscan(h))) return rc;
-  if (fused(h)) return launch_xfz(h, resid);
   if ((rc = launch_xf(h))) return rc;
   return launch_z(h, resid);
+}
+
+// bookkeeping after `count` enqueued iterations
+void after_iterations(admm_handle* h, int count) {
+  if (count <= 0) return;
+  if (fused(h)) { h->v_valid = true; h->zy_valid = false; h->w_stale = true; }
+  else          { h->zy_valid = true; h->v_valid = false; h->w_stale = false; }
 }
 
 int chunks_of_iteration(const admm_handle* h) { return fused(h) ? h->S : h->zchunks; }
@@ -212,7 +243,7 @@ int ensure_w(admm_handle* h) {
 
 int step_x(admm_handle* h) {
   int rc;
-  if ((rc = launch_xb(h))) return rc;
+  if ((rc = launch_xb(h, h->v_valid))) return rc;
   if ((rc = launch_xscan(h))) return rc;
   if ((rc = launch_xf(h))) return rc;
   return ADMM_OK;
@@ -283,7 +314,7 @@ void release(admm_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   destroy_graph(h);
-  double** bufs[] = {&h->w, &h->z, &h->y, &h->q, &h->dbuf, &h->scan_in, &h->scan_out, &h->scanWp,
+  double** bufs[] = {&h->w, &h->z, &h->y, &h->v, &h->q, &h->dbuf, &h->scan_in, &h->scan_out, &h->scanWp,
                      &h->part, &h->resid, &h->lo, &h->hi, &h->recB, &h->recF, &h->recS, &h->stage};
   for (auto b : bufs)
     if (*b) { (void)hipFree(*b); *b = nullptr; }
@@ -306,7 +337,7 @@ int capture_iterations(admm_handle* h) {
   destroy_graph(h);
   for (int v = 0; v < 2; ++v) {
     HIP_TRY(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-    int rc = enqueue_iteration(h, v == 1);
+    int rc = enqueue_iteration(h, v == 1, /*use_v=*/true);   // steady state of the fused path
     if (!rc && v == 1) rc = launch_finalize(h, 0, chunks_of_iteration(h));
     hipGraph_t g = nullptr;
     hipError_t e = hipStreamEndCapture(h->stream, &g);
@@ -451,6 +482,7 @@ int admm_setup(admm_handle** out, const admm_problem* p, const admm_options* o_i
   TRY_RELEASE(dalloc(&h->w, L * P));
   TRY_RELEASE(dalloc(&h->z, L * P));
   TRY_RELEASE(dalloc(&h->y, L * P));
+  TRY_RELEASE(dalloc(&h->v, L * P));
   if (h->has_q) TRY_RELEASE(dalloc(&h->q, L * P));
   TRY_RELEASE(dalloc(&h->dbuf, (size_t)h->N * h->m * P));
   {  // scan operands: in = tseg | x0 | eseg | pad,  out = t_in | pad | x_in | pad  (admm_factor.hpp)
@@ -485,6 +517,7 @@ int admm_setup(admm_handle** out, const admm_problem* p, const admm_options* o_i
   HIP_TRY_RELEASE(hipMemsetAsync(h->w, 0, sizeof(double) * L * P, h->stream));
   HIP_TRY_RELEASE(hipMemsetAsync(h->z, 0, sizeof(double) * L * P, h->stream));
   HIP_TRY_RELEASE(hipMemsetAsync(h->y, 0, sizeof(double) * L * P, h->stream));
+  HIP_TRY_RELEASE(hipMemsetAsync(h->v, 0, sizeof(double) * L * P, h->stream));
   HIP_TRY_RELEASE(hipMemsetAsync(h->dbuf, 0, sizeof(double) * (size_t)h->N * h->m * P, h->stream));
   HIP_TRY_RELEASE(hipMemsetAsync(h->part, 0, sizeof(double) * part_chunks * 5 * P, h->stream));
   HIP_TRY_RELEASE(hipMemsetAsync(h->resid, 0, sizeof(double) * 5 * P, h->stream));
@@ -541,8 +574,13 @@ int admm_set_state(admm_handle* h, const double* w, const double* z, const doubl
     if ((rc = upload_transposed(h, w, h->w, h->L))) return rc;
     h->w_stale = false;
   }
-  if (z && (rc = upload_transposed(h, z, h->z, h->L))) return rc;
-  if (y && (rc = upload_transposed(h, y, h->y, h->L))) return rc;
+  if (z || y) {
+    if ((rc = ensure_zy(h))) return rc;        // keep the one that is not overwritten
+    if (z && (rc = upload_transposed(h, z, h->z, h->L))) return rc;
+    if (y && (rc = upload_transposed(h, y, h->y, h->L))) return rc;
+    h->zy_valid = true;
+    h->v_valid = false;                         // an arbitrary (z, y) pair need not be of the form (clip(v), v - clip(v))
+  }
   return ADMM_OK;
 }
 
@@ -561,14 +599,35 @@ int admm_step_z(admm_handle* h, int32_t residuals) {
   if (!h) return fail(ADMM_ERR_INVALID, "NULL handle");
   HIP_TRY(hipSetDevice(h->device));
   int rc = ensure_w(h);
+  if (!rc) rc = ensure_zy(h);
   if (!rc) rc = launch_z(h, residuals != 0);
   if (rc) return rc;
+  h->v_valid = false;
   if (residuals) {
     launch_finalize(h, 0, h->zchunks);
     h->resid_valid = true;
   }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(h->stream));
+  return ADMM_OK;
+}
+
+// Enqueue iteration number `it` (1-based within the caller's loop).  The graphs hold the
+// steady-state kernel forms; an iteration whose input state is not in that form (first
+// fused iteration after setup / set_state / an unfused step) is launched directly.
+static int enqueue_one(admm_handle* h, bool resid, bool use_graph) {
+  int rc;
+  const bool steady = fused(h) ? h->v_valid : h->zy_valid;
+  if (!fused(h) && !h->zy_valid && (rc = ensure_zy(h))) return rc;
+  if (use_graph && steady) {
+    HIP_TRY(hipGraphLaunch(h->graph_exec[resid ? 1 : 0], h->stream));
+  } else {
+    rc = enqueue_iteration(h, resid, fused(h) && h->v_valid);
+    if (!rc && resid) rc = launch_finalize(h, 0, chunks_of_iteration(h));
+    if (rc) return rc;
+  }
+  after_iterations(h, 1);
+  if (resid) h->resid_valid = true;
   return ADMM_OK;
 }
 
@@ -583,16 +642,9 @@ int admm_run(admm_handle* h, int32_t iters, int32_t residual_every) {
   }
   for (int it = 1; it <= iters; ++it) {
     const bool resid = residual_every > 0 && (it % residual_every == 0);
-    if (use_graph) {
-      HIP_TRY(hipGraphLaunch(h->graph_exec[resid ? 1 : 0], h->stream));
-    } else {
-      int rc = enqueue_iteration(h, resid);
-      if (!rc && resid) rc = launch_finalize(h, 0, chunks_of_iteration(h));
-      if (rc) return rc;
-    }
-    if (resid) h->resid_valid = true;
+    int rc = enqueue_one(h, resid, use_graph);
+    if (rc) return rc;
   }
-  if (iters > 0 && fused(h)) h->w_stale = true;
   HIP_TRY(hipGetLastError());
   return ADMM_OK;
 }
@@ -625,23 +677,23 @@ int admm_solve(admm_handle* h, const double* z0, const double* y0, admm_info* in
   const int ci = h->opt.check_interval;
   for (it = 1; it <= h->opt.max_iter; ++it) {
     const bool check = (it % ci == 0) || it == h->opt.max_iter;
-    if (!check && use_graph) {
-      HIP_TRY(hipGraphLaunch(h->graph_exec[0], h->stream));
+    if (!check) {
+      if ((rc = enqueue_one(h, false, use_graph))) return rc;
       continue;
     }
-    if ((rc = enqueue_iteration(h, check))) return rc;
-    if (check) {
-      HIP_TRY(hipMemsetAsync(h->nconv, 0, sizeof(int), h->stream));
-      launch_finalize(h, it, chunks_of_iteration(h));
-      HIP_TRY(hipMemcpyAsync(h->h_nconv, h->nconv, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-      HIP_TRY(hipStreamSynchronize(h->stream));
-      nconv = *h->h_nconv;
-      h->resid_valid = true;
-      if (nconv >= h->batch) break;
-    }
+    // checked iteration: launched directly so that the finalise kernel gets the iteration number
+    if (!fused(h) && (rc = ensure_zy(h))) return rc;
+    if ((rc = enqueue_iteration(h, true, fused(h) && h->v_valid))) return rc;
+    after_iterations(h, 1);
+    HIP_TRY(hipMemsetAsync(h->nconv, 0, sizeof(int), h->stream));
+    launch_finalize(h, it, chunks_of_iteration(h));
+    HIP_TRY(hipMemcpyAsync(h->h_nconv, h->nconv, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    nconv = *h->h_nconv;
+    h->resid_valid = true;
+    if (nconv >= h->batch) break;
   }
   if (it > h->opt.max_iter) it = h->opt.max_iter;
-  if (fused(h)) h->w_stale = true;
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(h->stream));
   h->iters_run = it;
@@ -678,6 +730,7 @@ int admm_get(admm_handle* h, double* w, double* z, double* y) {
   HIP_TRY(hipSetDevice(h->device));
   int rc;
   if (w && (rc = ensure_w(h))) return rc;
+  if ((z || y) && (rc = ensure_zy(h))) return rc;
   if (w && (rc = download_transposed(h, h->w, w, h->L))) return rc;
   if (z && (rc = download_transposed(h, h->z, z, h->L))) return rc;
   if (y && (rc = download_transposed(h, h->y, y, h->L))) return rc;
@@ -706,19 +759,24 @@ int admm_profile(admm_handle* h, int32_t iters, int32_t residuals, int32_t fused
   const bool res = residuals != 0;
   for (int it = 0; it < iters && !rc; ++it) {
     hipEvent_t* e = &ev[(size_t)it * NE];
+    const bool use_v = fused_path && h->v_valid;
+    if (!fused_path && (rc = ensure_zy(h))) break;
     HIP_TRY(hipEventRecord(e[0], h->stream));
-    rc = launch_xb(h);
+    rc = launch_xb(h, use_v);
     HIP_TRY(hipEventRecord(e[1], h->stream));
     if (!rc) rc = launch_xscan(h);
     HIP_TRY(hipEventRecord(e[2], h->stream));
-    if (!rc) rc = fused_path ? launch_xfz(h, res) : launch_xf(h);
+    if (!rc) rc = fused_path ? launch_xfz(h, res, use_v) : launch_xf(h);
     HIP_TRY(hipEventRecord(e[3], h->stream));
     if (!rc && !fused_path) rc = launch_z(h, res);
+    if (!rc) {
+      if (fused_path) { h->v_valid = true; h->zy_valid = false; h->w_stale = true; }
+      else            { h->zy_valid = true; h->v_valid = false; h->w_stale = false; }
+    }
     HIP_TRY(hipEventRecord(e[4], h->stream));
     if (!rc && res) rc = launch_finalize(h, 0, fused_path ? h->S : h->zchunks);
     HIP_TRY(hipEventRecord(e[5], h->stream));
   }
-  if (fused_path) h->w_stale = true;
   if (res) h->resid_valid = true;
   HIP_TRY(hipStreamSynchronize(h->stream));
   for (int v = 0; v < 6; ++v) ms[v] = 0.0;

@@ -33,8 +33,19 @@ __device__ __forceinline__ cdouble_p as_const(const double* p) {
 __device__ __forceinline__ cint_p as_const(const int* p) { return (cint_p)(uintptr_t)p; }
 
 // ---------------------------------------------------------------------------
+// State compression ("v-form").  After any z-update,
+//     z = clip(v, lo, hi),   y = v - z        with  v = w^ + y_old
+// so the pair (z, y) is a function of the single vector v.  The steady-state
+// kernels therefore keep only v in HBM and rebuild z and y in registers with
+// the very operations that produced them -- bit-identical iterates, half the
+// state traffic.  Kernels take a VFORM / VIN flag: false = read the separate
+// z, y arrays (first iteration after admm_setup / admm_set_state, unfused path).
+// ---------------------------------------------------------------------------
+
+// ---------------------------------------------------------------------------
 // x-update, backward sweep (segment-local).  One lane = one QP, blockIdx.y =
 // segment.  For stages k = b-1 .. a of the segment, with tail t = 0 on entry:
+//     (z, y) = VFORM ? (clip(v), v - clip(v)) : loaded
 //     g    = q - rho (z - y)                    (block k: g^u (m), g^x (n))
 //     p    = g^x + t
 //     h    = B_k' p + g^u
@@ -42,14 +53,17 @@ __device__ __forceinline__ cint_p as_const(const int* p) { return (cint_p)(uintp
 //     t    = A_k' p - K_k' h
 //     e   += Omega_k d0_k
 // and on exit t -> tseg[s], e -> eseg[s] (n rows each).
-// HBM per stacked element: reads z, y (16 B, +8 with q), writes d (8 m/(n+m)).
+// HBM per stacked element: VFORM: read v 8 (+8 with q), write d 8 m/(n+m);
+// otherwise read z, y 16.
 // ---------------------------------------------------------------------------
-template <int NX, int NU, bool HASQ>
+template <int NX, int NU, bool HASQ, bool VFORM>
 __global__ __launch_bounds__(XB_THREADS) void xb_kernel(
     const double* __restrict__ z, const double* __restrict__ y, const double* __restrict__ q,
     const double* __restrict__ recB_, const int* __restrict__ seg_start_,
+    const double* __restrict__ lo_, const double* __restrict__ hi_,
     double* __restrict__ dbuf, double* __restrict__ tseg, double* __restrict__ eseg,
     double rho, int pitch) {
+  // VFORM: `z` is the v array and `y` is unused.
   constexpr int NB = NX + NU;
   constexpr int RB = NX * NX + NU * NX + NU * NU + NX * NU + NX * NU;
   constexpr int O_AT = 0, O_BT = NX * NX, O_SI = O_BT + NU * NX, O_KT = O_SI + NU * NU, O_OM = O_KT + NX * NU;
@@ -59,6 +73,8 @@ __global__ __launch_bounds__(XB_THREADS) void xb_kernel(
   cint_p seg_start = as_const(seg_start_);
   const int k0 = seg_start[s], k1 = seg_start[s + 1];
   const size_t P = (size_t)pitch;
+  cdouble_p lo = as_const(lo_);
+  cdouble_p hi = as_const(hi_);
 
   double t[NX], e[NX];
 #pragma unroll
@@ -70,7 +86,7 @@ __global__ __launch_bounds__(XB_THREADS) void xb_kernel(
 #pragma unroll
     for (int r = 0; r < NB; ++r) {
       lz[r] = z[r0 + r * P];
-      ly[r] = y[r0 + r * P];
+      if (!VFORM) ly[r] = y[r0 + r * P];
       if (HASQ) lq[r] = q[r0 + r * P];
     }
   }
@@ -79,7 +95,14 @@ __global__ __launch_bounds__(XB_THREADS) void xb_kernel(
     double g[NB];
 #pragma unroll
     for (int r = 0; r < NB; ++r) {
-      g[r] = -rho * (lz[r] - ly[r]);
+      double zz = lz[r], yy;
+      if (VFORM) {
+        zz = fmin(fmax(lz[r], lo[k * NB + r]), hi[k * NB + r]);
+        yy = lz[r] - zz;
+      } else {
+        yy = ly[r];
+      }
+      g[r] = -rho * (zz - yy);
       if (HASQ) g[r] += lq[r];
     }
     {  // prefetch the next (earlier) stage; clamped so the last one is a harmless re-read
@@ -88,7 +111,7 @@ __global__ __launch_bounds__(XB_THREADS) void xb_kernel(
 #pragma unroll
       for (int r = 0; r < NB; ++r) {
         lz[r] = z[r0 + r * P];
-        ly[r] = y[r0 + r * P];
+        if (!VFORM) ly[r] = y[r0 + r * P];
         if (HASQ) lq[r] = q[r0 + r * P];
       }
     }
@@ -431,23 +454,27 @@ __global__ __launch_bounds__(XB_THREADS) void xf_kernel(
 // ---------------------------------------------------------------------------
 // Fused forward rollout + z-update + dual ascent + residual partials (the
 // default iteration path).  Same rollout as xf_kernel, but block k of w is
-// consumed in registers instead of being written to HBM and re-read:
+// consumed in registers instead of being written to HBM and re-read, and the
+// result is stored in v-form:
+//     (z, y) = VIN ? (clip(v), v - clip(v)) : loaded from the z / y arrays
 //     wh = alpha w + (1 - alpha) z       (RELAX only)
-//     v  = wh + y;  z+ = min(max(v, lo), hi);  y+ = v - z+        (in place)
-//     RESID: per-QP sums over the segment's rows of (w - z+)^2, (z+ - z)^2,
-//            w^2, z+^2, y+^2  -> part[segment][5][pitch]
-// w itself is not stored (nothing in the next iteration reads it; admm_get
-// re-materialises it with xf_kernel from the same d / t_in / x_in).
-// Algorithmic HBM bytes per stacked element, fp64:
-//     RESID or RELAX: d 8 m/(n+m) + z, y read 16 + z+, y+ written 16
-//     plain:          d 8 m/(n+m) + y read 8     + z+, y+ written 16
+//     v+ = wh + y                                               -> v (in place)
+//     RESID: z+ = clip(v+), y+ = v+ - z+ and per-QP sums over the segment's rows
+//            of (w - z+)^2, (z+ - z)^2, w^2, z+^2, y+^2  -> part[segment][5][pitch]
+// Neither w nor z+ / y+ is stored: nothing in the next iteration reads w, and
+// z+, y+ are functions of v+ (admm_get re-materialises all three on demand).
+// Algorithmic HBM bytes per stacked element, fp64, steady state (VIN):
+//     d read 8 m/(n+m) + v read 8 + v+ written 8        (= 18.67 for n = 6, m = 3)
 // ---------------------------------------------------------------------------
-template <int NX, int NU, bool RESID, bool RELAX>
+template <int NX, int NU, bool RESID, bool RELAX, bool VIN>
 __global__ __launch_bounds__(XB_THREADS) void xfz_kernel(
     const double* __restrict__ dbuf, const double* __restrict__ tin, const double* __restrict__ xin,
     const double* __restrict__ recF_, const int* __restrict__ seg_start_,
-    double* __restrict__ z, double* __restrict__ y, const double* __restrict__ lo_,
-    const double* __restrict__ hi_, double* __restrict__ part, double alpha, int pitch) {
+    const double* __restrict__ zin, const double* __restrict__ yin, double* __restrict__ v,
+    const double* __restrict__ lo_, const double* __restrict__ hi_, double* __restrict__ part,
+    double alpha, int pitch) {
+  // VIN: the state is read from v (zin, yin unused); otherwise from zin, yin.  Either
+  // way v+ is written to v.  (zin / yin never alias v.)
   constexpr int NB = NX + NU;
   constexpr int RF = NU * NX + NU * NX + NX * NX + NX * NU;
   constexpr int O_PSI = 0, O_K = NU * NX, O_A = O_K + NU * NX, O_B = O_A + NX * NX;
@@ -469,7 +496,8 @@ __global__ __launch_bounds__(XB_THREADS) void xfz_kernel(
       x[i] = xin[o + i * P];
     }
   }
-  double ld[NU], lz[NB], ly[NB];
+  // prefetch registers: l0 = v (VIN) or y; l1 = z (only !VIN && NEEDZ)
+  double ld[NU], l0[NB], l1[NB];
   {
     const size_t d0 = (size_t)k0 * NU * P + col;
 #pragma unroll
@@ -477,19 +505,23 @@ __global__ __launch_bounds__(XB_THREADS) void xfz_kernel(
     const size_t r0 = (size_t)k0 * NB * P + col;
 #pragma unroll
     for (int r = 0; r < NB; ++r) {
-      ly[r] = y[r0 + r * P];
-      if (NEEDZ) lz[r] = z[r0 + r * P];
+      if (VIN) {
+        l0[r] = v[r0 + r * P];
+      } else {
+        l0[r] = yin[r0 + r * P];
+        if (NEEDZ) l1[r] = zin[r0 + r * P];
+      }
     }
   }
   double a_r = 0, a_s = 0, a_w = 0, a_z = 0, a_y = 0;
   for (int k = k0; k < k1; ++k) {
-    double d[NU], zc[NB], yc[NB];
+    double d[NU], c0[NB], c1[NB];
 #pragma unroll
     for (int j = 0; j < NU; ++j) d[j] = ld[j];
 #pragma unroll
     for (int r = 0; r < NB; ++r) {
-      yc[r] = ly[r];
-      if (NEEDZ) zc[r] = lz[r];
+      c0[r] = l0[r];
+      if (!VIN && NEEDZ) c1[r] = l1[r];
     }
     {  // prefetch the next stage (clamped: the last one is a harmless re-read of
        // rows this lane is about to overwrite -- same lane, program order)
@@ -500,8 +532,12 @@ __global__ __launch_bounds__(XB_THREADS) void xfz_kernel(
       const size_t r0 = (size_t)kn * NB * P + col;
 #pragma unroll
       for (int r = 0; r < NB; ++r) {
-        ly[r] = y[r0 + r * P];
-        if (NEEDZ) lz[r] = z[r0 + r * P];
+        if (VIN) {
+          l0[r] = v[r0 + r * P];
+        } else {
+          l0[r] = yin[r0 + r * P];
+          if (NEEDZ) l1[r] = zin[r0 + r * P];
+        }
       }
     }
     cdouble_p rf = as_const(recF_) + (size_t)k * RF;
@@ -530,15 +566,22 @@ __global__ __launch_bounds__(XB_THREADS) void xfz_kernel(
 #pragma unroll
     for (int r = 0; r < NB; ++r) {
       const double l = lo[k * NB + r], h = hi[k * NB + r];
+      double zo, yo;                       // state before this z-update
+      if (VIN) {
+        zo = fmin(fmax(c0[r], l), h);
+        yo = c0[r] - zo;
+      } else {
+        yo = c0[r];
+        zo = NEEDZ ? c1[r] : 0.0;
+      }
       double wh = wv[r];
-      if (RELAX) wh = fma(alpha, wv[r], (1.0 - alpha) * zc[r]);
-      const double v = wh + yc[r];
-      const double zn = fmin(fmax(v, l), h);
-      const double yn = v - zn;
-      z[r0 + r * P] = zn;
-      y[r0 + r * P] = yn;
+      if (RELAX) wh = fma(alpha, wv[r], (1.0 - alpha) * zo);
+      const double vn = wh + yo;
+      v[r0 + r * P] = vn;
       if (RESID) {
-        const double dr = wv[r] - zn, ds = zn - zc[r];
+        const double zn = fmin(fmax(vn, l), h);
+        const double yn = vn - zn;
+        const double dr = wv[r] - zn, ds = zn - zo;
         a_r = fma(dr, dr, a_r);
         a_s = fma(ds, ds, a_s);
         a_w = fma(wv[r], wv[r], a_w);
@@ -554,6 +597,30 @@ __global__ __launch_bounds__(XB_THREADS) void xfz_kernel(
     part[o + 2 * P] = a_w;
     part[o + 3 * P] = a_z;
     part[o + 4 * P] = a_y;
+  }
+}
+
+// v -> (z, y): z = clip(v), y = v - z.  Read-out / mode switches only.  One lane =
+// two adjacent QPs, blockIdx.y = row chunk (same geometry as zdual_kernel).
+__global__ __launch_bounds__(Z_THREADS) void v_to_zy_kernel(
+    const double* __restrict__ v, double* __restrict__ z, double* __restrict__ y,
+    const double* __restrict__ lo_, const double* __restrict__ hi_, int L, int zrows, int pitch) {
+  const int col = (blockIdx.x * Z_THREADS + threadIdx.x) * 2;
+  if (col >= pitch) return;
+  const int r_begin = blockIdx.y * zrows;
+  const int r_end = (r_begin + zrows < L) ? r_begin + zrows : L;
+  cdouble_p lo = as_const(lo_);
+  cdouble_p hi = as_const(hi_);
+  for (int r = r_begin; r < r_end; ++r) {
+    const size_t o = (size_t)r * pitch + col;
+    const double2 vv = *reinterpret_cast<const double2*>(v + o);
+    double2 zz, yy;
+    zz.x = fmin(fmax(vv.x, lo[r]), hi[r]);
+    zz.y = fmin(fmax(vv.y, lo[r]), hi[r]);
+    yy.x = vv.x - zz.x;
+    yy.y = vv.y - zz.y;
+    *reinterpret_cast<double2*>(z + o) = zz;
+    *reinterpret_cast<double2*>(y + o) = yy;
   }
 }
 
