@@ -94,8 +94,7 @@ int launch_xb(admm_handle* h, bool vform) {
 #define XB(NX, NU, HQ, VF)                                                                           \
   hipLaunchKernelGGL((admm::xb_kernel<NX, NU, HQ, VF>), grid, block, 0, h->stream,                   \
                      (const double*)(VF ? h->v : h->z), (const double*)h->y, (const double*)h->q,    \
-                     h->recB, h->seg_start, h->lo, h->hi, h->dbuf, h->tseg, h->eseg, h->opt.rho,     \
-                     h->pitch)
+                     h->recB, h->seg_start, h->dbuf, h->tseg, h->eseg, h->opt.rho, h->pitch)
 #define X(NX, NU)                                                          \
   if (h->n == NX && h->m == NU) {                                          \
     if (h->has_q) { if (vform) XB(NX, NU, true, true); else XB(NX, NU, true, false); }    \
@@ -155,7 +154,7 @@ int launch_xfz(admm_handle* h, bool resid, bool vin) {
 #define XFZ(NX, NU, RS, RX, VI)                                                                          \
   hipLaunchKernelGGL((admm::xfz_kernel<NX, NU, RS, RX, VI>), grid, block, 0, h->stream, h->dbuf, h->tin, \
                      h->xin, h->recF, h->seg_start, (const double*)h->z, (const double*)h->y, h->v,      \
-                     h->lo, h->hi, h->part, h->opt.alpha, h->pitch)
+                     h->part, h->opt.alpha, h->pitch)
 #define XFZ2(NX, NU, RS, RX) do { if (vin) XFZ(NX, NU, RS, RX, true); else XFZ(NX, NU, RS, RX, false); } while (0)
 #define X(NX, NU)                                                        \
   if (h->n == NX && h->m == NU) {                                        \

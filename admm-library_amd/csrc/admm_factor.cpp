@@ -92,7 +92,7 @@ int factorise(const admm_problem& p, double rho, int segments, Factor& f, std::s
   const int N = p.N, n = p.n, m = p.m;
   if (N < 1 || n < 1 || m < 1) { err = "N, n, m must be positive"; return ADMM_ERR_INVALID; }
   if (!(rho > 0.0) || !std::isfinite(rho)) { err = "rho must be positive and finite"; return ADMM_ERR_INVALID; }
-  if (!p.A || !p.B || !p.Q || !p.R || !p.QN) { err = "A, B, Q, R, QN must be non-NULL"; return ADMM_ERR_INVALID; }
+  if (!p.A || !p.B || !p.Q || !p.R || !p.QN || !p.lo || !p.hi) { err = "A, B, Q, R, QN, lo, hi must be non-NULL"; return ADMM_ERR_INVALID; }
   const int nst = p.time_varying ? N : 1;
   if (!all_finite(p.A, (size_t)nst * n * n) || !all_finite(p.B, (size_t)nst * n * m) ||
       !all_finite(p.Q, (size_t)n * n) || !all_finite(p.R, (size_t)m * m) || !all_finite(p.QN, (size_t)n * n)) {
@@ -169,6 +169,16 @@ int factorise(const admm_problem& p, double rho, int segments, Factor& f, std::s
     for (size_t i = 0; i < K.size(); ++i) rf[o++] = K[i];
     for (size_t i = 0; i < A[k].size(); ++i) rf[o++] = A[k][i];
     for (size_t i = 0; i < B[k].size(); ++i) rf[o++] = B[k][i];
+    // the box of block k rides at the tail of both records
+    const int nb = n + m;
+    const double* blo = p.lo + (p.stage_bounds ? (size_t)k * nb : 0);
+    const double* bhi = p.hi + (p.stage_bounds ? (size_t)k * nb : 0);
+    for (int r = 0; r < nb; ++r) {
+      rb[f.RB - 2 * nb + r] = blo[r];
+      rb[f.RB - nb + r] = bhi[r];
+      rf[f.RF - 2 * nb + r] = blo[r];
+      rf[f.RF - nb + r] = bhi[r];
+    }
   }
 
   // ---- segment algebra ----

@@ -22,11 +22,15 @@ namespace admm {
 //   Si  [m][m]   inverse of S_k = R + rho I + B_k' P_{k+1} B_k
 //   KT  [n][m]   KT[i][j]  = K_k[j][i]
 //   Om  [n][m]   Omega_k   = -(Acl_{b-1} ... Acl_{k+1}) B_k     (b = segment end)
+//   LO  [m+n], HI [m+n]    the box of block k (u rows, then x rows)
 // Forward record (stage k), RF doubles:
 //   Psi [m][n]   Psi_k     = Si_k B_k' (Acl_{b-1} ... Acl_{k+1})'
 //   K   [m][n]
 //   A   [n][n]
 //   B   [n][m]
+//   LO  [m+n], HI [m+n]
+// (the box rides in both records so that a stage's whole operand set is one
+//  contiguous block, staged into LDS by one coalesced copy)
 // Segment record (segment s), 3 n*n doubles:
 //   Phi [n][n]   (Acl_{b-1} ... Acl_a)'          tail map   t_out = t_out0 + Phi t_in
 //   Xi  [n][n]   sum_k Omega_k Psi_k            x_out += Xi t_in
@@ -57,8 +61,8 @@ struct Factor {
 constexpr int SCAN_MT = 4;          // M-tiles (of 16 rows) per wave in xscan_mfma_kernel
 constexpr int SCAN_KALIGN = 16;     // k-step ranges and K/4 are padded to this (= 2 * SCAN_U of the kernel)
 
-inline int rec_b_size(int n, int m) { return n * n + m * n + m * m + n * m + n * m; }
-inline int rec_f_size(int n, int m) { return m * n + m * n + n * n + n * m; }
+inline int rec_b_size(int n, int m) { return n * n + m * n + m * m + n * m + n * m + 2 * (n + m); }
+inline int rec_f_size(int n, int m) { return m * n + m * n + n * n + n * m + 2 * (n + m); }
 inline int rec_s_size(int n) { return 3 * n * n; }
 
 // Validates nothing about the batch; only dynamics/weights.  Returns an

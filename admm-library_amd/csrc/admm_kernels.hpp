@@ -21,6 +21,18 @@ namespace admm {
 constexpr int XB_THREADS = 256;   // x-update workgroup: 4 waves = 256 QPs of one segment
 constexpr int Z_THREADS = 256;    // z/dual workgroup: 256 lanes x 2 QPs = 512 columns
 constexpr int T_TILE = 32;        // transpose tile
+constexpr int XB_PREFETCH = 4;    // stages of operand prefetch in xb / xfz (register ring depth)
+
+// Stage records (per-stage matrices + box, shared by the batch) are staged into LDS in
+// chunks of this many stages: <= 40 KiB per workgroup (two workgroups per CU), a
+// multiple of XB_PREFETCH so that ring slots stay aligned across refills.
+constexpr int stage_chunk(int rec_doubles) {
+  int ch = 5120 / rec_doubles;
+  ch = (ch / XB_PREFETCH) * XB_PREFETCH;
+  if (ch < XB_PREFETCH) ch = XB_PREFETCH;
+  if (ch > 64) ch = 64;
+  return ch;
+}
 
 // Per-stage matrices are wave-uniform; reading them through the constant
 // address space makes hipcc select scalar (SMEM) loads for them.
@@ -59,107 +71,131 @@ __device__ __forceinline__ cint_p as_const(const int* p) { return (cint_p)(uintp
 template <int NX, int NU, bool HASQ, bool VFORM>
 __global__ __launch_bounds__(XB_THREADS) void xb_kernel(
     const double* __restrict__ z, const double* __restrict__ y, const double* __restrict__ q,
-    const double* __restrict__ recB_, const int* __restrict__ seg_start_,
-    const double* __restrict__ lo_, const double* __restrict__ hi_,
+    const double* __restrict__ recB, const int* __restrict__ seg_start_,
     double* __restrict__ dbuf, double* __restrict__ tseg, double* __restrict__ eseg,
     double rho, int pitch) {
   // VFORM: `z` is the v array and `y` is unused.
   constexpr int NB = NX + NU;
-  constexpr int RB = NX * NX + NU * NX + NU * NU + NX * NU + NX * NU;
+  constexpr int RB = NX * NX + NU * NX + NU * NU + NX * NU + NX * NU + 2 * NB;
   constexpr int O_AT = 0, O_BT = NX * NX, O_SI = O_BT + NU * NX, O_KT = O_SI + NU * NU, O_OM = O_KT + NX * NU;
-  const int col = blockIdx.x * XB_THREADS + threadIdx.x;
+  constexpr int O_LO = O_OM + NX * NU, O_HI = O_LO + NB;
+  constexpr int PF = XB_PREFETCH;
+  constexpr int CH = stage_chunk(RB);            // stages whose records are staged in LDS at once
+  __shared__ double rec[CH * RB];
+
+  const int col_raw = blockIdx.x * XB_THREADS + threadIdx.x;
+  const bool active = col_raw < pitch;           // no early return: every wave reaches the barriers
+  const int col = active ? col_raw : pitch - 1;
   const int s = blockIdx.y;
-  if (col >= pitch) return;
   cint_p seg_start = as_const(seg_start_);
   const int k0 = seg_start[s], k1 = seg_start[s + 1];
   const size_t P = (size_t)pitch;
-  cdouble_p lo = as_const(lo_);
-  cdouble_p hi = as_const(hi_);
 
   double t[NX], e[NX];
 #pragma unroll
   for (int i = 0; i < NX; ++i) { t[i] = 0.0; e[i] = 0.0; }
 
-  double lz[NB], ly[NB], lq[NB];
-  {
-    const size_t r0 = (size_t)(k1 - 1) * NB * P + col;
+  // Operand prefetch ring, PF stages deep (slot = stage offset inside the unrolled group, so
+  // slots are compile-time registers).
+  double lz[PF][NB], ly[PF][NB], lq[PF][NB];
+#pragma unroll
+  for (int j = 0; j < PF; ++j) {
+    const int kj = (k1 - 1 - j > k0) ? k1 - 1 - j : k0;
+    const size_t r0 = (size_t)kj * NB * P + col;
 #pragma unroll
     for (int r = 0; r < NB; ++r) {
-      lz[r] = z[r0 + r * P];
-      if (!VFORM) ly[r] = y[r0 + r * P];
-      if (HASQ) lq[r] = q[r0 + r * P];
+      lz[j][r] = z[r0 + r * P];
+      if (!VFORM) ly[j][r] = y[r0 + r * P];
+      if (HASQ) lq[j][r] = q[r0 + r * P];
     }
   }
 
-  for (int k = k1 - 1; k >= k0; --k) {
-    double g[NB];
-#pragma unroll
-    for (int r = 0; r < NB; ++r) {
-      double zz = lz[r], yy;
-      if (VFORM) {
-        zz = fmin(fmax(lz[r], lo[k * NB + r]), hi[k * NB + r]);
-        yy = lz[r] - zz;
-      } else {
-        yy = ly[r];
-      }
-      g[r] = -rho * (zz - yy);
-      if (HASQ) g[r] += lq[r];
-    }
-    {  // prefetch the next (earlier) stage; clamped so the last one is a harmless re-read
-      const int kn = (k > k0) ? k - 1 : k0;
-      const size_t r0 = (size_t)kn * NB * P + col;
-#pragma unroll
-      for (int r = 0; r < NB; ++r) {
-        lz[r] = z[r0 + r * P];
-        if (!VFORM) ly[r] = y[r0 + r * P];
-        if (HASQ) lq[r] = q[r0 + r * P];
-      }
-    }
-    cdouble_p rb = as_const(recB_) + (size_t)k * RB;
-    double p[NX], h[NU], d[NU];
-#pragma unroll
-    for (int i = 0; i < NX; ++i) p[i] = g[NU + i] + t[i];
-#pragma unroll
-    for (int j = 0; j < NU; ++j) {
-      double a = g[j];
-#pragma unroll
-      for (int i = 0; i < NX; ++i) a = fma(rb[O_BT + j * NX + i], p[i], a);
-      h[j] = a;
-    }
-#pragma unroll
-    for (int j = 0; j < NU; ++j) {
-      double a = 0.0;
-#pragma unroll
-      for (int l = 0; l < NU; ++l) a = fma(rb[O_SI + j * NU + l], h[l], a);
-      d[j] = a;
-    }
+  for (int kc = k1 - 1; kc >= k0; kc -= CH) {      // LDS refill: stages kc, kc-1, ..., klo
+    const int klo = (kc - CH + 1 > k0) ? kc - CH + 1 : k0;
+    __syncthreads();
     {
-      const size_t d0 = (size_t)k * NU * P + col;
-#pragma unroll
-      for (int j = 0; j < NU; ++j) dbuf[d0 + j * P] = d[j];
+      const double* src = recB + (size_t)klo * RB;
+      const int cnt = (kc - klo + 1) * RB;
+      for (int i = threadIdx.x; i < cnt; i += XB_THREADS) rec[i] = src[i];
     }
+    __syncthreads();
+    for (int kb = kc; kb >= klo; kb -= PF) {
 #pragma unroll
-    for (int i = 0; i < NX; ++i) {
-      double a = 0.0;
+      for (int j = 0; j < PF; ++j) {
+        const int k = kb - j;
+        if (k < klo) break;
+        const double* rb = rec + (k - klo) * RB;     // wave-uniform address: LDS broadcast reads
+        double g[NB];
 #pragma unroll
-      for (int l = 0; l < NX; ++l) a = fma(rb[O_AT + i * NX + l], p[l], a);
+        for (int r = 0; r < NB; ++r) {
+          double zz = lz[j][r], yy;
+          if (VFORM) {
+            zz = fmin(fmax(lz[j][r], rb[O_LO + r]), rb[O_HI + r]);
+            yy = lz[j][r] - zz;
+          } else {
+            yy = ly[j][r];
+          }
+          g[r] = -rho * (zz - yy);
+          if (HASQ) g[r] += lq[j][r];
+        }
+        {  // refill this slot with stage k - PF (clamped: a harmless re-read near the segment start)
+          const int kn = (k - PF > k0) ? k - PF : k0;
+          const size_t r0 = (size_t)kn * NB * P + col;
 #pragma unroll
-      for (int j = 0; j < NU; ++j) a = fma(-rb[O_KT + i * NU + j], h[j], a);
-      t[i] = a;
-    }
+          for (int r = 0; r < NB; ++r) {
+            lz[j][r] = z[r0 + r * P];
+            if (!VFORM) ly[j][r] = y[r0 + r * P];
+            if (HASQ) lq[j][r] = q[r0 + r * P];
+          }
+        }
+        double p[NX], h[NU], d[NU];
 #pragma unroll
-    for (int i = 0; i < NX; ++i) {
-      double a = e[i];
+        for (int i = 0; i < NX; ++i) p[i] = g[NU + i] + t[i];
 #pragma unroll
-      for (int j = 0; j < NU; ++j) a = fma(rb[O_OM + i * NU + j], d[j], a);
-      e[i] = a;
+        for (int jj = 0; jj < NU; ++jj) {
+          double a = g[jj];
+#pragma unroll
+          for (int i = 0; i < NX; ++i) a = fma(rb[O_BT + jj * NX + i], p[i], a);
+          h[jj] = a;
+        }
+#pragma unroll
+        for (int jj = 0; jj < NU; ++jj) {
+          double a = 0.0;
+#pragma unroll
+          for (int l = 0; l < NU; ++l) a = fma(rb[O_SI + jj * NU + l], h[l], a);
+          d[jj] = a;
+        }
+        if (active) {
+          const size_t d0 = (size_t)k * NU * P + col;
+#pragma unroll
+          for (int jj = 0; jj < NU; ++jj) dbuf[d0 + jj * P] = d[jj];
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+          double a = 0.0;
+#pragma unroll
+          for (int l = 0; l < NX; ++l) a = fma(rb[O_AT + i * NX + l], p[l], a);
+#pragma unroll
+          for (int jj = 0; jj < NU; ++jj) a = fma(-rb[O_KT + i * NU + jj], h[jj], a);
+          t[i] = a;
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+          double a = e[i];
+#pragma unroll
+          for (int jj = 0; jj < NU; ++jj) a = fma(rb[O_OM + i * NU + jj], d[jj], a);
+          e[i] = a;
+        }
+      }
     }
   }
-  const size_t o = (size_t)s * NX * P + col;
+  if (active) {
+    const size_t o = (size_t)s * NX * P + col;
 #pragma unroll
-  for (int i = 0; i < NX; ++i) {
-    tseg[o + i * P] = t[i];
-    eseg[o + i * P] = e[i];
+    for (int i = 0; i < NX; ++i) {
+      tseg[o + i * P] = t[i];
+      eseg[o + i * P] = e[i];
+    }
   }
 }
 
@@ -387,7 +423,7 @@ __global__ __launch_bounds__(XB_THREADS) void xf_kernel(
     const double* __restrict__ recF_, const int* __restrict__ seg_start_,
     double* __restrict__ w, int pitch) {
   constexpr int NB = NX + NU;
-  constexpr int RF = NU * NX + NU * NX + NX * NX + NX * NU;
+  constexpr int RF = NU * NX + NU * NX + NX * NX + NX * NU + 2 * NB;   // box at the tail, unused here
   constexpr int O_PSI = 0, O_K = NU * NX, O_A = O_K + NU * NX, O_B = O_A + NX * NX;
   const int col = blockIdx.x * XB_THREADS + threadIdx.x;
   const int s = blockIdx.y;
@@ -469,24 +505,27 @@ __global__ __launch_bounds__(XB_THREADS) void xf_kernel(
 template <int NX, int NU, bool RESID, bool RELAX, bool VIN>
 __global__ __launch_bounds__(XB_THREADS) void xfz_kernel(
     const double* __restrict__ dbuf, const double* __restrict__ tin, const double* __restrict__ xin,
-    const double* __restrict__ recF_, const int* __restrict__ seg_start_,
+    const double* __restrict__ recF, const int* __restrict__ seg_start_,
     const double* __restrict__ zin, const double* __restrict__ yin, double* __restrict__ v,
-    const double* __restrict__ lo_, const double* __restrict__ hi_, double* __restrict__ part,
-    double alpha, int pitch) {
+    double* __restrict__ part, double alpha, int pitch) {
   // VIN: the state is read from v (zin, yin unused); otherwise from zin, yin.  Either
   // way v+ is written to v.  (zin / yin never alias v.)
   constexpr int NB = NX + NU;
-  constexpr int RF = NU * NX + NU * NX + NX * NX + NX * NU;
+  constexpr int RF = NU * NX + NU * NX + NX * NX + NX * NU + 2 * NB;
   constexpr int O_PSI = 0, O_K = NU * NX, O_A = O_K + NU * NX, O_B = O_A + NX * NX;
+  constexpr int O_LO = O_B + NX * NU, O_HI = O_LO + NB;
   constexpr bool NEEDZ = RESID || RELAX;
-  const int col = blockIdx.x * XB_THREADS + threadIdx.x;
+  constexpr int PF = XB_PREFETCH;
+  constexpr int CH = stage_chunk(RF);
+  __shared__ double rec[CH * RF];
+
+  const int col_raw = blockIdx.x * XB_THREADS + threadIdx.x;
+  const bool active = col_raw < pitch;
+  const int col = active ? col_raw : pitch - 1;
   const int s = blockIdx.y;
-  if (col >= pitch) return;
   cint_p seg_start = as_const(seg_start_);
   const int k0 = seg_start[s], k1 = seg_start[s + 1];
   const size_t P = (size_t)pitch;
-  cdouble_p lo = as_const(lo_);
-  cdouble_p hi = as_const(hi_);
   double t[NX], x[NX];
   {
     const size_t o = (size_t)s * NX * P + col;
@@ -496,101 +535,118 @@ __global__ __launch_bounds__(XB_THREADS) void xfz_kernel(
       x[i] = xin[o + i * P];
     }
   }
-  // prefetch registers: l0 = v (VIN) or y; l1 = z (only !VIN && NEEDZ)
-  double ld[NU], l0[NB], l1[NB];
-  {
-    const size_t d0 = (size_t)k0 * NU * P + col;
+  // prefetch ring (see xb_kernel): l0 = v (VIN) or y; l1 = z (only !VIN && NEEDZ)
+  double ld[PF][NU], l0[PF][NB], l1[PF][NB];
 #pragma unroll
-    for (int j = 0; j < NU; ++j) ld[j] = dbuf[d0 + j * P];
-    const size_t r0 = (size_t)k0 * NB * P + col;
+  for (int j = 0; j < PF; ++j) {
+    const int kj = (k0 + j < k1) ? k0 + j : k1 - 1;
+    const size_t d0 = (size_t)kj * NU * P + col;
+#pragma unroll
+    for (int jj = 0; jj < NU; ++jj) ld[j][jj] = dbuf[d0 + jj * P];
+    const size_t r0 = (size_t)kj * NB * P + col;
 #pragma unroll
     for (int r = 0; r < NB; ++r) {
       if (VIN) {
-        l0[r] = v[r0 + r * P];
+        l0[j][r] = v[r0 + r * P];
       } else {
-        l0[r] = yin[r0 + r * P];
-        if (NEEDZ) l1[r] = zin[r0 + r * P];
+        l0[j][r] = yin[r0 + r * P];
+        if (NEEDZ) l1[j][r] = zin[r0 + r * P];
       }
     }
   }
   double a_r = 0, a_s = 0, a_w = 0, a_z = 0, a_y = 0;
-  for (int k = k0; k < k1; ++k) {
-    double d[NU], c0[NB], c1[NB];
-#pragma unroll
-    for (int j = 0; j < NU; ++j) d[j] = ld[j];
-#pragma unroll
-    for (int r = 0; r < NB; ++r) {
-      c0[r] = l0[r];
-      if (!VIN && NEEDZ) c1[r] = l1[r];
+  for (int kc = k0; kc < k1; kc += CH) {           // LDS refill: stages kc .. khi
+    const int khi = (kc + CH - 1 < k1 - 1) ? kc + CH - 1 : k1 - 1;
+    __syncthreads();
+    {
+      const double* src = recF + (size_t)kc * RF;
+      const int cnt = (khi - kc + 1) * RF;
+      for (int i = threadIdx.x; i < cnt; i += XB_THREADS) rec[i] = src[i];
     }
-    {  // prefetch the next stage (clamped: the last one is a harmless re-read of
-       // rows this lane is about to overwrite -- same lane, program order)
-      const int kn = (k + 1 < k1) ? k + 1 : k;
-      const size_t d0 = (size_t)kn * NU * P + col;
+    __syncthreads();
+    for (int kb = kc; kb <= khi; kb += PF) {
 #pragma unroll
-      for (int j = 0; j < NU; ++j) ld[j] = dbuf[d0 + j * P];
-      const size_t r0 = (size_t)kn * NB * P + col;
+      for (int j = 0; j < PF; ++j) {
+        const int k = kb + j;
+        if (k > khi) break;
+        const double* rf = rec + (k - kc) * RF;      // wave-uniform address: LDS broadcast reads
+        double d[NU], c0[NB], c1[NB];
 #pragma unroll
-      for (int r = 0; r < NB; ++r) {
-        if (VIN) {
-          l0[r] = v[r0 + r * P];
-        } else {
-          l0[r] = yin[r0 + r * P];
-          if (NEEDZ) l1[r] = zin[r0 + r * P];
+        for (int jj = 0; jj < NU; ++jj) d[jj] = ld[j][jj];
+#pragma unroll
+        for (int r = 0; r < NB; ++r) {
+          c0[r] = l0[j][r];
+          if (!VIN && NEEDZ) c1[r] = l1[j][r];
+        }
+        {  // refill this slot with stage k + PF (clamped to the segment; a clamped re-read of
+           // rows this lane overwrites later is harmless: same lane, program order, value unused)
+          const int kn = (k + PF < k1) ? k + PF : k1 - 1;
+          const size_t d0 = (size_t)kn * NU * P + col;
+#pragma unroll
+          for (int jj = 0; jj < NU; ++jj) ld[j][jj] = dbuf[d0 + jj * P];
+          const size_t r0 = (size_t)kn * NB * P + col;
+#pragma unroll
+          for (int r = 0; r < NB; ++r) {
+            if (VIN) {
+              l0[j][r] = v[r0 + r * P];
+            } else {
+              l0[j][r] = yin[r0 + r * P];
+              if (NEEDZ) l1[j][r] = zin[r0 + r * P];
+            }
+          }
+        }
+        double wv[NB];
+#pragma unroll
+        for (int jj = 0; jj < NU; ++jj) {
+          double a = d[jj];
+#pragma unroll
+          for (int i = 0; i < NX; ++i) a = fma(rf[O_PSI + jj * NX + i], t[i], a);
+#pragma unroll
+          for (int i = 0; i < NX; ++i) a = fma(rf[O_K + jj * NX + i], x[i], a);
+          wv[jj] = -a;
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+          double a = 0.0;
+#pragma unroll
+          for (int l = 0; l < NX; ++l) a = fma(rf[O_A + i * NX + l], x[l], a);
+#pragma unroll
+          for (int jj = 0; jj < NU; ++jj) a = fma(rf[O_B + i * NU + jj], wv[jj], a);
+          wv[NU + i] = a;
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) x[i] = wv[NU + i];
+        const size_t r0 = (size_t)k * NB * P + col;
+#pragma unroll
+        for (int r = 0; r < NB; ++r) {
+          const double l = rf[O_LO + r], h = rf[O_HI + r];
+          double zo, yo;                       // state before this z-update
+          if (VIN) {
+            zo = fmin(fmax(c0[r], l), h);
+            yo = c0[r] - zo;
+          } else {
+            yo = c0[r];
+            zo = NEEDZ ? c1[r] : 0.0;
+          }
+          double wh = wv[r];
+          if (RELAX) wh = fma(alpha, wv[r], (1.0 - alpha) * zo);
+          const double vn = wh + yo;
+          if (active) v[r0 + r * P] = vn;
+          if (RESID) {
+            const double zn = fmin(fmax(vn, l), h);
+            const double yn = vn - zn;
+            const double dr = wv[r] - zn, ds = zn - zo;
+            a_r = fma(dr, dr, a_r);
+            a_s = fma(ds, ds, a_s);
+            a_w = fma(wv[r], wv[r], a_w);
+            a_z = fma(zn, zn, a_z);
+            a_y = fma(yn, yn, a_y);
+          }
         }
       }
     }
-    cdouble_p rf = as_const(recF_) + (size_t)k * RF;
-    double wv[NB];
-#pragma unroll
-    for (int j = 0; j < NU; ++j) {
-      double a = d[j];
-#pragma unroll
-      for (int i = 0; i < NX; ++i) a = fma(rf[O_PSI + j * NX + i], t[i], a);
-#pragma unroll
-      for (int i = 0; i < NX; ++i) a = fma(rf[O_K + j * NX + i], x[i], a);
-      wv[j] = -a;
-    }
-#pragma unroll
-    for (int i = 0; i < NX; ++i) {
-      double a = 0.0;
-#pragma unroll
-      for (int l = 0; l < NX; ++l) a = fma(rf[O_A + i * NX + l], x[l], a);
-#pragma unroll
-      for (int j = 0; j < NU; ++j) a = fma(rf[O_B + i * NU + j], wv[j], a);
-      wv[NU + i] = a;
-    }
-#pragma unroll
-    for (int i = 0; i < NX; ++i) x[i] = wv[NU + i];
-    const size_t r0 = (size_t)k * NB * P + col;
-#pragma unroll
-    for (int r = 0; r < NB; ++r) {
-      const double l = lo[k * NB + r], h = hi[k * NB + r];
-      double zo, yo;                       // state before this z-update
-      if (VIN) {
-        zo = fmin(fmax(c0[r], l), h);
-        yo = c0[r] - zo;
-      } else {
-        yo = c0[r];
-        zo = NEEDZ ? c1[r] : 0.0;
-      }
-      double wh = wv[r];
-      if (RELAX) wh = fma(alpha, wv[r], (1.0 - alpha) * zo);
-      const double vn = wh + yo;
-      v[r0 + r * P] = vn;
-      if (RESID) {
-        const double zn = fmin(fmax(vn, l), h);
-        const double yn = vn - zn;
-        const double dr = wv[r] - zn, ds = zn - zo;
-        a_r = fma(dr, dr, a_r);
-        a_s = fma(ds, ds, a_s);
-        a_w = fma(wv[r], wv[r], a_w);
-        a_z = fma(zn, zn, a_z);
-        a_y = fma(yn, yn, a_y);
-      }
-    }
   }
-  if (RESID) {
+  if (RESID && active) {
     const size_t o = (size_t)s * 5 * P + col;
     part[o + 0 * P] = a_r;
     part[o + 1 * P] = a_s;

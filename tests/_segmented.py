@@ -16,18 +16,21 @@ def unpack(rec, n, m):
     SI = rb[:, o:o + m * m].reshape(N, m, m); o += m * m
     KT = rb[:, o:o + n * m].reshape(N, n, m); o += n * m
     OM = rb[:, o:o + n * m].reshape(N, n, m); o += n * m
+    LO, HI = rb[:, o:o + n + m], rb[:, o + n + m:o + 2 * (n + m)]; o += 2 * (n + m)
     assert o == rb.shape[1]
     o = 0
     PSI = rf[:, o:o + m * n].reshape(N, m, n); o += m * n
     K = rf[:, o:o + m * n].reshape(N, m, n); o += m * n
     A = rf[:, o:o + n * n].reshape(N, n, n); o += n * n
     B = rf[:, o:o + n * m].reshape(N, n, m); o += n * m
+    assert np.array_equal(rf[:, o:o + n + m], LO) and np.array_equal(rf[:, o + n + m:o + 2 * (n + m)], HI)
+    o += 2 * (n + m)
     assert o == rf.shape[1]
     S = rs.shape[0]
     PHI = rs[:, :n * n].reshape(S, n, n)
     XI = rs[:, n * n:2 * n * n].reshape(S, n, n)
     TH = rs[:, 2 * n * n:].reshape(S, n, n)
-    return dict(AT=AT, BT=BT, SI=SI, KT=KT, OM=OM, PSI=PSI, K=K, A=A, B=B, PHI=PHI, XI=XI, TH=TH)
+    return dict(AT=AT, BT=BT, SI=SI, KT=KT, OM=OM, PSI=PSI, K=K, A=A, B=B, PHI=PHI, XI=XI, TH=TH, LO=LO, HI=HI)
 
 
 def x_update_segmented(rec, n, m, g, x0, scan="chain", return_parts=False):

@@ -74,6 +74,11 @@ def test_host_factor_matches_oracles(lib, make, rho):
         assert np.abs(hf["K"] - a).max() <= 1e-11 * max(1.0, np.abs(a).max())
     for a in (f.Sinv, Si):
         assert np.abs(hf["Sinv"] - a).max() <= 1e-11 * max(1.0, np.abs(a).max())
+    from _segmented import unpack
+    lo, hi = ar.expand_bounds(p.lo, p.hi, p.N, p.nb)
+    u = unpack(hf, p.n, p.m)
+    np.testing.assert_array_equal(u["LO"].reshape(-1), lo)      # the box rides in the stage records
+    np.testing.assert_array_equal(u["HI"].reshape(-1), hi)
     assert hf["seg_start"][0] == 0 and hf["seg_start"][-1] == p.N
     assert (np.diff(hf["seg_start"]) > 0).all()
 
