@@ -155,29 +155,30 @@ int factorise(const admm_problem& p, double rho, int segments, Factor& f, std::s
     for (size_t i = 0; i < K.size(); ++i) f.K[(size_t)k * m * n + i] = K[i];
     for (size_t i = 0; i < Si.size(); ++i) f.Sinv[(size_t)k * m * m + i] = Si[i];
 
-    // stage-local parts of the records
+    // stage-local parts of the records (offsets: admm_layout.hpp)
+    const RecBLayout lb = rec_b_layout(n, m);
+    const RecFLayout lf = rec_f_layout(n, m);
     double* rb = &f.recB[(size_t)k * f.RB];
     const Mat KT = tr(K, m, n);
-    size_t o = 0;
-    for (size_t i = 0; i < At.size(); ++i) rb[o++] = At[i];   // AT
-    for (size_t i = 0; i < Bt.size(); ++i) rb[o++] = Bt[i];   // BT
-    for (size_t i = 0; i < Si.size(); ++i) rb[o++] = Si[i];   // Si
-    for (size_t i = 0; i < KT.size(); ++i) rb[o++] = KT[i];   // KT
+    for (size_t i = 0; i < At.size(); ++i) rb[lb.AT + i] = At[i];
+    for (size_t i = 0; i < Bt.size(); ++i) rb[lb.BT + i] = Bt[i];
+    for (size_t i = 0; i < Si.size(); ++i) rb[lb.SI + i] = Si[i];
+    for (size_t i = 0; i < KT.size(); ++i) rb[lb.KT + i] = KT[i];
     // Om filled below
     double* rf = &f.recF[(size_t)k * f.RF];
-    o = (size_t)m * n;                                        // Psi filled below
-    for (size_t i = 0; i < K.size(); ++i) rf[o++] = K[i];
-    for (size_t i = 0; i < A[k].size(); ++i) rf[o++] = A[k][i];
-    for (size_t i = 0; i < B[k].size(); ++i) rf[o++] = B[k][i];
+    // Psi filled below
+    for (size_t i = 0; i < K.size(); ++i) rf[lf.K + i] = K[i];
+    for (size_t i = 0; i < A[k].size(); ++i) rf[lf.A + i] = A[k][i];
+    for (size_t i = 0; i < B[k].size(); ++i) rf[lf.B + i] = B[k][i];
     // the box of block k rides at the tail of both records
     const int nb = n + m;
     const double* blo = p.lo + (p.stage_bounds ? (size_t)k * nb : 0);
     const double* bhi = p.hi + (p.stage_bounds ? (size_t)k * nb : 0);
     for (int r = 0; r < nb; ++r) {
-      rb[f.RB - 2 * nb + r] = blo[r];
-      rb[f.RB - nb + r] = bhi[r];
-      rf[f.RF - 2 * nb + r] = blo[r];
-      rf[f.RF - nb + r] = bhi[r];
+      rb[lb.LO + r] = blo[r];
+      rb[lb.HI + r] = bhi[r];
+      rf[lf.LO + r] = blo[r];
+      rf[lf.HI + r] = bhi[r];
     }
   }
 
@@ -195,9 +196,9 @@ int factorise(const admm_problem& p, double rho, int segments, Factor& f, std::s
       const Mat Psi = mul(Si, mul(Bt, Phi, m, n, n), m, m, n);
       const Mat OP = mul(Om, Psi, n, m, n);
       for (size_t i = 0; i < Xi.size(); ++i) Xi[i] += OP[i];
-      double* rb = &f.recB[(size_t)k * f.RB + (size_t)n * n + (size_t)m * n + (size_t)m * m + (size_t)n * m];
+      double* rb = &f.recB[(size_t)k * f.RB + rec_b_layout(n, m).OM];
       for (size_t i = 0; i < Om.size(); ++i) rb[i] = Om[i];
-      double* rf = &f.recF[(size_t)k * f.RF];
+      double* rf = &f.recF[(size_t)k * f.RF + rec_f_layout(n, m).PSI];
       for (size_t i = 0; i < Psi.size(); ++i) rf[i] = Psi[i];
       Lam = mul(Lam, Acl[k], n, n, n);
     }

@@ -10,11 +10,12 @@
 #include <vector>
 
 #include "../../include/admm_hip.h"
+#include "admm_layout.hpp"
 
 namespace admm {
 
 // Packed per-stage records, laid out in the order the kernels consume them.
-// All row-major, fp64.
+// All row-major, fp64; block offsets (even, zero-padded) come from admm_layout.hpp.
 //
 // Backward record (stage k), RB doubles:
 //   AT  [n][n]   AT[i][l]  = A_k[l][i]
@@ -61,8 +62,8 @@ struct Factor {
 constexpr int SCAN_MT = 4;          // M-tiles (of 16 rows) per wave in xscan_mfma_kernel
 constexpr int SCAN_KALIGN = 16;     // k-step ranges and K/4 are padded to this (= 2 * SCAN_U of the kernel)
 
-inline int rec_b_size(int n, int m) { return n * n + m * n + m * m + n * m + n * m + 2 * (n + m); }
-inline int rec_f_size(int n, int m) { return m * n + m * n + n * n + n * m + 2 * (n + m); }
+inline int rec_b_size(int n, int m) { return rec_b_layout(n, m).SIZE; }
+inline int rec_f_size(int n, int m) { return rec_f_layout(n, m).SIZE; }
 inline int rec_s_size(int n) { return 3 * n * n; }
 
 // Validates nothing about the batch; only dynamics/weights.  Returns an

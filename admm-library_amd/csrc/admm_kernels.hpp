@@ -16,12 +16,20 @@
 #include <cstddef>
 #include <cstdint>
 
+#include "admm_layout.hpp"
+
 namespace admm {
 
-constexpr int XB_THREADS = 256;   // x-update workgroup: 4 waves = 256 QPs of one segment
+#ifndef ADMM_XB_THREADS
+#define ADMM_XB_THREADS 256
+#endif
+#ifndef ADMM_XB_PREFETCH
+#define ADMM_XB_PREFETCH 1
+#endif
+constexpr int XB_THREADS = ADMM_XB_THREADS;   // x-update workgroup: 4 waves = 256 QPs of one segment
 constexpr int Z_THREADS = 256;    // z/dual workgroup: 256 lanes x 2 QPs = 512 columns
 constexpr int T_TILE = 32;        // transpose tile
-constexpr int XB_PREFETCH = 4;    // stages of operand prefetch in xb / xfz (register ring depth)
+constexpr int XB_PREFETCH = ADMM_XB_PREFETCH;    // stages of operand prefetch in xb / xfz (register ring depth)
 
 // Stage records (per-stage matrices + box, shared by the batch) are staged into LDS in
 // chunks of this many stages: <= 40 KiB per workgroup (two workgroups per CU), a
@@ -43,6 +51,20 @@ __device__ __forceinline__ cdouble_p as_const(const double* p) {
   return (cdouble_p)(uintptr_t)p;
 }
 __device__ __forceinline__ cint_p as_const(const int* p) { return (cint_p)(uintptr_t)p; }
+
+// LEN (even) doubles from a 16-byte-aligned, wave-uniform LDS address, as 16-byte pairs
+// (ds_read_b128 broadcasts).
+template <int LEN>
+__device__ __forceinline__ void lds_block(const double* p, double (&o)[LEN]) {
+  static_assert(LEN % 2 == 0, "blocks are padded to even length");
+  const double2* q = reinterpret_cast<const double2*>(p);
+#pragma unroll
+  for (int c = 0; c < LEN / 2; ++c) {
+    const double2 v = q[c];
+    o[2 * c] = v.x;
+    o[2 * c + 1] = v.y;
+  }
+}
 
 // ---------------------------------------------------------------------------
 // State compression ("v-form").  After any z-update,
@@ -76,12 +98,11 @@ __global__ __launch_bounds__(XB_THREADS) void xb_kernel(
     double rho, int pitch) {
   // VFORM: `z` is the v array and `y` is unused.
   constexpr int NB = NX + NU;
-  constexpr int RB = NX * NX + NU * NX + NU * NU + NX * NU + NX * NU + 2 * NB;
-  constexpr int O_AT = 0, O_BT = NX * NX, O_SI = O_BT + NU * NX, O_KT = O_SI + NU * NU, O_OM = O_KT + NX * NU;
-  constexpr int O_LO = O_OM + NX * NU, O_HI = O_LO + NB;
+  constexpr RecBLayout LB = rec_b_layout(NX, NU);
+  constexpr int RB = LB.SIZE;
   constexpr int PF = XB_PREFETCH;
   constexpr int CH = stage_chunk(RB);            // stages whose records are staged in LDS at once
-  __shared__ double rec[CH * RB];
+  __shared__ __attribute__((aligned(16))) double rec[CH * RB];
 
   const int col_raw = blockIdx.x * XB_THREADS + threadIdx.x;
   const bool active = col_raw < pitch;           // no early return: every wave reaches the barriers
@@ -125,12 +146,17 @@ __global__ __launch_bounds__(XB_THREADS) void xb_kernel(
         const int k = kb - j;
         if (k < klo) break;
         const double* rb = rec + (k - klo) * RB;     // wave-uniform address: LDS broadcast reads
+        double mLO[even_up(NB)], mHI[even_up(NB)];
+        if (VFORM) {
+          lds_block(rb + LB.LO, mLO);
+          lds_block(rb + LB.HI, mHI);
+        }
         double g[NB];
 #pragma unroll
         for (int r = 0; r < NB; ++r) {
           double zz = lz[j][r], yy;
           if (VFORM) {
-            zz = fmin(fmax(lz[j][r], rb[O_LO + r]), rb[O_HI + r]);
+            zz = fmin(fmax(lz[j][r], mLO[r]), mHI[r]);
             yy = lz[j][r] - zz;
           } else {
             yy = ly[j][r];
@@ -149,20 +175,27 @@ __global__ __launch_bounds__(XB_THREADS) void xb_kernel(
           }
         }
         double p[NX], h[NU], d[NU];
+        double mBT[even_up(NU * NX)], mSI[even_up(NU * NU)], mAT[even_up(NX * NX)], mKT[even_up(NX * NU)],
+            mOM[even_up(NX * NU)];
+        lds_block(rb + LB.BT, mBT);
+        lds_block(rb + LB.SI, mSI);
+        lds_block(rb + LB.AT, mAT);
+        lds_block(rb + LB.KT, mKT);
+        lds_block(rb + LB.OM, mOM);
 #pragma unroll
         for (int i = 0; i < NX; ++i) p[i] = g[NU + i] + t[i];
 #pragma unroll
         for (int jj = 0; jj < NU; ++jj) {
           double a = g[jj];
 #pragma unroll
-          for (int i = 0; i < NX; ++i) a = fma(rb[O_BT + jj * NX + i], p[i], a);
+          for (int i = 0; i < NX; ++i) a = fma(mBT[jj * NX + i], p[i], a);
           h[jj] = a;
         }
 #pragma unroll
         for (int jj = 0; jj < NU; ++jj) {
           double a = 0.0;
 #pragma unroll
-          for (int l = 0; l < NU; ++l) a = fma(rb[O_SI + jj * NU + l], h[l], a);
+          for (int l = 0; l < NU; ++l) a = fma(mSI[jj * NU + l], h[l], a);
           d[jj] = a;
         }
         if (active) {
@@ -174,16 +207,16 @@ __global__ __launch_bounds__(XB_THREADS) void xb_kernel(
         for (int i = 0; i < NX; ++i) {
           double a = 0.0;
 #pragma unroll
-          for (int l = 0; l < NX; ++l) a = fma(rb[O_AT + i * NX + l], p[l], a);
+          for (int l = 0; l < NX; ++l) a = fma(mAT[i * NX + l], p[l], a);
 #pragma unroll
-          for (int jj = 0; jj < NU; ++jj) a = fma(-rb[O_KT + i * NU + jj], h[jj], a);
+          for (int jj = 0; jj < NU; ++jj) a = fma(-mKT[i * NU + jj], h[jj], a);
           t[i] = a;
         }
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
           double a = e[i];
 #pragma unroll
-          for (int jj = 0; jj < NU; ++jj) a = fma(rb[O_OM + i * NU + jj], d[jj], a);
+          for (int jj = 0; jj < NU; ++jj) a = fma(mOM[i * NU + jj], d[jj], a);
           e[i] = a;
         }
       }
@@ -423,8 +456,9 @@ __global__ __launch_bounds__(XB_THREADS) void xf_kernel(
     const double* __restrict__ recF_, const int* __restrict__ seg_start_,
     double* __restrict__ w, int pitch) {
   constexpr int NB = NX + NU;
-  constexpr int RF = NU * NX + NU * NX + NX * NX + NX * NU + 2 * NB;   // box at the tail, unused here
-  constexpr int O_PSI = 0, O_K = NU * NX, O_A = O_K + NU * NX, O_B = O_A + NX * NX;
+  constexpr RecFLayout LF = rec_f_layout(NX, NU);
+  constexpr int RF = LF.SIZE;
+  constexpr int O_PSI = LF.PSI, O_K = LF.K, O_A = LF.A, O_B = LF.B;
   const int col = blockIdx.x * XB_THREADS + threadIdx.x;
   const int s = blockIdx.y;
   if (col >= pitch) return;
@@ -511,13 +545,12 @@ __global__ __launch_bounds__(XB_THREADS) void xfz_kernel(
   // VIN: the state is read from v (zin, yin unused); otherwise from zin, yin.  Either
   // way v+ is written to v.  (zin / yin never alias v.)
   constexpr int NB = NX + NU;
-  constexpr int RF = NU * NX + NU * NX + NX * NX + NX * NU + 2 * NB;
-  constexpr int O_PSI = 0, O_K = NU * NX, O_A = O_K + NU * NX, O_B = O_A + NX * NX;
-  constexpr int O_LO = O_B + NX * NU, O_HI = O_LO + NB;
+  constexpr RecFLayout LF = rec_f_layout(NX, NU);
+  constexpr int RF = LF.SIZE;
   constexpr bool NEEDZ = RESID || RELAX;
   constexpr int PF = XB_PREFETCH;
   constexpr int CH = stage_chunk(RF);
-  __shared__ double rec[CH * RF];
+  __shared__ __attribute__((aligned(16))) double rec[CH * RF];
 
   const int col_raw = blockIdx.x * XB_THREADS + threadIdx.x;
   const bool active = col_raw < pitch;
@@ -596,22 +629,30 @@ __global__ __launch_bounds__(XB_THREADS) void xfz_kernel(
           }
         }
         double wv[NB];
+        double mPSI[even_up(NU * NX)], mK[even_up(NU * NX)], mA[even_up(NX * NX)], mB[even_up(NX * NU)],
+            mLO[even_up(NB)], mHI[even_up(NB)];
+        lds_block(rf + LF.PSI, mPSI);
+        lds_block(rf + LF.K, mK);
+        lds_block(rf + LF.A, mA);
+        lds_block(rf + LF.B, mB);
+        lds_block(rf + LF.LO, mLO);
+        lds_block(rf + LF.HI, mHI);
 #pragma unroll
         for (int jj = 0; jj < NU; ++jj) {
           double a = d[jj];
 #pragma unroll
-          for (int i = 0; i < NX; ++i) a = fma(rf[O_PSI + jj * NX + i], t[i], a);
+          for (int i = 0; i < NX; ++i) a = fma(mPSI[jj * NX + i], t[i], a);
 #pragma unroll
-          for (int i = 0; i < NX; ++i) a = fma(rf[O_K + jj * NX + i], x[i], a);
+          for (int i = 0; i < NX; ++i) a = fma(mK[jj * NX + i], x[i], a);
           wv[jj] = -a;
         }
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
           double a = 0.0;
 #pragma unroll
-          for (int l = 0; l < NX; ++l) a = fma(rf[O_A + i * NX + l], x[l], a);
+          for (int l = 0; l < NX; ++l) a = fma(mA[i * NX + l], x[l], a);
 #pragma unroll
-          for (int jj = 0; jj < NU; ++jj) a = fma(rf[O_B + i * NU + jj], wv[jj], a);
+          for (int jj = 0; jj < NU; ++jj) a = fma(mB[i * NU + jj], wv[jj], a);
           wv[NU + i] = a;
         }
 #pragma unroll
@@ -619,7 +660,7 @@ __global__ __launch_bounds__(XB_THREADS) void xfz_kernel(
         const size_t r0 = (size_t)k * NB * P + col;
 #pragma unroll
         for (int r = 0; r < NB; ++r) {
-          const double l = rf[O_LO + r], h = rf[O_HI + r];
+          const double l = mLO[r], h = mHI[r];
           double zo, yo;                       // state before this z-update
           if (VIN) {
             zo = fmin(fmax(c0[r], l), h);

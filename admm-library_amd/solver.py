@@ -34,7 +34,8 @@ class AdmmError(RuntimeError):
 
 
 def library_path() -> str:
-    return os.path.join(_PKG_DIR, _LIB_NAME)
+    """In-tree libadmm_hip.so; ADMM_HIP_LIB overrides it (A/B runs of kernel variants)."""
+    return os.environ.get("ADMM_HIP_LIB") or os.path.join(_PKG_DIR, _LIB_NAME)
 
 
 # name -> (restype, argtypes); every symbol include/admm_hip.h declares.

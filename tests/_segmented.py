@@ -7,29 +7,47 @@ xf_kernel of csrc/admm_kernels.hpp statement by statement."""
 import numpy as np
 
 
+def _even(v):
+    return (v + 1) & ~1
+
+
 def unpack(rec, n, m):
+    """Split the packed records (layout: csrc/admm_layout.hpp -- every block starts at an
+    even offset, zero padded)."""
     N = rec["recB"].shape[0]
     rb, rf, rs = rec["recB"], rec["recF"], rec["recS"]
+    nb = n + m
+
+    def take(a, o, rows, cols):
+        blk = a[:, o:o + rows * cols].reshape(N, rows, cols) if cols > 1 or rows > 1 else a[:, o:o + 1]
+        pad = a[:, o + rows * cols:o + _even(rows * cols)]
+        assert not pad.any()
+        return blk, o + _even(rows * cols)
+
     o = 0
-    AT = rb[:, o:o + n * n].reshape(N, n, n); o += n * n
-    BT = rb[:, o:o + m * n].reshape(N, m, n); o += m * n
-    SI = rb[:, o:o + m * m].reshape(N, m, m); o += m * m
-    KT = rb[:, o:o + n * m].reshape(N, n, m); o += n * m
-    OM = rb[:, o:o + n * m].reshape(N, n, m); o += n * m
-    LO, HI = rb[:, o:o + n + m], rb[:, o + n + m:o + 2 * (n + m)]; o += 2 * (n + m)
+    AT, o = take(rb, o, n, n)
+    BT, o = take(rb, o, m, n)
+    SI, o = take(rb, o, m, m)
+    KT, o = take(rb, o, n, m)
+    OM, o = take(rb, o, n, m)
+    LO = rb[:, o:o + nb]; o += _even(nb)
+    HI = rb[:, o:o + nb]; o += _even(nb)
     assert o == rb.shape[1]
     o = 0
-    PSI = rf[:, o:o + m * n].reshape(N, m, n); o += m * n
-    K = rf[:, o:o + m * n].reshape(N, m, n); o += m * n
-    A = rf[:, o:o + n * n].reshape(N, n, n); o += n * n
-    B = rf[:, o:o + n * m].reshape(N, n, m); o += n * m
-    assert np.array_equal(rf[:, o:o + n + m], LO) and np.array_equal(rf[:, o + n + m:o + 2 * (n + m)], HI)
-    o += 2 * (n + m)
+    PSI, o = take(rf, o, m, n)
+    K, o = take(rf, o, m, n)
+    A, o = take(rf, o, n, n)
+    B, o = take(rf, o, n, m)
+    assert np.array_equal(rf[:, o:o + nb], LO) and np.array_equal(rf[:, o + _even(nb):o + _even(nb) + nb], HI)
+    o += 2 * _even(nb)
     assert o == rf.shape[1]
     S = rs.shape[0]
     PHI = rs[:, :n * n].reshape(S, n, n)
     XI = rs[:, n * n:2 * n * n].reshape(S, n, n)
     TH = rs[:, 2 * n * n:].reshape(S, n, n)
+    AT, BT, SI, KT, OM, PSI, K, A, B = [np.asarray(x).reshape(N, r, c) for x, (r, c) in
+                                        zip((AT, BT, SI, KT, OM, PSI, K, A, B),
+                                            ((n, n), (m, n), (m, m), (n, m), (n, m), (m, n), (m, n), (n, n), (n, m)))]
     return dict(AT=AT, BT=BT, SI=SI, KT=KT, OM=OM, PSI=PSI, K=K, A=A, B=B, PHI=PHI, XI=XI, TH=TH, LO=LO, HI=HI)
 
 
