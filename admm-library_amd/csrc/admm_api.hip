@@ -111,7 +111,7 @@ static_assert(admm::SCAN_KALIGN == 2 * admm::SCAN_U, "host range alignment must 
 
 int launch_xscan_mfma(admm_handle* h) {
   const int mtiles = h->fac.scanM / 16, ngroups = mtiles / admm::SCAN_MT;
-  dim3 grid(h->pitch / 16, (ngroups + 3) / 4), block(256);
+  dim3 grid(h->pitch / 64, ngroups), block(256);
   hipLaunchKernelGGL((admm::xscan_mfma_kernel<admm::SCAN_MT>), grid, block, 0, h->stream, h->scanWp,
                      h->scan_in, h->scan_out, h->scan_range, mtiles, ngroups, h->pitch);
   return ADMM_OK;
@@ -440,12 +440,14 @@ int admm_setup(admm_handle** out, const admm_problem* p, const admm_options* o_i
   h->pitch = ((p->batch + 63) / 64) * 64;
   h->has_q = p->q != nullptr;
 
-  // x-update segments: enough (column-wave x segment) pairs for >= 2 waves per SIMD.
+  // x-update segments: one (column-wave x segment) wave per SIMD (1024 SIMDs).  Measured on
+  // MI355X: the x kernels run as fast at 1 wave/SIMD as at 2, and the scan's
+  // work grows with S^2, so fewer, longer segments win; S = 16 for pitch 4096.
   {
     int S = o.segments;
     if (S == 0) {
       const int wave_cols = h->pitch / 64;
-      S = (2048 + wave_cols - 1) / wave_cols;
+      S = (1024 + wave_cols - 1) / wave_cols;
       const int max_by_len = h->N >= 16 ? h->N / 8 : 1;
       if (S > max_by_len) S = max_by_len;
       if (S > 64) S = 64;

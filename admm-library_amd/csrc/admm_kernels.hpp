@@ -57,6 +57,11 @@ __device__ __forceinline__ cint_p as_const(const int* p) { return (cint_p)(uintp
 template <int LEN>
 __device__ __forceinline__ void lds_block(const double* p, double (&o)[LEN]) {
   static_assert(LEN % 2 == 0, "blocks are padded to even length");
+#ifdef ADMM_ABLATE_LDS      // timing-only diagnostic build: no LDS reads, wrong results
+#pragma unroll
+  for (int c = 0; c < LEN; ++c) o[c] = 0.25 + 0.001 * c;
+  (void)p;
+#else
   const double2* q = reinterpret_cast<const double2*>(p);
 #pragma unroll
   for (int c = 0; c < LEN / 2; ++c) {
@@ -64,6 +69,7 @@ __device__ __forceinline__ void lds_block(const double* p, double (&o)[LEN]) {
     o[2 * c] = v.x;
     o[2 * c + 1] = v.y;
   }
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -169,7 +175,11 @@ __global__ __launch_bounds__(XB_THREADS) void xb_kernel(
           const size_t r0 = (size_t)kn * NB * P + col;
 #pragma unroll
           for (int r = 0; r < NB; ++r) {
+#ifdef ADMM_ABLATE_GLOBAL   // timing-only diagnostic build: no operand loads in the stage loop
+            lz[j][r] = lz[j][r] * 0.5 + (double)r0;
+#else
             lz[j][r] = z[r0 + r * P];
+#endif
             if (!VFORM) ly[j][r] = y[r0 + r * P];
             if (HASQ) lq[j][r] = q[r0 + r * P];
           }
@@ -219,6 +229,9 @@ __global__ __launch_bounds__(XB_THREADS) void xb_kernel(
           for (int jj = 0; jj < NU; ++jj) a = fma(mOM[i * NU + jj], d[jj], a);
           e[i] = a;
         }
+        // keep the unrolled stages apart: without this the scheduler hoists the next stage's
+        // LDS matrix reads across the boundary and the register file overflows into AGPR moves
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   }
@@ -379,9 +392,10 @@ __global__ __launch_bounds__(64) void xscan_kernel(
 // batch-minor layout IS the row-major B operand.  This trades 2S dependent
 // latency-bound steps for one pass of v_mfma_f64_16x16x4_f64.
 //   wave  = one 16-column N-tile x SCAN_MT M-tiles (4 accumulators: covers the MFMA
-//           dependent-issue latency); workgroup = 4 waves = 4 M-groups of one N-tile
-//   A     = W pre-packed on the host in fragment order (one coalesced 512-B load
-//           per fragment, L2-resident: 1.2 MB); B = in[4 ks + (lane>>4)][n0 + (lane&15)]
+//           dependent-issue latency); workgroup = 4 waves = 4 N-tiles of one M-group
+//   A     = W pre-packed on the host in fragment order (coalesced, L2-resident: 1.4 MB),
+//           fetched once per workgroup into a double-buffered LDS slab;
+//           B = in[4 ks + (lane>>4)][n0 + (lane&15)], straight to registers
 //   sparsity: per M-group the [k_begin, k_end) step range outside which its rows of
 //           W vanish (block-triangular structure) comes from the host; ~50 % skipped.
 // f64 MFMA operand maps (cdna_hip_programming.md §3): A[i = lane&15][k = lane>>4],
@@ -389,51 +403,69 @@ __global__ __launch_bounds__(64) void xscan_kernel(
 // ---------------------------------------------------------------------------
 typedef double mfma_d4 __attribute__((ext_vector_type(4)));
 
-constexpr int SCAN_U = 8;   // k-steps per register batch; host pads K and the ranges to 2 * SCAN_U steps
+constexpr int SCAN_U = 8;   // k-steps per batch; host pads K and the ranges to 2 * SCAN_U steps
 
 template <int MT>
 __global__ __launch_bounds__(256) void xscan_mfma_kernel(
     const double* __restrict__ Wp, const double* __restrict__ in, double* __restrict__ out,
     const int* __restrict__ krange_, int mtiles, int ngroups, int pitch) {
+  // Workgroup = 4 waves = 4 adjacent N-tiles (64 columns) of ONE M-group, so the A
+  // fragments (the same for every N-tile) are fetched from L2 once per workgroup and
+  // shared through a double-buffered LDS slab; each wave loads its own B fragments.
   constexpr int U = SCAN_U;
-  const int lane = threadIdx.x & 63;
-  const int group = blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform
-  if (group >= ngroups) return;
+  constexpr int SLAB = U * MT * 64;                  // doubles of A per batch (16 KiB at MT = 4)
+  __shared__ __attribute__((aligned(16))) double abuf[2][SLAB];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int group = ngroups - 1 - (int)blockIdx.y;   // long k-ranges (x_in rows) are dispatched first
   cint_p krange = as_const(krange_);
   const int kb = krange[2 * group], ke = krange[2 * group + 1];    // multiples of 2 U
   const size_t P = (size_t)pitch;
-  const int n0 = blockIdx.x * 16;
+  const int n0 = (blockIdx.x * 4 + wave) * 16;       // pitch is a multiple of 64
   const double* bptr = in + (size_t)(lane >> 4) * P + n0 + (lane & 15);
-  const double* aptr = Wp + (size_t)group * MT * 64 + lane;
+  const double* aptr = Wp + (size_t)group * MT * 64 + tid;         // this thread's element of each k-step's slab row
   const size_t astep = (size_t)mtiles * 64, bstep = 4 * P;
   mfma_d4 acc[MT];
 #pragma unroll
   for (int t = 0; t < MT; ++t) acc[t] = mfma_d4{0.0, 0.0, 0.0, 0.0};
-  // Two register batches in ping-pong: while the MFMAs of one batch issue, the loads
-  // of the next are in flight.  Written as an explicit A/B body so that no register
-  // copy (and hence no vmcnt(0)) sits on the loop back-edge.
-  double a0[U][MT], b0[U], a1[U][MT], b1[U];
-#define SCAN_LOAD(A_, B_, KS_)                                   \
-  _Pragma("unroll") for (int u = 0; u < U; ++u) {                \
-    B_[u] = bptr[(size_t)((KS_) + u) * bstep];                   \
-    _Pragma("unroll") for (int t = 0; t < MT; ++t) A_[u][t] = aptr[(size_t)((KS_) + u) * astep + t * 64]; \
-  }
-#define SCAN_MMA(A_, B_)                                         \
-  _Pragma("unroll") for (int u = 0; u < U; ++u) {                \
-    _Pragma("unroll") for (int t = 0; t < MT; ++t)               \
-      acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(A_[u][t], B_[u], acc[t], 0, 0, 0); \
-  }
   if (kb < ke) {
-    SCAN_LOAD(a0, b0, kb)
-    for (int ks = kb; ks < ke; ks += 2 * U) {
-      SCAN_LOAD(a1, b1, ks + U)
-      SCAN_MMA(a0, b0)
-      if (ks + 2 * U < ke) { SCAN_LOAD(a0, b0, ks + 2 * U) }
-      SCAN_MMA(a1, b1)
+    double ar[U], bc[U], bn[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      ar[u] = aptr[(size_t)(kb + u) * astep];
+      bc[u] = bptr[(size_t)(kb + u) * bstep];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) abuf[0][u * MT * 64 + tid] = ar[u];
+    __syncthreads();
+    int buf = 0;
+    for (int ks = kb; ks < ke; ks += U) {
+      const bool has_next = ks + U < ke;
+      if (has_next) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          ar[u] = aptr[(size_t)(ks + U + u) * astep];
+          bn[u] = bptr[(size_t)(ks + U + u) * bstep];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(abuf[buf][(u * MT + t) * 64 + lane], bc[u], acc[t], 0, 0, 0);
+      }
+      if (has_next) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          abuf[buf ^ 1][u * MT * 64 + tid] = ar[u];
+          bc[u] = bn[u];
+        }
+      }
+      __syncthreads();
+      buf ^= 1;
     }
   }
-#undef SCAN_LOAD
-#undef SCAN_MMA
 #pragma unroll
   for (int t = 0; t < MT; ++t) {
     const int row0 = (group * MT + t) * 16 + (lane >> 4);
@@ -684,6 +716,7 @@ __global__ __launch_bounds__(XB_THREADS) void xfz_kernel(
             a_y = fma(yn, yn, a_y);
           }
         }
+        __builtin_amdgcn_sched_barrier(0);   // see xb_kernel
       }
     }
   }

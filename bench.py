@@ -18,11 +18,11 @@ device (check_interval = 1), which is the most expensive honest form of the
 iteration.  `value` = QP-iterations/s summed over all ranks.
 
 Extra objects on the JSON line:
-  roofline     -- the dominant kernel, xfz<RESID>: 8 m/(n+m) + 32 = 34.67 B per
-                  stacked element (d, z, y read; z+, y+ written; fp64) x L x
-                  pitch per launch, divided by its average launch duration
-                  measured with HIP events on the library's own stream
-                  (admm_profile).
+  roofline     -- the dominant kernel, xfz<RESID, VIN>: 8 m/(n+m) + 16 = 18.67 B per
+                  stacked element (d and v read; v+ written; fp64 -- the state is
+                  kept in v-form) x L x pitch per launch, divided
+                  by its average launch duration measured with HIP events on the
+                  library's own stream (admm_profile).
   roofline_zdual_standalone -- the standalone fused z/dual/residual kernel of
                   the ADMM_FLAG_UNFUSED path (40 B per element),
                   measured the same way in the same run.
@@ -140,10 +140,11 @@ def main():
     L = full.L
     elems = L * geo["pitch"]
     n_, m_ = full.n, full.m
-    b_xfz = 8.0 * m_ / (n_ + m_) + 32.0          # d read + z, y read + z+, y+ written
+    b_xfz = 8.0 * m_ / (n_ + m_) + 16.0          # d read + v read + v+ written
     xfz_ms = prof["xfz_ms"]
     achieved = b_xfz * elems / (xfz_ms * 1e-3) / 1e9
-    roofline = {"kernel": "xfz_kernel<6,3,RESID=true> (forward rollout fused with z-update + dual ascent + residual partials)",
+    roofline = {"kernel": "xfz_kernel<6,3,RESID=true,RELAX=false,VIN=true> (forward rollout fused with z-update + dual "
+                          "ascent + residual partials, state in v-form)",
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                 "bytes_per_launch": b_xfz * elems, "bytes_per_element": b_xfz, "avg_launch_ms": xfz_ms}
@@ -153,8 +154,9 @@ def main():
                   "bound": "hbm", "achieved": zs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": zs / HBM_PEAK_GBS,
                   "bytes_per_launch": BYTES_PER_ELEM_ZDUAL * elems, "bytes_per_element": BYTES_PER_ELEM_ZDUAL,
                   "avg_launch_ms": zs_ms}
-    b_xb = 16.0 + 8.0 * m_ / (n_ + m_)
+    b_xb = 8.0 + 8.0 * m_ / (n_ + m_)             # v read + d written
     xb_gbs = b_xb * elems / (prof["xb_ms"] * 1e-3) / 1e9
+    b_iter = b_xb + b_xfz                          # algorithmic HBM bytes per element per fused iteration
 
     # mixed mode a solver would normally run: residuals every 10th iteration
     solver.run(10, residual_every=10)
@@ -182,7 +184,9 @@ def main():
             "kernels_ms": {"fused_resid": {k: round(v, 5) for k, v in prof.items()},
                            "fused_plain": {k: round(v, 5) for k, v in prof_plain.items()},
                            "unfused_resid": {k: round(v, 5) for k, v in prof_unf.items()},
-                           "xb_GBs": xb_gbs},
+                           "xb_GBs": xb_gbs, "xb_bytes_per_element": b_xb,
+                           "iteration_bytes_per_element": b_iter,
+                           "iteration_GBs": b_iter * elems / (ms_per_step * 1e-3) / 1e9},
             "check_interval_10": {"batch_iterations_per_s": a.steps / dt10,
                                   "QP_iterations_per_s": a.batch * a.steps / dt10},
         }
