@@ -20,7 +20,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def pmc(dirname, counter):
-    f = glob.glob(os.path.join(dirname, "*", "*_counter_collection.csv"))[0]
+    f = max(glob.glob(os.path.join(dirname, "*", "*_counter_collection.csv")), key=os.path.getmtime)   # newest run
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == counter:
@@ -30,7 +30,7 @@ def pmc(dirname, counter):
 
 def main():
     tag, stats = sys.argv[1], sys.argv[2]
-    src = glob.glob(os.path.join(stats, "*", "*_kernel_stats.csv"))[0]
+    src = max(glob.glob(os.path.join(stats, "*", "*_kernel_stats.csv")), key=os.path.getmtime)   # newest run
     shutil.copy(src, os.path.join(HERE, f"{tag}_kernel_stats.csv"))
     if len(sys.argv) >= 5:
         fe, wr = pmc(sys.argv[3], "FETCH_SIZE"), pmc(sys.argv[4], "WRITE_SIZE")
