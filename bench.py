@@ -113,12 +113,21 @@ def main():
     if pkg.device_count() < 1:
         raise SystemExit("bench.py: no HIP device visible; the solver has no CPU fallback")
 
+    # One process per GPU.  ADMM_BENCH_BACKEND=gloo (+ several ranks sharing one GPU) exists only to
+    # rehearse the N > 1 code path on a 1-GPU box; the driver's runs use RCCL ("nccl").
+    backend = os.environ.get("ADMM_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % max(ndev, 1) if backend != "nccl" else local_rank
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    red_device = f"cuda:{dev_index}" if backend == "nccl" else "cpu"
 
     def barrier():
         if dist is not None:
@@ -129,7 +138,7 @@ def main():
     gbatch = a.batch * world
     lo_i, hi_i = pkg.shard_bounds(gbatch, world, rank)
     full = pkg.cw_rendezvous(N=a.horizon, batch=hi_i - lo_i, seed0=pkg.SEED0 + lo_i)
-    opt = pkg.Options(rho=0.05, check_interval=1, segments=a.segments, zrows=a.zrows, device=local_rank)
+    opt = pkg.Options(rho=0.05, check_interval=1, segments=a.segments, zrows=a.zrows, device=dev_index)
     solver = pkg.Solver(full, opt)
     geo = solver.geometry()
 
@@ -140,7 +149,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
+        t = torch.tensor([dt], dtype=torch.float64, device=red_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -185,6 +194,10 @@ def main():
     solver.run(a.steps, residual_every=10, sync=True)
     barrier()
     dt10 = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt10], dtype=torch.float64, device=red_device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt10 = float(t.item())
 
     if rank == 0:
         out = {
@@ -208,7 +221,7 @@ def main():
                            "iteration_bytes_per_element": b_iter,
                            "iteration_GBs": b_iter * elems / (ms_per_step * 1e-3) / 1e9},
             "check_interval_10": {"batch_iterations_per_s": a.steps / dt10,
-                                  "QP_iterations_per_s": a.batch * a.steps / dt10},
+                                  "QP_iterations_per_s": gbatch * a.steps / dt10},
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.horizon, a.cpu_seconds)

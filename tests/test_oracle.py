@@ -169,3 +169,34 @@ def test_warm_start_and_elements_on_bounds():
     zn, yn = ar.z_update(w, np.zeros_like(w), np.zeros_like(w), lo, hi)
     np.testing.assert_array_equal(zn, w)
     np.testing.assert_array_equal(yn, np.zeros_like(w))
+
+
+def test_c_oracle_under_sanitizers(tmp_path):
+    """the CPU oracle built with -fsanitize=address,undefined runs a small solve
+    cleanly (GPU sanitizers are not available on the pool; this covers the checker itself)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["make", "-C", os.path.join(root, "oracle"), "-s", "liboracle_asan.so"], check=True)
+    libasan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True, check=True).stdout.strip()
+    code = f"""
+import sys, ctypes as C, numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, {os.path.join(root, 'oracle')!r})
+import admm_library_amd as pkg
+from admm_library_amd import _abi
+lib = C.CDLL({os.path.join(root, 'oracle', 'liboracle_asan.so')!r})
+p = pkg.random_ltv(N=13, n=4, m=2, batch=5, seed=3)
+cp, keep = _abi.marshal_problem(p)
+co = _abi.make_options(rho=0.3, max_iter=25, check_interval=4)
+z = np.zeros((5, p.L)); y = np.zeros((5, p.L)); w = np.zeros((5, p.L))
+it = np.zeros(5, np.int32); st = np.zeros(5, np.int32); r = np.zeros(5); s = np.zeros(5); run = C.c_int32()
+lib.oracle_solve.argtypes = [C.POINTER(_abi.CProblem), C.POINTER(_abi.COptions), C.c_int32] + [_abi.c_double_p] * 3 + [_abi.c_int32_p] * 2 + [_abi.c_double_p] * 2 + [_abi.c_int32_p, C.c_int32]
+rc = lib.oracle_solve(C.byref(cp), C.byref(co), 1, _abi.dptr(z), _abi.dptr(y), _abi.dptr(w), _abi.iptr(it), _abi.iptr(st), _abi.dptr(r), _abi.dptr(s), C.byref(run), 2)
+assert rc == 0 and np.isfinite(z).all()
+print("ok", run.value)
+"""
+    env = dict(os.environ, LD_PRELOAD=libasan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1",
+               UBSAN_OPTIONS="halt_on_error=1", OMP_NUM_THREADS="2")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0 and out.stdout.startswith("ok"), out.stderr[-2000:]
