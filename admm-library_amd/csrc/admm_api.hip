@@ -4,6 +4,7 @@
 // every compute entry point returns ADMM_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -474,6 +475,14 @@ int admm_setup(admm_handle** out, const admm_problem* p, const admm_options* o_i
   rc = admm::factorise(*p, o.rho, h->S, h->fac, err);
   if (rc) { release(h); return fail(rc, err); }
   h->S = h->fac.S;
+  {  // the x kernels address one segment of an array through a 32-bit buffer descriptor
+    int longest = 0;
+    for (int s = 0; s < h->S; ++s) longest = std::max(longest, h->fac.seg_start[s + 1] - h->fac.seg_start[s]);
+    if ((double)longest * h->nb * h->pitch * 8.0 >= 4.0e9) {
+      release(h);
+      return fail(ADMM_ERR_UNSUPPORTED, "one segment of the state exceeds 4 GB: use more segments or a smaller batch per GPU");
+    }
+  }
 
 #define TRY_RELEASE(expr) do { int rc_ = (expr); if (rc_) { std::string keep = g_err; release(h); g_err = keep; return rc_; } } while (0)
 #define HIP_TRY_RELEASE(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { release(h); return fail(ADMM_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } } while (0)

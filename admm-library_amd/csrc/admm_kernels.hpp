@@ -31,15 +31,49 @@ constexpr int Z_THREADS = 256;    // z/dual workgroup: 256 lanes x 2 QPs = 512 c
 constexpr int T_TILE = 32;        // transpose tile
 constexpr int XB_PREFETCH = ADMM_XB_PREFETCH;    // stages of operand prefetch in xb / xfz (register ring depth)
 
+// The x kernels run at 1-2 waves per SIMD (grid size and the LDS record slab decide that, not
+// registers).  Saying so lets the scheduler spend registers on instruction-level parallelism:
+// left at the default it minimises register pressure and serialises every LDS operand read
+// (`ds_read_b128 v[2:5]; s_waitcnt lgkmcnt(0); use; ...` -- measured 30 % slower on xfz).
+#ifndef ADMM_X_MAX_WAVES
+#define ADMM_X_MAX_WAVES 2
+#endif
+#define ADMM_X_OCCUPANCY __attribute__((amdgpu_waves_per_eu(1, ADMM_X_MAX_WAVES)))
+
 // Stage records (per-stage matrices + box, shared by the batch) are staged into LDS in
-// chunks of this many stages: <= 40 KiB per workgroup (two workgroups per CU), a
+// chunks of this many stages: <= 64 KiB per workgroup (two workgroups per CU still fit), a
 // multiple of XB_PREFETCH so that ring slots stay aligned across refills.
 constexpr int stage_chunk(int rec_doubles) {
-  int ch = 5120 / rec_doubles;
+  int ch = 8192 / rec_doubles;
   ch = (ch / XB_PREFETCH) * XB_PREFETCH;
   if (ch < XB_PREFETCH) ch = XB_PREFETCH;
-  if (ch > 64) ch = 64;
+  if (ch > 128) ch = 128;
   return ch;
+}
+
+// Cooperative global -> LDS copy of `cnt` doubles (cnt even, both sides 16-byte aligned).
+// Four independent 16-byte loads per thread are issued before the first LDS write: a naive
+// element loop compiles to load / s_waitcnt vmcnt(0) / ds_write per element, i.e. one exposed
+// memory round trip per 2 KiB of records.
+template <int THREADS>
+__device__ __forceinline__ void stage_records(double* lds, const double* src, int cnt, int tid) {
+  const double2* s2 = reinterpret_cast<const double2*>(src);
+  double2* d2 = reinterpret_cast<double2*>(lds);
+  const int cnt2 = cnt >> 1;
+  constexpr int U = 4;
+  for (int i0 = 0; i0 < cnt2; i0 += THREADS * U) {
+    double2 tmp[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = i0 + u * THREADS + tid;
+      tmp[u] = (i < cnt2) ? s2[i] : double2{0.0, 0.0};
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = i0 + u * THREADS + tid;
+      if (i < cnt2) d2[i] = tmp[u];
+    }
+  }
 }
 
 // Per-stage matrices are wave-uniform; reading them through the constant
@@ -51,6 +85,27 @@ __device__ __forceinline__ cdouble_p as_const(const double* p) {
   return (cdouble_p)(uintptr_t)p;
 }
 __device__ __forceinline__ cint_p as_const(const int* p) { return (cint_p)(uintptr_t)p; }
+
+// Rows of a batch-minor array through a buffer resource: the 128-bit descriptor and the row's
+// byte offset are wave-uniform (SGPRs), the lane part is ONE 32-bit byte offset shared by every
+// access of the kernel -- `buffer_load_dwordx2 v, v_off, s[rsrc], s_row offen`.  No per-access
+// 64-bit VALU address arithmetic (it was ~18 % of the VALU instructions of a stage) and no
+// per-row address VGPRs.  The descriptor spans one segment of the array (< 4 GiB, checked at
+// setup), so out-of-range accesses are dropped by the hardware instead of faulting.
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+struct RowView {
+  __amdgpu_buffer_rsrc_t rsrc;
+  __device__ __forceinline__ RowView(const double* base, size_t first_elem, size_t span_bytes)
+      : rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(base + first_elem), 0,
+                                               (int)(unsigned)span_bytes, 0x00020000)) {}
+  __device__ __forceinline__ double load(unsigned lane_bytes, unsigned row_bytes) const {
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsrc, lane_bytes, row_bytes, 0));
+  }
+  __device__ __forceinline__ void store(double v, unsigned lane_bytes, unsigned row_bytes) const {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rsrc, lane_bytes, row_bytes, 0);
+  }
+};
 
 // LEN (even) doubles from a 16-byte-aligned, wave-uniform LDS address, as 16-byte pairs
 // (ds_read_b128 broadcasts).
@@ -70,6 +125,49 @@ __device__ __forceinline__ void lds_block(const double* p, double (&o)[LEN]) {
     o[2 * c + 1] = v.y;
   }
 #endif
+}
+
+// acc[r] (+|-)= sum_c M[r][c] x[c] with M (ROWS x COLS, row-major, zero-padded to even length)
+// at a 16-byte-aligned, wave-uniform LDS address.  The matrix is consumed as a flat stream of
+// 16-byte pairs; per row the products are accumulated in column order (the same order as a plain
+// row loop).  For large blocks a scheduling barrier every LDS_GROUP_PAIRS pairs stops the
+// scheduler from hoisting the whole matrix into registers (n = 12 spilled to scratch without it);
+// blocks of up to 2 * LDS_GROUP_PAIRS doubles (all of n = 6, m = 3) are unaffected.
+constexpr int LDS_GROUP_PAIRS = 24;
+
+template <int ROWS, int COLS, bool NEG>
+__device__ __forceinline__ void lds_matvec_acc(const double* blk, const double (&x)[COLS], double (&acc)[ROWS]) {
+  constexpr int PAIRS = even_up(ROWS * COLS) / 2;
+  constexpr int G = LDS_GROUP_PAIRS;
+#ifndef ADMM_ABLATE_LDS
+  const double2* q = reinterpret_cast<const double2*>(blk);
+#else
+  (void)blk;
+#endif
+  // Group by group: first every 16-byte read of the group (source order = issue order, so the
+  // reads pipeline and the waits are counted), then its FMAs.  Interleaving read/use in the
+  // source made the scheduler wait for each read individually.
+#pragma unroll
+  for (int g0 = 0; g0 < PAIRS; g0 += G) {
+    double2 m[G];
+#pragma unroll
+    for (int c = 0; c < G; ++c)
+      if (g0 + c < PAIRS) {
+#ifdef ADMM_ABLATE_LDS      // timing-only diagnostic build: no LDS reads, wrong results
+        m[c] = double2{0.25 + 0.001 * (g0 + c), 0.125 + 0.002 * (g0 + c)};
+#else
+        m[c] = q[g0 + c];
+#endif
+      }
+#pragma unroll
+    for (int c = 0; c < G; ++c)
+      if (g0 + c < PAIRS) {
+        const int e0 = 2 * (g0 + c), e1 = e0 + 1;
+        if (e0 < ROWS * COLS) acc[e0 / COLS] = fma(NEG ? -m[c].x : m[c].x, x[e0 % COLS], acc[e0 / COLS]);
+        if (e1 < ROWS * COLS) acc[e1 / COLS] = fma(NEG ? -m[c].y : m[c].y, x[e1 % COLS], acc[e1 / COLS]);
+      }
+    if (g0 + G < PAIRS) __builtin_amdgcn_sched_barrier(0);   // large blocks only: bound the hoisting
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -97,7 +195,7 @@ __device__ __forceinline__ void lds_block(const double* p, double (&o)[LEN]) {
 // otherwise read z, y 16.
 // ---------------------------------------------------------------------------
 template <int NX, int NU, bool HASQ, bool VFORM>
-__global__ __launch_bounds__(XB_THREADS) void xb_kernel(
+__global__ __launch_bounds__(XB_THREADS) ADMM_X_OCCUPANCY void xb_kernel(
     const double* __restrict__ z, const double* __restrict__ y, const double* __restrict__ q,
     const double* __restrict__ recB, const int* __restrict__ seg_start_,
     double* __restrict__ dbuf, double* __restrict__ tseg, double* __restrict__ eseg,
@@ -110,13 +208,27 @@ __global__ __launch_bounds__(XB_THREADS) void xb_kernel(
   constexpr int CH = stage_chunk(RB);            // stages whose records are staged in LDS at once
   __shared__ __attribute__((aligned(16))) double rec[CH * RB];
 
+  // No early return (every wave must reach the barriers) and no store predicate: lanes past the
+  // pitch are clamped onto the last column, compute exactly what that column's lane computes and
+  // store the same values to the same addresses -- harmless, and the stage loop stays branch-free.
   const int col_raw = blockIdx.x * XB_THREADS + threadIdx.x;
-  const bool active = col_raw < pitch;           // no early return: every wave reaches the barriers
-  const int col = active ? col_raw : pitch - 1;
+  const int col = col_raw < pitch ? col_raw : pitch - 1;
+#ifdef ADMM_STORE_PRED      // A/B diagnostic: the older predicated-store form
+  const bool st = col_raw < pitch;
+#else
+  constexpr bool st = true;
+#endif
   const int s = blockIdx.y;
   cint_p seg_start = as_const(seg_start_);
   const int k0 = seg_start[s], k1 = seg_start[s + 1];
   const size_t P = (size_t)pitch;
+  const unsigned lb = (unsigned)col * 8u;          // this lane's byte offset inside a row
+  const unsigned PB = (unsigned)pitch * 8u;        // bytes per row
+  // views of this segment's rows (row offsets below are relative to stage k0)
+  const RowView vz(z, (size_t)k0 * NB * P, (size_t)(k1 - k0) * NB * P * 8);
+  const RowView vy(VFORM ? z : y, (size_t)k0 * NB * P, (size_t)(k1 - k0) * NB * P * 8);
+  const RowView vq(HASQ ? q : z, (size_t)k0 * NB * P, (size_t)(k1 - k0) * NB * P * 8);
+  const RowView vd(dbuf, (size_t)k0 * NU * P, (size_t)(k1 - k0) * NU * P * 8);
 
   double t[NX], e[NX];
 #pragma unroll
@@ -128,23 +240,19 @@ __global__ __launch_bounds__(XB_THREADS) void xb_kernel(
 #pragma unroll
   for (int j = 0; j < PF; ++j) {
     const int kj = (k1 - 1 - j > k0) ? k1 - 1 - j : k0;
-    const size_t r0 = (size_t)kj * NB * P + col;
+    const unsigned r0 = (unsigned)(kj - k0) * NB * PB;
 #pragma unroll
     for (int r = 0; r < NB; ++r) {
-      lz[j][r] = z[r0 + r * P];
-      if (!VFORM) ly[j][r] = y[r0 + r * P];
-      if (HASQ) lq[j][r] = q[r0 + r * P];
+      lz[j][r] = vz.load(lb, r0 + r * PB);
+      if (!VFORM) ly[j][r] = vy.load(lb, r0 + r * PB);
+      if (HASQ) lq[j][r] = vq.load(lb, r0 + r * PB);
     }
   }
 
   for (int kc = k1 - 1; kc >= k0; kc -= CH) {      // LDS refill: stages kc, kc-1, ..., klo
     const int klo = (kc - CH + 1 > k0) ? kc - CH + 1 : k0;
     __syncthreads();
-    {
-      const double* src = recB + (size_t)klo * RB;
-      const int cnt = (kc - klo + 1) * RB;
-      for (int i = threadIdx.x; i < cnt; i += XB_THREADS) rec[i] = src[i];
-    }
+    stage_records<XB_THREADS>(rec, recB + (size_t)klo * RB, (kc - klo + 1) * RB, threadIdx.x);
     __syncthreads();
     for (int kb = kc; kb >= klo; kb -= PF) {
 #pragma unroll
@@ -172,70 +280,46 @@ __global__ __launch_bounds__(XB_THREADS) void xb_kernel(
         }
         {  // refill this slot with stage k - PF (clamped: a harmless re-read near the segment start)
           const int kn = (k - PF > k0) ? k - PF : k0;
-          const size_t r0 = (size_t)kn * NB * P + col;
+          const unsigned r0 = (unsigned)(kn - k0) * NB * PB;
 #pragma unroll
           for (int r = 0; r < NB; ++r) {
 #ifdef ADMM_ABLATE_GLOBAL   // timing-only diagnostic build: no operand loads in the stage loop
             lz[j][r] = lz[j][r] * 0.5 + (double)r0;
 #else
-            lz[j][r] = z[r0 + r * P];
+            lz[j][r] = vz.load(lb, r0 + r * PB);
 #endif
-            if (!VFORM) ly[j][r] = y[r0 + r * P];
-            if (HASQ) lq[j][r] = q[r0 + r * P];
+            if (!VFORM) ly[j][r] = vy.load(lb, r0 + r * PB);
+            if (HASQ) lq[j][r] = vq.load(lb, r0 + r * PB);
           }
         }
         double p[NX], h[NU], d[NU];
-        double mBT[even_up(NU * NX)], mSI[even_up(NU * NU)], mAT[even_up(NX * NX)], mKT[even_up(NX * NU)],
-            mOM[even_up(NX * NU)];
-        lds_block(rb + LB.BT, mBT);
-        lds_block(rb + LB.SI, mSI);
-        lds_block(rb + LB.AT, mAT);
-        lds_block(rb + LB.KT, mKT);
-        lds_block(rb + LB.OM, mOM);
 #pragma unroll
         for (int i = 0; i < NX; ++i) p[i] = g[NU + i] + t[i];
 #pragma unroll
-        for (int jj = 0; jj < NU; ++jj) {
-          double a = g[jj];
+        for (int jj = 0; jj < NU; ++jj) h[jj] = g[jj];
+        __builtin_amdgcn_sched_barrier(0);                        // region boundary (see xfz_kernel)
+        lds_matvec_acc<NU, NX, false>(rb + LB.BT, p, h);          // h = g^u + B' p
 #pragma unroll
-          for (int i = 0; i < NX; ++i) a = fma(mBT[jj * NX + i], p[i], a);
-          h[jj] = a;
+        for (int jj = 0; jj < NU; ++jj) d[jj] = 0.0;
+        lds_matvec_acc<NU, NU, false>(rb + LB.SI, h, d);          // d = Si h
+        if (st) {
+          const unsigned d0 = (unsigned)(k - k0) * NU * PB;
+#pragma unroll
+          for (int jj = 0; jj < NU; ++jj) vd.store(d[jj], lb, d0 + jj * PB);
         }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int jj = 0; jj < NU; ++jj) {
-          double a = 0.0;
-#pragma unroll
-          for (int l = 0; l < NU; ++l) a = fma(mSI[jj * NU + l], h[l], a);
-          d[jj] = a;
-        }
-        if (active) {
-          const size_t d0 = (size_t)k * NU * P + col;
-#pragma unroll
-          for (int jj = 0; jj < NU; ++jj) dbuf[d0 + jj * P] = d[jj];
-        }
-#pragma unroll
-        for (int i = 0; i < NX; ++i) {
-          double a = 0.0;
-#pragma unroll
-          for (int l = 0; l < NX; ++l) a = fma(mAT[i * NX + l], p[l], a);
-#pragma unroll
-          for (int jj = 0; jj < NU; ++jj) a = fma(-mKT[i * NU + jj], h[jj], a);
-          t[i] = a;
-        }
-#pragma unroll
-        for (int i = 0; i < NX; ++i) {
-          double a = e[i];
-#pragma unroll
-          for (int jj = 0; jj < NU; ++jj) a = fma(mOM[i * NU + jj], d[jj], a);
-          e[i] = a;
-        }
+        for (int i = 0; i < NX; ++i) t[i] = 0.0;
+        lds_matvec_acc<NX, NX, false>(rb + LB.AT, p, t);          // t = A' p
+        lds_matvec_acc<NX, NU, true>(rb + LB.KT, h, t);           //       - K' h
+        lds_matvec_acc<NX, NU, false>(rb + LB.OM, d, e);          // e += Omega d
         // keep the unrolled stages apart: without this the scheduler hoists the next stage's
         // LDS matrix reads across the boundary and the register file overflows into AGPR moves
         __builtin_amdgcn_sched_barrier(0);
       }
     }
   }
-  if (active) {
+  {
     const size_t o = (size_t)s * NX * P + col;
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
@@ -569,7 +653,7 @@ __global__ __launch_bounds__(XB_THREADS) void xf_kernel(
 //     d read 8 m/(n+m) + v read 8 + v+ written 8        (= 18.67 for n = 6, m = 3)
 // ---------------------------------------------------------------------------
 template <int NX, int NU, bool RESID, bool RELAX, bool VIN>
-__global__ __launch_bounds__(XB_THREADS) void xfz_kernel(
+__global__ __launch_bounds__(XB_THREADS) ADMM_X_OCCUPANCY void xfz_kernel(
     const double* __restrict__ dbuf, const double* __restrict__ tin, const double* __restrict__ xin,
     const double* __restrict__ recF, const int* __restrict__ seg_start_,
     const double* __restrict__ zin, const double* __restrict__ yin, double* __restrict__ v,
@@ -585,12 +669,23 @@ __global__ __launch_bounds__(XB_THREADS) void xfz_kernel(
   __shared__ __attribute__((aligned(16))) double rec[CH * RF];
 
   const int col_raw = blockIdx.x * XB_THREADS + threadIdx.x;
-  const bool active = col_raw < pitch;
-  const int col = active ? col_raw : pitch - 1;
+  const int col = col_raw < pitch ? col_raw : pitch - 1;      // clamped lanes duplicate the last column (see xb_kernel)
+#ifdef ADMM_STORE_PRED
+  const bool st = col_raw < pitch;
+#else
+  constexpr bool st = true;
+#endif
   const int s = blockIdx.y;
   cint_p seg_start = as_const(seg_start_);
   const int k0 = seg_start[s], k1 = seg_start[s + 1];
   const size_t P = (size_t)pitch;
+  const unsigned lb = (unsigned)col * 8u;          // this lane's byte offset inside a row
+  const unsigned PB = (unsigned)pitch * 8u;        // bytes per row
+  // views of this segment's rows (row offsets below are relative to stage k0)
+  const RowView vv(v, (size_t)k0 * NB * P, (size_t)(k1 - k0) * NB * P * 8);
+  const RowView vy(VIN ? v : yin, (size_t)k0 * NB * P, (size_t)(k1 - k0) * NB * P * 8);
+  const RowView vz(VIN ? v : zin, (size_t)k0 * NB * P, (size_t)(k1 - k0) * NB * P * 8);
+  const RowView vd(dbuf, (size_t)k0 * NU * P, (size_t)(k1 - k0) * NU * P * 8);
   double t[NX], x[NX];
   {
     const size_t o = (size_t)s * NX * P + col;
@@ -605,17 +700,17 @@ __global__ __launch_bounds__(XB_THREADS) void xfz_kernel(
 #pragma unroll
   for (int j = 0; j < PF; ++j) {
     const int kj = (k0 + j < k1) ? k0 + j : k1 - 1;
-    const size_t d0 = (size_t)kj * NU * P + col;
+    const unsigned d0 = (unsigned)(kj - k0) * NU * PB;
 #pragma unroll
-    for (int jj = 0; jj < NU; ++jj) ld[j][jj] = dbuf[d0 + jj * P];
-    const size_t r0 = (size_t)kj * NB * P + col;
+    for (int jj = 0; jj < NU; ++jj) ld[j][jj] = vd.load(lb, d0 + jj * PB);
+    const unsigned r0 = (unsigned)(kj - k0) * NB * PB;
 #pragma unroll
     for (int r = 0; r < NB; ++r) {
       if (VIN) {
-        l0[j][r] = v[r0 + r * P];
+        l0[j][r] = vv.load(lb, r0 + r * PB);
       } else {
-        l0[j][r] = yin[r0 + r * P];
-        if (NEEDZ) l1[j][r] = zin[r0 + r * P];
+        l0[j][r] = vy.load(lb, r0 + r * PB);
+        if (NEEDZ) l1[j][r] = vz.load(lb, r0 + r * PB);
       }
     }
   }
@@ -623,11 +718,7 @@ __global__ __launch_bounds__(XB_THREADS) void xfz_kernel(
   for (int kc = k0; kc < k1; kc += CH) {           // LDS refill: stages kc .. khi
     const int khi = (kc + CH - 1 < k1 - 1) ? kc + CH - 1 : k1 - 1;
     __syncthreads();
-    {
-      const double* src = recF + (size_t)kc * RF;
-      const int cnt = (khi - kc + 1) * RF;
-      for (int i = threadIdx.x; i < cnt; i += XB_THREADS) rec[i] = src[i];
-    }
+    stage_records<XB_THREADS>(rec, recF + (size_t)kc * RF, (khi - kc + 1) * RF, threadIdx.x);
     __syncthreads();
     for (int kb = kc; kb <= khi; kb += PF) {
 #pragma unroll
@@ -646,53 +737,49 @@ __global__ __launch_bounds__(XB_THREADS) void xfz_kernel(
         {  // refill this slot with stage k + PF (clamped to the segment; a clamped re-read of
            // rows this lane overwrites later is harmless: same lane, program order, value unused)
           const int kn = (k + PF < k1) ? k + PF : k1 - 1;
-          const size_t d0 = (size_t)kn * NU * P + col;
+          const unsigned d0 = (unsigned)(kn - k0) * NU * PB;
 #pragma unroll
-          for (int jj = 0; jj < NU; ++jj) ld[j][jj] = dbuf[d0 + jj * P];
-          const size_t r0 = (size_t)kn * NB * P + col;
+          for (int jj = 0; jj < NU; ++jj) ld[j][jj] = vd.load(lb, d0 + jj * PB);
+          const unsigned r0 = (unsigned)(kn - k0) * NB * PB;
 #pragma unroll
           for (int r = 0; r < NB; ++r) {
             if (VIN) {
-              l0[j][r] = v[r0 + r * P];
+              l0[j][r] = vv.load(lb, r0 + r * PB);
             } else {
-              l0[j][r] = yin[r0 + r * P];
-              if (NEEDZ) l1[j][r] = zin[r0 + r * P];
+              l0[j][r] = vy.load(lb, r0 + r * PB);
+              if (NEEDZ) l1[j][r] = vz.load(lb, r0 + r * PB);
             }
           }
         }
         double wv[NB];
-        double mPSI[even_up(NU * NX)], mK[even_up(NU * NX)], mA[even_up(NX * NX)], mB[even_up(NX * NU)],
-            mLO[even_up(NB)], mHI[even_up(NB)];
-        lds_block(rf + LF.PSI, mPSI);
-        lds_block(rf + LF.K, mK);
-        lds_block(rf + LF.A, mA);
-        lds_block(rf + LF.B, mB);
-        lds_block(rf + LF.LO, mLO);
-        lds_block(rf + LF.HI, mHI);
+        {
+          double uacc[NU], xn[NX];
 #pragma unroll
-        for (int jj = 0; jj < NU; ++jj) {
-          double a = d[jj];
+          for (int jj = 0; jj < NU; ++jj) uacc[jj] = d[jj];
+          lds_matvec_acc<NU, NX, false>(rf + LF.PSI, t, uacc);    // d0 + Psi t_in
+          lds_matvec_acc<NU, NX, false>(rf + LF.K, x, uacc);      //      + K x
 #pragma unroll
-          for (int i = 0; i < NX; ++i) a = fma(mPSI[jj * NX + i], t[i], a);
+          for (int jj = 0; jj < NU; ++jj) wv[jj] = -uacc[jj];     // u = -(...)
+          double uu[NU];
 #pragma unroll
-          for (int i = 0; i < NX; ++i) a = fma(mK[jj * NX + i], x[i], a);
-          wv[jj] = -a;
-        }
+          for (int jj = 0; jj < NU; ++jj) uu[jj] = wv[jj];
 #pragma unroll
-        for (int i = 0; i < NX; ++i) {
-          double a = 0.0;
+          for (int i = 0; i < NX; ++i) xn[i] = 0.0;
+          lds_matvec_acc<NX, NX, false>(rf + LF.A, x, xn);        // x+ = A x
+          lds_matvec_acc<NX, NU, false>(rf + LF.B, uu, xn);       //      + B u
 #pragma unroll
-          for (int l = 0; l < NX; ++l) a = fma(mA[i * NX + l], x[l], a);
-#pragma unroll
-          for (int jj = 0; jj < NU; ++jj) a = fma(mB[i * NU + jj], wv[jj], a);
-          wv[NU + i] = a;
+          for (int i = 0; i < NX; ++i) wv[NU + i] = xn[i];
         }
 #pragma unroll
         for (int i = 0; i < NX; ++i) x[i] = wv[NU + i];
-        const size_t r0 = (size_t)k * NB * P + col;
+        // Scheduling-region boundaries: one stage as a single huge region makes the scheduler
+        // fall back to its minimum-register order (every LDS read waited for immediately);
+        // split into rollout | row | row | ... each region gets a latency-aware schedule.
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned r0 = (unsigned)(k - k0) * NB * PB;
 #pragma unroll
         for (int r = 0; r < NB; ++r) {
-          const double l = mLO[r], h = mHI[r];
+          const double l = rf[LF.LO + r], h = rf[LF.HI + r];
           double zo, yo;                       // state before this z-update
           if (VIN) {
             zo = fmin(fmax(c0[r], l), h);
@@ -704,7 +791,7 @@ __global__ __launch_bounds__(XB_THREADS) void xfz_kernel(
           double wh = wv[r];
           if (RELAX) wh = fma(alpha, wv[r], (1.0 - alpha) * zo);
           const double vn = wh + yo;
-          if (active) v[r0 + r * P] = vn;
+          if (st) vv.store(vn, lb, r0 + r * PB);
           if (RESID) {
             const double zn = fmin(fmax(vn, l), h);
             const double yn = vn - zn;
@@ -715,12 +802,13 @@ __global__ __launch_bounds__(XB_THREADS) void xfz_kernel(
             a_z = fma(zn, zn, a_z);
             a_y = fma(yn, yn, a_y);
           }
+          if (r % 3 == 2) __builtin_amdgcn_sched_barrier(0);
         }
         __builtin_amdgcn_sched_barrier(0);   // see xb_kernel
       }
     }
   }
-  if (RESID && active) {
+  if (RESID) {
     const size_t o = (size_t)s * 5 * P + col;
     part[o + 0 * P] = a_r;
     part[o + 1 * P] = a_s;

@@ -181,6 +181,34 @@ def cw_rendezvous(N: int = 1000, batch: int = 1, seed0: int = SEED0,
                    name=f"cw_rendezvous_N{N}_b{batch}")
 
 
+def cw_formation(N: int = 1000, batch: int = 1, seed0: int = SEED0, u_max: float = 0.2) -> Problem:
+    """BASELINE.json configs[4] shape (n = 12, m = 6): two spacecraft in Clohessy-Wiltshire
+    relative motion about the same reference orbit, each with its own thrust box, coupled through
+    the cost: the stage and terminal weights penalise each craft's state AND their separation, so
+    Q and QN are full 12 x 12 matrices (block [[Q1+Qr, -Qr], [-Qr, Q2+Qr]])."""
+    dt = 2.0 * np.pi / N
+    A1, B1 = cw_matrices(dt)
+    A = np.block([[A1, np.zeros((6, 6))], [np.zeros((6, 6)), A1]])
+    B = np.block([[B1, np.zeros((6, 3))], [np.zeros((6, 3)), B1]])
+    q1 = np.diag([1.0, 1.0, 1.0, 0.1, 0.1, 0.1]) * dt
+    qr = np.diag([2.0, 2.0, 2.0, 0.2, 0.2, 0.2]) * dt
+    Q = np.block([[q1 + qr, -qr], [-qr, q1 + qr]])
+    t1 = np.diag([50.0, 50.0, 50.0, 20.0, 20.0, 20.0])
+    tr = np.diag([25.0, 25.0, 25.0, 10.0, 10.0, 10.0])
+    QN = np.block([[t1 + tr, -tr], [-tr, t1 + tr]])
+    R = np.eye(6) * dt
+    box = np.array([0.3, 2.0, 1.0, 0.1, 0.1, 0.1] * 2)
+    x0 = np.empty((batch, 12))
+    for i in range(batch):
+        rng = np.random.default_rng(seed0 + i)
+        x0[i] = rng.uniform(-box, box)
+    inf = np.inf
+    lo = np.array([-u_max] * 6 + [-inf] * 12)
+    hi = np.array([u_max] * 6 + [inf] * 12)
+    return Problem(N=N, A=A, B=B, Q=Q, R=R, QN=QN, x0=x0, lo=lo, hi=hi,
+                   name=f"cw_formation_N{N}_b{batch}")
+
+
 def random_ltv(N: int, n: int, m: int, batch: int, seed: int = SEED0,
                with_q: bool = True, state_bounds: bool = True) -> Problem:
     """Random stable-ish time-varying problem with full weights, per-stage

@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=4096, help="QPs per GPU")
     ap.add_argument("--horizon", type=int, default=1000)
+    ap.add_argument("--workload", choices=["cw_rendezvous", "cw_formation"], default="cw_rendezvous",
+                    help="cw_rendezvous = configs[1..3] (n=6, m=3, the metric's workload); cw_formation = configs[4]'s "
+                         "shape (n=12, m=6) in fp64 -- a side measurement, never the reported metric's config")
     ap.add_argument("--segments", type=int, default=0)
     ap.add_argument("--zrows", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -137,7 +140,8 @@ def main():
     # global problem = batch * world QPs; this rank's contiguous shard
     gbatch = a.batch * world
     lo_i, hi_i = pkg.shard_bounds(gbatch, world, rank)
-    full = pkg.cw_rendezvous(N=a.horizon, batch=hi_i - lo_i, seed0=pkg.SEED0 + lo_i)
+    make = pkg.cw_rendezvous if a.workload == "cw_rendezvous" else pkg.cw_formation
+    full = make(N=a.horizon, batch=hi_i - lo_i, seed0=pkg.SEED0 + lo_i)
     opt = pkg.Options(rho=0.05, check_interval=1, segments=a.segments, zrows=a.zrows, device=dev_index)
     solver = pkg.Solver(full, opt)
     geo = solver.geometry()
@@ -167,12 +171,12 @@ def main():
     b_xfz = 8.0 * m_ / (n_ + m_) + 16.0          # d read + v read + v+ written
     xfz_ms = prof["xfz_ms"]
     achieved = b_xfz * elems / (xfz_ms * 1e-3) / 1e9
-    roofline = {"kernel": "xfz_kernel<6,3,RESID=true,RELAX=false,VIN=true> (forward rollout fused with z-update + dual "
+    roofline = {"kernel": f"xfz_kernel<{n_},{m_},RESID=true,RELAX=false,VIN=true> (forward rollout fused with z-update + dual "
                           "ascent + residual partials, state in v-form)",
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                 "bytes_per_launch": b_xfz * elems, "bytes_per_element": b_xfz, "avg_launch_ms": xfz_ms}
-    if (a.batch, a.horizon) == (4096, 1000):      # the stored PMC run is of this workload only
+    if (a.batch, a.horizon, a.workload) == (4096, 1000, "cw_rendezvous"):   # the stored PMC run is of this workload only
         tr, src = pmc_traffic("xfz_kernel<6, 3, true, false, true>")
         roofline["traffic"] = tr
         if src:
@@ -207,9 +211,12 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"configs[2]: batch of {a.batch} independent N={a.horizon} n=6 m=3 "
-                                   f"Clohessy-Wiltshire QPs per GPU, residuals every iteration",
-                       "N": a.horizon, "n": 6, "m": 3, "batch_per_gpu": a.batch, "global_batch": gbatch,
+            "config": {"workload": (f"configs[2]: batch of {a.batch} independent N={a.horizon} n=6 m=3 "
+                                    f"Clohessy-Wiltshire QPs per GPU, residuals every iteration")
+                       if a.workload == "cw_rendezvous" else
+                       (f"SIDE MEASUREMENT, configs[4] shape in fp64: batch of {a.batch} N={a.horizon} n=12 m=6 "
+                        f"two-craft Clohessy-Wiltshire QPs per GPU, residuals every iteration"),
+                       "N": a.horizon, "n": n_, "m": m_, "batch_per_gpu": a.batch, "global_batch": gbatch,
                        "rho": 0.05, "sharding": f"batch/{world}, no collective in the iteration",
                        **geo},
             "roofline": roofline,

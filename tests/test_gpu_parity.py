@@ -42,6 +42,7 @@ CASES = [
     # segments longer than one LDS record chunk (several refills per segment)
     (lambda: pkg.random_ltv(N=40, n=12, m=6, batch=3, seed=17), 0.4, 2),
     (lambda: pkg.cw_rendezvous(N=200, batch=70), 0.05, 2),
+    (lambda: pkg.cw_formation(N=120, batch=66), 0.05, 0),       # configs[4] shape, full Q / QN
     # degenerate horizons
     (lambda: pkg.random_ltv(N=1, n=4, m=2, batch=3, seed=18), 0.3, 0),
     (lambda: pkg.random_ltv(N=2, n=6, m=3, batch=2, seed=19), 0.3, 0),
@@ -106,7 +107,7 @@ def test_zdual_kernel(gpu, alpha, resid):
 
 
 @pytest.mark.parametrize("flags", [0, 2], ids=["fused", "unfused"])
-@pytest.mark.parametrize("idx", [0, 1, 3, 5, 7, 9, 15, 16, 17, 19])
+@pytest.mark.parametrize("idx", [0, 1, 3, 5, 7, 9, 15, 16, 17, 18, 20])
 def test_iterate_parity(gpu, idx, flags):
     """T4: iterates of the full loop vs the C oracle after 1, 2, 10, 40 iterations,
     on the default fused path (xb, xscan, xfz) and on the ADMM_FLAG_UNFUSED path
