@@ -24,12 +24,16 @@ namespace admm {
 #define ADMM_XB_THREADS 256
 #endif
 #ifndef ADMM_XB_PREFETCH
-#define ADMM_XB_PREFETCH 1
+#define ADMM_XB_PREFETCH 0      // 0 = by block size (prefetch_depth below)
 #endif
 constexpr int XB_THREADS = ADMM_XB_THREADS;   // x-update workgroup: 4 waves = 256 QPs of one segment
 constexpr int Z_THREADS = 256;    // z/dual workgroup: 256 lanes x 2 QPs = 512 columns
 constexpr int T_TILE = 32;        // transpose tile
-constexpr int XB_PREFETCH = ADMM_XB_PREFETCH;    // stages of operand prefetch in xb / xfz (register ring depth)
+// Stages of operand prefetch in xb / xfz (register ring depth).  Measured at n = 6, m = 3:
+// 1 -> 4721, 2 -> 4844, 3 -> 4861 iterations/s; larger blocks get a shallower ring (registers).
+constexpr int prefetch_depth(int nb) {
+  return ADMM_XB_PREFETCH > 0 ? ADMM_XB_PREFETCH : (nb <= 9 ? 3 : (nb <= 12 ? 2 : 1));
+}
 
 // The x kernels run at 1-2 waves per SIMD (grid size and the LDS record slab decide that, not
 // registers).  Saying so lets the scheduler spend registers on instruction-level parallelism:
@@ -42,11 +46,11 @@ constexpr int XB_PREFETCH = ADMM_XB_PREFETCH;    // stages of operand prefetch i
 
 // Stage records (per-stage matrices + box, shared by the batch) are staged into LDS in
 // chunks of this many stages: <= 64 KiB per workgroup (two workgroups per CU still fit), a
-// multiple of XB_PREFETCH so that ring slots stay aligned across refills.
-constexpr int stage_chunk(int rec_doubles) {
+// multiple of the prefetch depth so that ring slots stay aligned across refills.
+constexpr int stage_chunk(int rec_doubles, int pf) {
   int ch = 8192 / rec_doubles;
-  ch = (ch / XB_PREFETCH) * XB_PREFETCH;
-  if (ch < XB_PREFETCH) ch = XB_PREFETCH;
+  ch = (ch / pf) * pf;
+  if (ch < pf) ch = pf;
   if (ch > 128) ch = 128;
   return ch;
 }
@@ -204,8 +208,8 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_X_OCCUPANCY void xb_kernel(
   constexpr int NB = NX + NU;
   constexpr RecBLayout LB = rec_b_layout(NX, NU);
   constexpr int RB = LB.SIZE;
-  constexpr int PF = XB_PREFETCH;
-  constexpr int CH = stage_chunk(RB);            // stages whose records are staged in LDS at once
+  constexpr int PF = prefetch_depth(NB);
+  constexpr int CH = stage_chunk(RB, PF);        // stages whose records are staged in LDS at once
   __shared__ __attribute__((aligned(16))) double rec[CH * RB];
 
   // No early return (every wave must reach the barriers) and no store predicate: lanes past the
@@ -664,8 +668,8 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_X_OCCUPANCY void xfz_kernel(
   constexpr RecFLayout LF = rec_f_layout(NX, NU);
   constexpr int RF = LF.SIZE;
   constexpr bool NEEDZ = RESID || RELAX;
-  constexpr int PF = XB_PREFETCH;
-  constexpr int CH = stage_chunk(RF);
+  constexpr int PF = prefetch_depth(NB);
+  constexpr int CH = stage_chunk(RF, PF);
   __shared__ __attribute__((aligned(16))) double rec[CH * RF];
 
   const int col_raw = blockIdx.x * XB_THREADS + threadIdx.x;
