@@ -203,6 +203,27 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt10 = float(t.item())
 
+    # iterations-to-epsilon (second half of BASELINE.json's metric; "vs MATLAB" -> vs the CPU oracle):
+    # a full admm_solve of this rank's shard to eps_abs = eps_rel = 1e-6, stop test every 10 iterations.
+    solver.close()
+    sopt = pkg.Options(rho=0.05, eps_abs=1e-6, eps_rel=1e-6, max_iter=4000, check_interval=10,
+                       segments=a.segments, zrows=a.zrows, device=dev_index)
+    solver = pkg.Solver(full, sopt)
+    info = solver.solve()
+    iters_to_eps = {"eps_abs": 1e-6, "eps_rel": 1e-6, "check_interval": 10, "rho": 0.05,
+                    "batch_iterations_run": int(info.iters_run), "converged": int(info.n_converged),
+                    "batch": int(full.batch), "per_qp_median": float(np.median(info.iters)),
+                    "per_qp_max": int(info.iters.max()), "solve_ms": float(info.solve_ms)}
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle_c
+        ns = min(64, full.batch)
+        ref = oracle_c.solve(full.slice(0, ns), rho=0.05, eps_abs=1e-6, eps_rel=1e-6, max_iter=4000, check_interval=10)
+        iters_to_eps["oracle_sample"] = {"qps": ns, "per_qp_iters_equal": int((ref["iters"] == info.iters[:ns]).sum()),
+                                         "oracle_median": float(np.median(ref["iters"])), "oracle_max": int(ref["iters"].max()),
+                                         "gpu_median_same_qps": float(np.median(info.iters[:ns])),
+                                         "gpu_max_same_qps": int(info.iters[:ns].max())}
+
     if rank == 0:
         out = {
             "metric": "ADMM iterations/sec (fp64) at N=1000 n=6 batch=4096",
@@ -227,6 +248,7 @@ def main():
                            "xb_GBs": xb_gbs, "xb_bytes_per_element": b_xb,
                            "iteration_bytes_per_element": b_iter,
                            "iteration_GBs": b_iter * elems / (ms_per_step * 1e-3) / 1e9},
+            "iters_to_eps": iters_to_eps,
             "check_interval_10": {"batch_iterations_per_s": a.steps / dt10,
                                   "QP_iterations_per_s": gbatch * a.steps / dt10},
         }
