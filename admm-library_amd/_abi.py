@@ -12,7 +12,7 @@ import numpy as np
 
 from .problems import Problem
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 ADMM_OK = 0
 STATUS_NAMES = {0: "ADMM_OK", 1: "ADMM_ERR_INVALID", 2: "ADMM_ERR_UNSUPPORTED",
@@ -40,12 +40,14 @@ class COptions(C.Structure):
     _fields_ = [("rho", C.c_double), ("alpha", C.c_double), ("eps_abs", C.c_double),
                 ("eps_rel", C.c_double), ("max_iter", C.c_int32), ("check_interval", C.c_int32),
                 ("segments", C.c_int32), ("device", C.c_int32), ("zrows", C.c_int32),
-                ("flags", C.c_int32)]
+                ("flags", C.c_int32), ("adapt_interval", C.c_int32), ("adapt_max", C.c_int32),
+                ("adapt_mu", C.c_double), ("adapt_tau", C.c_double)]
 
 
 class CInfo(C.Structure):
     _fields_ = [("iters_run", C.c_int32), ("n_converged", C.c_int32),
-                ("max_r", C.c_double), ("max_s", C.c_double), ("solve_ms", C.c_double)]
+                ("max_r", C.c_double), ("max_s", C.c_double), ("solve_ms", C.c_double),
+                ("rho", C.c_double), ("rho_updates", C.c_int32), ("reserved", C.c_int32)]
 
 
 def dptr(a):
@@ -88,7 +90,9 @@ def marshal_problem(p: Problem):
 
 
 def make_options(rho=0.1, alpha=1.0, eps_abs=1e-6, eps_rel=1e-6, max_iter=4000,
-                 check_interval=10, segments=0, device=-1, zrows=0, flags=0) -> COptions:
+                 check_interval=10, segments=0, device=-1, zrows=0, flags=0,
+                 adapt_interval=0, adapt_max=16, adapt_mu=10.0, adapt_tau=2.0) -> COptions:
     return COptions(rho=rho, alpha=alpha, eps_abs=eps_abs, eps_rel=eps_rel,
                     max_iter=max_iter, check_interval=check_interval, segments=segments,
-                    device=device, zrows=zrows, flags=flags)
+                    device=device, zrows=zrows, flags=flags, adapt_interval=adapt_interval,
+                    adapt_max=adapt_max, adapt_mu=adapt_mu, adapt_tau=adapt_tau)

@@ -42,6 +42,10 @@ struct admm_handle {
   bool has_q = false;
   admm_options opt{};
   admm::Factor fac;
+  // host copy of the shared problem data (the caller's pointers are never kept): admm_set_rho refactors from it
+  std::vector<double> pA, pB, pQ, pR, pQN, plo, phi;
+  int time_varying = 0, stage_bounds = 0;
+  int rho_updates = 0;
   hipStream_t stream = nullptr;
   // batch-minor state and work buffers
   double *w = nullptr, *z = nullptr, *y = nullptr, *v = nullptr, *q = nullptr, *x0 = nullptr;
@@ -281,6 +285,13 @@ int validate_options(const admm_options* o) {
   if (o->max_iter < 1) return fail(ADMM_ERR_INVALID, "max_iter must be >= 1");
   if (o->check_interval < 1) return fail(ADMM_ERR_INVALID, "check_interval must be >= 1");
   if (o->segments < 0 || o->zrows < 0) return fail(ADMM_ERR_INVALID, "segments / zrows must be >= 0");
+  if (o->adapt_interval < 0 || o->adapt_max < 0) return fail(ADMM_ERR_INVALID, "adapt_interval / adapt_max must be >= 0");
+  if (o->adapt_interval > 0) {
+    if (o->adapt_interval % o->check_interval != 0)
+      return fail(ADMM_ERR_INVALID, "adapt_interval must be a multiple of check_interval");
+    if (!(o->adapt_mu > 1.0) || !(o->adapt_tau > 1.0) || !std::isfinite(o->adapt_mu) || !std::isfinite(o->adapt_tau))
+      return fail(ADMM_ERR_INVALID, "adapt_mu and adapt_tau must be finite and > 1");
+  }
   return ADMM_OK;
 }
 
@@ -365,6 +376,10 @@ void admm_default_options(admm_options* o) {
   o->device = -1;
   o->zrows = 0;
   o->flags = ADMM_FLAG_NONE;
+  o->adapt_interval = 0;
+  o->adapt_max = 16;
+  o->adapt_mu = 10.0;
+  o->adapt_tau = 2.0;
 }
 
 const char* admm_last_error(void) { return g_err.c_str(); }
@@ -475,6 +490,18 @@ int admm_setup(admm_handle** out, const admm_problem* p, const admm_options* o_i
   rc = admm::factorise(*p, o.rho, h->S, h->fac, err);
   if (rc) { release(h); return fail(rc, err); }
   h->S = h->fac.S;
+  {  // host copy of the shared problem data, for admm_set_rho / the adaptive rule
+    const size_t nst = p->time_varying ? (size_t)p->N : 1, nbd = (size_t)h->nb * (p->stage_bounds ? p->N : 1);
+    h->pA.assign(p->A, p->A + nst * p->n * p->n);
+    h->pB.assign(p->B, p->B + nst * p->n * p->m);
+    h->pQ.assign(p->Q, p->Q + (size_t)p->n * p->n);
+    h->pR.assign(p->R, p->R + (size_t)p->m * p->m);
+    h->pQN.assign(p->QN, p->QN + (size_t)p->n * p->n);
+    h->plo.assign(p->lo, p->lo + nbd);
+    h->phi.assign(p->hi, p->hi + nbd);
+    h->time_varying = p->time_varying;
+    h->stage_bounds = p->stage_bounds;
+  }
   {  // the x kernels address one segment of an array through a 32-bit buffer descriptor
     int longest = 0;
     for (int s = 0; s < h->S; ++s) longest = std::max(longest, h->fac.seg_start[s + 1] - h->fac.seg_start[s]);
@@ -574,6 +601,50 @@ int admm_update_instances(admm_handle* h, const double* x0, const double* q) {
     if ((rc = upload_transposed(h, q, h->q, h->L))) return rc;
   }
   return ADMM_OK;
+}
+
+// Refactor for a new rho, re-upload the records, rescale the scaled dual.  The state is
+// switched to (z, y) form so that y *= rho_old / rho_new is applied to the very numbers the
+// iteration produced (bit-identical to the oracle); the next iteration reads z, y directly.
+static int set_rho_internal(admm_handle* h, double rho_new) {
+  if (!(rho_new > 0.0) || !std::isfinite(rho_new)) return fail(ADMM_ERR_INVALID, "rho must be positive and finite");
+  if (rho_new == h->opt.rho) return ADMM_OK;
+  admm_problem p{};
+  p.N = h->N; p.n = h->n; p.m = h->m; p.batch = h->batch;
+  p.time_varying = h->time_varying; p.stage_bounds = h->stage_bounds;
+  p.A = h->pA.data(); p.B = h->pB.data(); p.Q = h->pQ.data(); p.R = h->pR.data(); p.QN = h->pQN.data();
+  p.lo = h->plo.data(); p.hi = h->phi.data();
+  admm::Factor f;
+  std::string err;
+  int rc = admm::factorise(p, rho_new, h->S, f, err);
+  if (rc) return fail(rc, err);
+  if (f.recB.size() != h->fac.recB.size() || f.scanWp.size() != h->fac.scanWp.size())
+    return fail(ADMM_ERR_NUMERIC, "internal: record sizes changed on refactor");
+  if ((rc = ensure_zy(h))) return rc;
+  {
+    const double c = h->opt.rho / rho_new;
+    const size_t count2 = (size_t)h->L * h->pitch / 2;      // pitch is even
+    hipLaunchKernelGGL(admm::scale_kernel, dim3(2048), dim3(256), 0, h->stream, h->y, c, count2);
+    HIP_TRY(hipGetLastError());
+  }
+  h->zy_valid = true;
+  h->v_valid = false;
+  HIP_TRY(hipStreamSynchronize(h->stream));                // kernels of the old rho are done before the records change
+  h->fac = std::move(f);
+  HIP_TRY(hipMemcpy(h->recB, h->fac.recB.data(), sizeof(double) * h->fac.recB.size(), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->recF, h->fac.recF.data(), sizeof(double) * h->fac.recF.size(), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->recS, h->fac.recS.data(), sizeof(double) * h->fac.recS.size(), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->scanWp, h->fac.scanWp.data(), sizeof(double) * h->fac.scanWp.size(), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->scan_range, h->fac.scanRange.data(), sizeof(int32_t) * h->fac.scanRange.size(), hipMemcpyHostToDevice));
+  h->opt.rho = rho_new;
+  destroy_graph(h);                                        // rho is a captured kernel argument
+  return ADMM_OK;
+}
+
+int admm_set_rho(admm_handle* h, double rho) {
+  if (!h) return fail(ADMM_ERR_INVALID, "NULL handle");
+  HIP_TRY(hipSetDevice(h->device));
+  return set_rho_internal(h, rho);
 }
 
 int admm_set_state(admm_handle* h, const double* w, const double* z, const double* y) {
@@ -683,6 +754,7 @@ int admm_solve(admm_handle* h, const double* z0, const double* y0, admm_info* in
   }
   const bool use_graph = !(h->opt.flags & ADMM_FLAG_NO_GRAPH);
   if (use_graph && !h->graph_exec[0] && (rc = capture_iterations(h))) return rc;
+  h->rho_updates = 0;
   int it = 0, nconv = 0;
   const int ci = h->opt.check_interval;
   for (it = 1; it <= h->opt.max_iter; ++it) {
@@ -702,6 +774,26 @@ int admm_solve(admm_handle* h, const double* z0, const double* y0, admm_info* in
     nconv = *h->h_nconv;
     h->resid_valid = true;
     if (nconv >= h->batch) break;
+    // adaptive rho: batch-level residual balancing over the unconverged QPs
+    if (h->opt.adapt_interval > 0 && it % h->opt.adapt_interval == 0 && h->rho_updates < h->opt.adapt_max &&
+        it < h->opt.max_iter) {
+      std::vector<double> rs(2 * P);
+      std::vector<int> st(P);
+      HIP_TRY(hipMemcpy(rs.data(), h->resid, sizeof(double) * 2 * P, hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(st.data(), h->status, sizeof(int) * P, hipMemcpyDeviceToHost));
+      double R = 0.0, S = 0.0;
+      for (int b = 0; b < h->batch; ++b)
+        if (!st[b]) { R += rs[b] * rs[b]; S += rs[P + b] * rs[P + b]; }
+      const double mu2 = h->opt.adapt_mu * h->opt.adapt_mu;
+      double rho_new = h->opt.rho;
+      if (R > mu2 * S) rho_new = h->opt.rho * h->opt.adapt_tau;
+      else if (S > mu2 * R) rho_new = h->opt.rho / h->opt.adapt_tau;
+      if (rho_new != h->opt.rho) {
+        if ((rc = set_rho_internal(h, rho_new))) return rc;
+        ++h->rho_updates;
+        if (use_graph && (rc = capture_iterations(h))) return rc;
+      }
+    }
   }
   if (it > h->opt.max_iter) it = h->opt.max_iter;
   HIP_TRY(hipGetLastError());
@@ -720,6 +812,9 @@ int admm_solve(admm_handle* h, const double* z0, const double* y0, admm_info* in
     info->max_r = mr;
     info->max_s = ms;
     info->solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    info->rho = h->opt.rho;
+    info->rho_updates = h->rho_updates;
+    info->reserved = 0;
   }
   return ADMM_OK;
 }

@@ -822,6 +822,18 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_X_OCCUPANCY void xfz_kernel(
   }
 }
 
+// y *= c over the whole array (rho change: the scaled dual y = lambda / rho is rescaled so that
+// the multiplier lambda is unchanged).  16-byte accesses, grid-stride.
+__global__ __launch_bounds__(256) void scale_kernel(double* __restrict__ y, double c, size_t count2) {
+  double2* y2 = reinterpret_cast<double2*>(y);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count2; i += (size_t)gridDim.x * 256) {
+    double2 v = y2[i];
+    v.x *= c;
+    v.y *= c;
+    y2[i] = v;
+  }
+}
+
 // v -> (z, y): z = clip(v), y = v - z.  Read-out / mode switches only.  One lane =
 // two adjacent QPs, blockIdx.y = row chunk (same geometry as zdual_kernel).
 __global__ __launch_bounds__(Z_THREADS) void v_to_zy_kernel(

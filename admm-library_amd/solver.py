@@ -44,6 +44,7 @@ _SIGNATURES = {
     "admm_setup": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(CProblem), C.POINTER(COptions)]),
     "admm_update_instances": (C.c_int, [C.c_void_p, c_double_p, c_double_p]),
     "admm_set_state": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p]),
+    "admm_set_rho": (C.c_int, [C.c_void_p, C.c_double]),
     "admm_solve": (C.c_int, [C.c_void_p, c_double_p, c_double_p, C.POINTER(CInfo)]),
     "admm_iterate": (C.c_int, [C.c_void_p, C.c_int32]),
     "admm_run": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
@@ -110,6 +111,10 @@ class Options:
     device: int = -1
     zrows: int = 0
     flags: int = 0
+    adapt_interval: int = 0
+    adapt_max: int = 16
+    adapt_mu: float = 10.0
+    adapt_tau: float = 2.0
 
     def to_c(self) -> COptions:
         return _abi.make_options(**dataclasses.asdict(self))
@@ -122,6 +127,8 @@ class SolveInfo:
     max_r: float
     max_s: float
     solve_ms: float
+    rho: float
+    rho_updates: int
     iters: np.ndarray
     status: np.ndarray
     r: np.ndarray
@@ -175,6 +182,9 @@ class Solver:
         q = self._vec(q)
         _check(self._lib, self._lib.admm_update_instances(self._h, dptr(x0), dptr(q)))
 
+    def set_rho(self, rho: float):
+        _check(self._lib, self._lib.admm_set_rho(self._h, float(rho)))
+
     def set_state(self, w=None, z=None, y=None):
         w, z, y = self._vec(w), self._vec(z), self._vec(y)
         _check(self._lib, self._lib.admm_set_state(self._h, dptr(w), dptr(z), dptr(y)))
@@ -188,7 +198,8 @@ class Solver:
         r = np.empty(self.batch)
         s = np.empty(self.batch)
         _check(self._lib, self._lib.admm_get_info(self._h, iptr(iters), iptr(status), dptr(r), dptr(s)))
-        return SolveInfo(ci.iters_run, ci.n_converged, ci.max_r, ci.max_s, ci.solve_ms, iters, status, r, s)
+        return SolveInfo(ci.iters_run, ci.n_converged, ci.max_r, ci.max_s, ci.solve_ms, ci.rho, ci.rho_updates,
+                         iters, status, r, s)
 
     def iterate(self, iters: int, sync: bool = True):
         _check(self._lib, self._lib.admm_iterate(self._h, int(iters)))

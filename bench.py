@@ -204,25 +204,37 @@ def main():
         dt10 = float(t.item())
 
     # iterations-to-epsilon (second half of BASELINE.json's metric; "vs MATLAB" -> vs the CPU oracle):
-    # a full admm_solve of this rank's shard to eps_abs = eps_rel = 1e-6, stop test every 10 iterations.
+    # a full admm_solve of this rank's shard to eps_abs = eps_rel = 1e-6, stop test every 10 iterations,
+    # once with fixed rho and once with the batch-level adaptive rule.
     solver.close()
-    sopt = pkg.Options(rho=0.05, eps_abs=1e-6, eps_rel=1e-6, max_iter=4000, check_interval=10,
-                       segments=a.segments, zrows=a.zrows, device=dev_index)
-    solver = pkg.Solver(full, sopt)
-    info = solver.solve()
-    iters_to_eps = {"eps_abs": 1e-6, "eps_rel": 1e-6, "check_interval": 10, "rho": 0.05,
-                    "batch_iterations_run": int(info.iters_run), "converged": int(info.n_converged),
-                    "batch": int(full.batch), "per_qp_median": float(np.median(info.iters)),
-                    "per_qp_max": int(info.iters.max()), "solve_ms": float(info.solve_ms)}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import oracle_c
-        ns = min(64, full.batch)
-        ref = oracle_c.solve(full.slice(0, ns), rho=0.05, eps_abs=1e-6, eps_rel=1e-6, max_iter=4000, check_interval=10)
-        iters_to_eps["oracle_sample"] = {"qps": ns, "per_qp_iters_equal": int((ref["iters"] == info.iters[:ns]).sum()),
-                                         "oracle_median": float(np.median(ref["iters"])), "oracle_max": int(ref["iters"].max()),
-                                         "gpu_median_same_qps": float(np.median(info.iters[:ns])),
-                                         "gpu_max_same_qps": int(info.iters[:ns].max())}
+    else:
+        oracle_c = None
+
+    def to_eps(**adapt):
+        base = dict(rho=0.05, eps_abs=1e-6, eps_rel=1e-6, max_iter=4000, check_interval=10)
+        with pkg.Solver(full, pkg.Options(segments=a.segments, zrows=a.zrows, device=dev_index, **base, **adapt)) as sv:
+            info = sv.solve()
+        out = {**base, **adapt, "batch_iterations_run": int(info.iters_run), "converged": int(info.n_converged),
+               "batch": int(full.batch), "per_qp_median": float(np.median(info.iters)),
+               "per_qp_max": int(info.iters.max()), "solve_ms": float(info.solve_ms),
+               "rho_final": float(info.rho), "rho_updates": int(info.rho_updates)}
+        if oracle_c is not None:
+            ns = min(64, full.batch)     # the rule is batch-level, so the sample is solved as its own batch on both sides
+            sub = full.slice(0, ns)
+            ref = oracle_c.solve(sub, **base, **adapt)
+            with pkg.Solver(sub, pkg.Options(device=dev_index, **base, **adapt)) as sv:
+                gi = sv.solve()
+            out["oracle_sample"] = {"qps": ns, "per_qp_iters_equal": int((ref["iters"] == gi.iters).sum()),
+                                    "oracle_iterations_run": int(ref["iters_run"]), "gpu_iterations_run": int(gi.iters_run),
+                                    "oracle_rho_final": float(ref["rho"]), "gpu_rho_final": float(gi.rho)}
+        return out
+
+    iters_to_eps = to_eps()
+    iters_to_eps_adaptive = to_eps(adapt_interval=50, adapt_mu=10.0, adapt_tau=2.0)
+    solver = None
 
     if rank == 0:
         out = {
@@ -249,13 +261,15 @@ def main():
                            "iteration_bytes_per_element": b_iter,
                            "iteration_GBs": b_iter * elems / (ms_per_step * 1e-3) / 1e9},
             "iters_to_eps": iters_to_eps,
+            "iters_to_eps_adaptive_rho": iters_to_eps_adaptive,
             "check_interval_10": {"batch_iterations_per_s": a.steps / dt10,
                                   "QP_iterations_per_s": gbatch * a.steps / dt10},
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.horizon, a.cpu_seconds)
         print(json.dumps(out))
-    solver.close()
+    if solver is not None:
+        solver.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

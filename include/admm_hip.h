@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ADMM_HIP_ABI_VERSION 1
+#define ADMM_HIP_ABI_VERSION 2
 
 typedef enum admm_status {
   ADMM_OK = 0,
@@ -76,6 +76,16 @@ typedef struct admm_options {
   int32_t device;         /* HIP device ordinal; -1 = current device */
   int32_t zrows;          /* rows per workgroup chunk in the z/dual kernel; 0 = auto */
   int32_t flags;          /* ADMM_FLAG_* */
+  /* Adaptive rho by residual balancing (Boyd et al. 2011 §3.4.1), batch-level because the KKT
+   * factor is shared by the batch.  At a checked iteration it with it % adapt_interval == 0, with
+   * R = sum r_b^2 and S = sum s_b^2 over the QPs that have not converged yet:
+   *   R > adapt_mu^2 S  ->  rho *= adapt_tau;     S > adapt_mu^2 R  ->  rho /= adapt_tau
+   * then the scaled dual is rescaled (y *= rho_old / rho_new), the KKT system is refactored on
+   * the host and the records re-uploaded.  adapt_interval = 0 disables (default). */
+  int32_t adapt_interval; /* iterations between adaptation tests; 0 = fixed rho; must be a multiple of check_interval */
+  int32_t adapt_max;      /* at most this many rho changes per admm_solve */
+  double adapt_mu;        /* > 1 */
+  double adapt_tau;       /* > 1 */
 } admm_options;
 
 #define ADMM_FLAG_NONE 0
@@ -91,11 +101,15 @@ typedef struct admm_info {
   double  max_r;          /* max over the batch of the last checked primal residual */
   double  max_s;          /* ... dual residual */
   double  solve_ms;       /* wall time of the last admm_solve (host clock) */
+  double  rho;            /* rho in force at the end of the solve */
+  int32_t rho_updates;    /* rho changes made by the adaptive rule during the solve */
+  int32_t reserved;
 } admm_info;
 
 typedef struct admm_handle admm_handle;
 
-/* Defaults: rho 0.1, alpha 1, eps 1e-6/1e-6, max_iter 4000, check_interval 10. */
+/* Defaults: rho 0.1, alpha 1, eps 1e-6/1e-6, max_iter 4000, check_interval 10, fixed rho
+ * (adapt_interval 0, adapt_max 16, adapt_mu 10, adapt_tau 2). */
 void admm_default_options(admm_options* o);
 
 /* Validate, factor the x-update's KKT system on the host (fp64 Riccati sweep),
@@ -105,6 +119,11 @@ int admm_setup(admm_handle** out, const admm_problem* p, const admm_options* o);
 /* Replace the per-instance data (x0: n*batch, q: L*batch or NULL = keep) of an
  * existing handle without refactoring. */
 int admm_update_instances(admm_handle* h, const double* x0, const double* q);
+
+/* Change rho on an existing handle: refactors the KKT system on the host, re-uploads the
+ * records and rescales the scaled dual (y *= rho_old / rho_new) so that the unscaled multiplier
+ * rho y is unchanged. */
+int admm_set_rho(admm_handle* h, double rho);
 
 /* Warm start / test hook: overwrite device state.  Any pointer may be NULL
  * (left unchanged).  Each is L*batch. */

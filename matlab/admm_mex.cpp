@@ -121,6 +121,10 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     o.segments = static_cast<int32_t>(scalar_or(O, "segments", 0));
     o.device = static_cast<int32_t>(scalar_or(O, "device", -1));
     o.flags = static_cast<int32_t>(scalar_or(O, "flags", 0));
+    o.adapt_interval = static_cast<int32_t>(scalar_or(O, "adapt_interval", o.adapt_interval));
+    o.adapt_max = static_cast<int32_t>(scalar_or(O, "adapt_max", o.adapt_max));
+    o.adapt_mu = scalar_or(O, "adapt_mu", o.adapt_mu);
+    o.adapt_tau = scalar_or(O, "adapt_tau", o.adapt_tau);
     admm_handle* h = nullptr;
     check(admm_setup(&h, &p, &o));
     remember(h, L, p.batch);
@@ -140,8 +144,11 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     if (y0 && mxGetNumberOfElements(prhs[3]) != static_cast<size_t>(d->L) * d->batch) fail("admm:input", "y0 must be L x batch");
     admm_info info;
     check(admm_solve(h, z0, y0, &info));
-    const char* names[] = {"iters_run", "n_converged", "max_r", "max_s", "solve_ms", "iters", "status", "r", "s"};
-    plhs[0] = mxCreateStructMatrix(1, 1, 9, names);
+    const char* names[] = {"iters_run", "n_converged", "max_r", "max_s", "solve_ms", "iters", "status", "r", "s",
+                           "rho", "rho_updates"};
+    plhs[0] = mxCreateStructMatrix(1, 1, 11, names);
+    mxSetField(plhs[0], 0, "rho", mxCreateDoubleScalar(info.rho));
+    mxSetField(plhs[0], 0, "rho_updates", mxCreateDoubleScalar(info.rho_updates));
     mxSetField(plhs[0], 0, "iters_run", mxCreateDoubleScalar(info.iters_run));
     mxSetField(plhs[0], 0, "n_converged", mxCreateDoubleScalar(info.n_converged));
     mxSetField(plhs[0], 0, "max_r", mxCreateDoubleScalar(info.max_r));

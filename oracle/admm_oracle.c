@@ -215,11 +215,15 @@ static void x_update_one(const admm_problem* p, const ofactor* f, const double* 
 int oracle_solve(const admm_problem* p, const admm_options* o, int32_t stop,
                  double* z, double* y, double* w,
                  int32_t* iters, int32_t* status, double* r_out, double* s_out,
-                 int32_t* iters_run, int32_t nthreads) {
+                 int32_t* iters_run, int32_t nthreads, double* rho_out, int32_t* rho_updates_out) {
   const int N = p->N, n = p->n, m = p->m, nb = n + m, batch = p->batch;
   if (n > 64 || m > 64 || N < 1 || batch < 1) return 1;
   const size_t L = (size_t)N * nb;
-  const double rho = o->rho, alpha = o->alpha;
+  double rho = o->rho;
+  const double alpha = o->alpha;
+  int n_updates = 0;
+  double* rr = (double*)calloc(batch, sizeof(double));   /* last checked r, s of every QP */
+  double* ss = (double*)calloc(batch, sizeof(double));
   ofactor f;
   if (factorise(p, rho, &f)) return 1;
   /* row-major copies of the stage dynamics */
@@ -268,14 +272,38 @@ int oracle_solve(const admm_problem* p, const admm_options* o, int32_t stop,
         const double e_dua = sqrtL * o->eps_abs + o->eps_rel * rho * sqrt(a_y);
         if (r_out) r_out[b] = r;
         if (s_out) s_out[b] = s;
+        rr[b] = r;
+        ss[b] = s;
         if (r <= e_pri && s <= e_dua && !st[b]) { st[b] = 1; itv[b] = it; }
         nconv += st[b];
       }
     }
     if (stop && check && nconv == batch) break;
+    /* adaptive rho: batch-level residual balancing over the unconverged QPs */
+    if (check && o->adapt_interval > 0 && it % o->adapt_interval == 0 && n_updates < o->adapt_max &&
+        it < o->max_iter) {
+      double R = 0.0, S = 0.0;
+      for (int b = 0; b < batch; ++b)
+        if (!st[b]) { R += rr[b] * rr[b]; S += ss[b] * ss[b]; }
+      const double mu2 = o->adapt_mu * o->adapt_mu;
+      double rho_new = rho;
+      if (R > mu2 * S) rho_new = rho * o->adapt_tau;
+      else if (S > mu2 * R) rho_new = rho / o->adapt_tau;
+      if (rho_new != rho) {
+        const double c = rho / rho_new;
+        for (size_t e = 0; e < L * (size_t)batch; ++e) y[e] *= c;
+        free(f.K); free(f.Sinv);
+        if (factorise(p, rho_new, &f)) { free(rr); free(ss); free(st); free(itv); free(AB); return 1; }
+        rho = rho_new;
+        ++n_updates;
+      }
+    }
   }
   if (it > o->max_iter) it = o->max_iter;
   if (iters_run) *iters_run = it;
+  if (rho_out) *rho_out = rho;
+  if (rho_updates_out) *rho_updates_out = n_updates;
+  free(rr); free(ss);
   if (iters) memcpy(iters, itv, sizeof(int32_t) * batch);
   if (status) memcpy(status, st, sizeof(int32_t) * batch);
   free(st); free(itv); free(AB); free(f.K); free(f.Sinv);

@@ -158,20 +158,25 @@ class Result:
     r: np.ndarray
     s: np.ndarray
     history: list
+    rho: float = 0.0
+    rho_updates: int = 0
 
 
 def solve(A, B, Q, R, QN, x0, lo, hi, N, q=None, rho=1.0, alpha=1.0,
           eps_abs=1e-6, eps_rel=1e-6, max_iter=1000, check_interval=10,
-          z0=None, y0=None, record=None, stop=True) -> Result:
+          z0=None, y0=None, record=None, stop=True,
+          adapt_interval=0, adapt_max=16, adapt_mu=10.0, adapt_tau=2.0) -> Result:
     """Run the batch loop.  All QPs iterate together until every one has met
     the stopping rule at a checked iteration (iterations that are multiples of
     ``check_interval``, and ``max_iter``), or ``max_iter`` is reached.
     ``record`` is an optional collection of iteration numbers whose (w, z, y)
     are kept in ``history``.  ``stop=False`` runs exactly max_iter iterations.
+    ``adapt_interval > 0`` enables batch-level residual balancing of rho.
     """
     x0 = np.atleast_2d(np.asarray(x0, np.float64))
     batch = x0.shape[0]
-    f = factor(A, B, Q, R, QN, rho, N)
+    R_weight = R
+    f = factor(A, B, Q, R_weight, QN, rho, N)
     n, m = f.B.shape[1], f.B.shape[2]
     nb = n + m
     L = N * nb
@@ -186,6 +191,7 @@ def solve(A, B, Q, R, QN, x0, lo, hi, N, q=None, rho=1.0, alpha=1.0,
     s = np.full(batch, np.inf)
     history = []
     it = 0
+    n_updates = 0
     for it in range(1, max_iter + 1):
         g = -rho * (z - y)
         if qq is not None:
@@ -204,8 +210,25 @@ def solve(A, B, Q, R, QN, x0, lo, hi, N, q=None, rho=1.0, alpha=1.0,
             history.append((it, w.copy(), z.copy(), y.copy()))
         if stop and check and status.all():
             break
+        if (check and adapt_interval > 0 and it % adapt_interval == 0 and n_updates < adapt_max
+                and it < max_iter):
+            Rsum = Ssum = 0.0
+            for b in range(batch):              # same summation order as the C oracle and the HIP host code
+                if not status[b]:
+                    Rsum += r[b] * r[b]
+                    Ssum += s[b] * s[b]
+            rho_new = rho
+            if Rsum > adapt_mu ** 2 * Ssum:
+                rho_new = rho * adapt_tau
+            elif Ssum > adapt_mu ** 2 * Rsum:
+                rho_new = rho / adapt_tau
+            if rho_new != rho:
+                y = y * (rho / rho_new)
+                f = factor(A, B, Q, R_weight, QN, rho_new, N)
+                rho = rho_new
+                n_updates += 1
     return Result(w=w, z=z, y=y, iters_run=it, iters=iters, status=status,
-                  r=r, s=s, history=history)
+                  r=r, s=s, history=history, rho=rho, rho_updates=n_updates)
 
 
 # ---------------------------------------------------------------------------

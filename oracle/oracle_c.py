@@ -34,7 +34,7 @@ def load():
         lib.oracle_solve.argtypes = [C.POINTER(_abi.CProblem), C.POINTER(_abi.COptions), C.c_int32,
                                      _abi.c_double_p, _abi.c_double_p, _abi.c_double_p,
                                      _abi.c_int32_p, _abi.c_int32_p, _abi.c_double_p, _abi.c_double_p,
-                                     _abi.c_int32_p, C.c_int32]
+                                     _abi.c_int32_p, C.c_int32, _abi.c_double_p, _abi.c_int32_p]
         lib.oracle_factor.restype = C.c_int
         lib.oracle_factor.argtypes = [C.POINTER(_abi.CProblem), C.c_double, _abi.c_double_p, _abi.c_double_p]
         lib.oracle_max_threads.restype = C.c_int
@@ -47,12 +47,14 @@ def max_threads() -> int:
 
 
 def solve(p: pkg.Problem, rho=0.1, alpha=1.0, eps_abs=1e-6, eps_rel=1e-6, max_iter=4000,
-          check_interval=10, z0=None, y0=None, stop=True, nthreads=0):
-    """Returns dict(w, z, y, iters_run, iters, status, r, s)."""
+          check_interval=10, z0=None, y0=None, stop=True, nthreads=0,
+          adapt_interval=0, adapt_max=16, adapt_mu=10.0, adapt_tau=2.0):
+    """Returns dict(w, z, y, iters_run, iters, status, r, s, rho, rho_updates)."""
     lib = load()
     cp, keep = _abi.marshal_problem(p)
     co = _abi.make_options(rho=rho, alpha=alpha, eps_abs=eps_abs, eps_rel=eps_rel, max_iter=max_iter,
-                           check_interval=check_interval)
+                           check_interval=check_interval, adapt_interval=adapt_interval, adapt_max=adapt_max,
+                           adapt_mu=adapt_mu, adapt_tau=adapt_tau)
     B, L = p.batch, p.L
     z = np.zeros((B, L)) if z0 is None else np.array(z0, np.float64).reshape(B, L).copy()
     y = np.zeros((B, L)) if y0 is None else np.array(y0, np.float64).reshape(B, L).copy()
@@ -62,13 +64,16 @@ def solve(p: pkg.Problem, rho=0.1, alpha=1.0, eps_abs=1e-6, eps_rel=1e-6, max_it
     r = np.full(B, np.inf)
     s = np.full(B, np.inf)
     run = C.c_int32(0)
+    rho_out = C.c_double(0.0)
+    upd = C.c_int32(0)
     rc = lib.oracle_solve(C.byref(cp), C.byref(co), int(bool(stop)), _abi.dptr(z), _abi.dptr(y), _abi.dptr(w),
                           _abi.iptr(iters), _abi.iptr(status), _abi.dptr(r), _abi.dptr(s), C.byref(run),
-                          int(nthreads))
+                          int(nthreads), C.byref(rho_out), C.byref(upd))
     del keep
     if rc != 0:
         raise RuntimeError("oracle_solve failed (bad input or S_k not SPD)")
-    return dict(w=w, z=z, y=y, iters_run=int(run.value), iters=iters, status=status, r=r, s=s)
+    return dict(w=w, z=z, y=y, iters_run=int(run.value), iters=iters, status=status, r=r, s=s,
+                rho=float(rho_out.value), rho_updates=int(upd.value))
 
 
 def factor(p: pkg.Problem, rho: float):

@@ -185,6 +185,43 @@ def test_solve_max_iter_and_unconverged(gpu):
         assert np.abs(info.r - ref["r"]).max() < 1e-10 and np.abs(info.s - ref["s"]).max() < 1e-10
 
 
+@pytest.mark.parametrize("flags", [0, 2], ids=["fused", "unfused"])
+@pytest.mark.parametrize("kw", [dict(adapt_interval=20), dict(adapt_interval=20, adapt_mu=5.0),
+                                dict(adapt_interval=50, adapt_tau=3.0, adapt_max=2)])
+def test_adaptive_rho_matches_oracle(gpu, kw, flags):
+    """batch-level residual balancing.  Same rho trajectory, same iteration
+    counts, same iterates as the oracle (the decision sums run in the same order on both sides)."""
+    p = pkg.cw_rendezvous(N=200, batch=12)
+    base = dict(rho=0.05, eps_abs=1e-6, eps_rel=1e-6, max_iter=3000, check_interval=10)
+    ref = oc.solve(p, **base, **kw)
+    assert ref["rho_updates"] >= 2
+    with pkg.Solver(p, pkg.Options(flags=flags, **base, **kw)) as s:
+        info = s.solve()
+        w, z, y = s.get()
+    assert info.iters_run == ref["iters_run"] and info.rho_updates == ref["rho_updates"]
+    assert info.rho == ref["rho"]
+    assert (np.abs(info.iters - ref["iters"]) <= base["check_interval"]).all()
+    for a, b in ((w, ref["w"]), (z, ref["z"]), (y, ref["y"])):
+        assert np.abs(a - b).max() <= TOL * max(1.0, np.abs(b).max())
+
+
+def test_set_rho_keeps_the_multiplier(gpu):
+    """admm_set_rho mid-run = refactor + y *= rho_old / rho_new (lambda = rho y unchanged)."""
+    p = pkg.random_ltv(N=30, n=6, m=3, batch=9, seed=41)
+    r1, r2 = 0.3, 0.9
+    a = oc.solve(p, rho=r1, max_iter=15, stop=False)
+    b = oc.solve(p, rho=r2, max_iter=11, stop=False, z0=a["z"], y0=a["y"] * (r1 / r2))
+    with pkg.Solver(p, pkg.Options(rho=r1)) as s:
+        s.iterate(15)
+        s.set_rho(r2)
+        _, z_mid, y_mid = s.get(False, True, True)
+        s.iterate(11)
+        w, z, y = s.get()
+    assert np.abs(z_mid - a["z"]).max() <= TOL and np.abs(y_mid - a["y"] * (r1 / r2)).max() <= TOL
+    for got, ref in ((w, b["w"]), (z, b["z"]), (y, b["y"])):
+        assert np.abs(got - ref).max() <= TOL * max(1.0, np.abs(ref).max())
+
+
 def test_update_instances(gpu):
     """New x0 on an existing handle = fresh setup with that x0."""
     p = pkg.cw_rendezvous(N=80, batch=10)

@@ -188,11 +188,12 @@ from admm_library_amd import _abi
 lib = C.CDLL({os.path.join(root, 'oracle', 'liboracle_asan.so')!r})
 p = pkg.random_ltv(N=13, n=4, m=2, batch=5, seed=3)
 cp, keep = _abi.marshal_problem(p)
-co = _abi.make_options(rho=0.3, max_iter=25, check_interval=4)
+co = _abi.make_options(rho=0.3, max_iter=60, check_interval=4, adapt_interval=8, adapt_mu=2.0)
 z = np.zeros((5, p.L)); y = np.zeros((5, p.L)); w = np.zeros((5, p.L))
 it = np.zeros(5, np.int32); st = np.zeros(5, np.int32); r = np.zeros(5); s = np.zeros(5); run = C.c_int32()
-lib.oracle_solve.argtypes = [C.POINTER(_abi.CProblem), C.POINTER(_abi.COptions), C.c_int32] + [_abi.c_double_p] * 3 + [_abi.c_int32_p] * 2 + [_abi.c_double_p] * 2 + [_abi.c_int32_p, C.c_int32]
-rc = lib.oracle_solve(C.byref(cp), C.byref(co), 1, _abi.dptr(z), _abi.dptr(y), _abi.dptr(w), _abi.iptr(it), _abi.iptr(st), _abi.dptr(r), _abi.dptr(s), C.byref(run), 2)
+lib.oracle_solve.argtypes = [C.POINTER(_abi.CProblem), C.POINTER(_abi.COptions), C.c_int32] + [_abi.c_double_p] * 3 + [_abi.c_int32_p] * 2 + [_abi.c_double_p] * 2 + [_abi.c_int32_p, C.c_int32, _abi.c_double_p, _abi.c_int32_p]
+rho = C.c_double(); upd = C.c_int32()
+rc = lib.oracle_solve(C.byref(cp), C.byref(co), 1, _abi.dptr(z), _abi.dptr(y), _abi.dptr(w), _abi.iptr(it), _abi.iptr(st), _abi.dptr(r), _abi.dptr(s), C.byref(run), 2, C.byref(rho), C.byref(upd))
 assert rc == 0 and np.isfinite(z).all()
 print("ok", run.value)
 """
