@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../include/admm_hip.h"
+#include "admm_dispatch.hpp"
 #include "admm_factor.hpp"
 #include "admm_kernels.hpp"
 
@@ -71,46 +72,45 @@ struct admm_handle {
 
 namespace {
 
-using admm::XB_THREADS;
 using admm::Z_THREADS;
 
-// (n, m) pairs with compiled x-update kernels.
-#define ADMM_FOR_EACH_DIM(X) \
-  X(2, 1) X(2, 2) X(3, 1) X(4, 1) X(4, 2) X(4, 4) X(6, 2) X(6, 3) X(6, 6) X(8, 4) X(12, 3) X(12, 6)
+// The (n, m)-templated kernels live in admm_dims_g*.hip (compiled in parallel); this file only
+// fills the launch descriptor and asks each group in turn.
+admm::XLaunch xlaunch_of(const admm_handle* h) {
+  admm::XLaunch l{};
+  l.stream = h->stream;
+  l.n = h->n; l.m = h->m; l.S = h->S; l.pitch = h->pitch;
+  l.has_q = h->has_q;
+  l.rho = h->opt.rho; l.alpha = h->opt.alpha;
+  l.z = h->z; l.y = h->y; l.q = h->q; l.v = h->v; l.w = h->w;
+  l.recB = h->recB; l.recF = h->recF; l.recS = h->recS; l.seg_start = h->seg_start;
+  l.dbuf = h->dbuf; l.tseg = h->tseg; l.eseg = h->eseg; l.tin = h->tin; l.xin = h->xin; l.part = h->part;
+  l.x0 = h->x0;
+  return l;
+}
+
+bool dispatch_x(const admm::XLaunch& l, admm::XKernel k, bool a, bool b, bool query_only) {
+  return admm::launch_group0(l, k, a, b, query_only) || admm::launch_group1(l, k, a, b, query_only) ||
+         admm::launch_group2(l, k, a, b, query_only) || admm::launch_group3(l, k, a, b, query_only);
+}
 
 bool dims_supported(int n, int m) {
-#define X(NX, NU) if (n == NX && m == NU) return true;
-  ADMM_FOR_EACH_DIM(X)
-#undef X
-  return false;
+  admm::XLaunch l{};
+  l.n = n; l.m = m;
+  return dispatch_x(l, admm::XKernel::XB, false, false, /*query_only=*/true);
 }
 
 std::string supported_list() {
-  std::string s;
-#define X(NX, NU) s += "(" #NX "," #NU ") ";
-  ADMM_FOR_EACH_DIM(X)
-#undef X
-  return s;
+  return std::string(admm::dims_group0()) + admm::dims_group1() + admm::dims_group2() + admm::dims_group3();
+}
+
+int launch_x(admm_handle* h, admm::XKernel k, bool a, bool b) {
+  if (!dispatch_x(xlaunch_of(h), k, a, b, false)) return fail(ADMM_ERR_UNSUPPORTED, "no x-update kernel for this (n, m)");
+  return ADMM_OK;
 }
 
 // vform: read the state from h->v (z = clip(v), y = v - z rebuilt in registers)
-int launch_xb(admm_handle* h, bool vform) {
-  dim3 grid((h->pitch + XB_THREADS - 1) / XB_THREADS, h->S), block(XB_THREADS);
-#define XB(NX, NU, HQ, VF)                                                                           \
-  hipLaunchKernelGGL((admm::xb_kernel<NX, NU, HQ, VF>), grid, block, 0, h->stream,                   \
-                     (const double*)(VF ? h->v : h->z), (const double*)h->y, (const double*)h->q,    \
-                     h->recB, h->seg_start, h->dbuf, h->tseg, h->eseg, h->opt.rho, h->pitch)
-#define X(NX, NU)                                                          \
-  if (h->n == NX && h->m == NU) {                                          \
-    if (h->has_q) { if (vform) XB(NX, NU, true, true); else XB(NX, NU, true, false); }    \
-    else          { if (vform) XB(NX, NU, false, true); else XB(NX, NU, false, false); }  \
-    return ADMM_OK;                                                        \
-  }
-  ADMM_FOR_EACH_DIM(X)
-#undef X
-#undef XB
-  return fail(ADMM_ERR_UNSUPPORTED, "no x-update kernel for this (n, m)");
-}
+int launch_xb(admm_handle* h, bool vform) { return launch_x(h, admm::XKernel::XB, vform, false); }
 
 static_assert(admm::SCAN_KALIGN == 2 * admm::SCAN_U, "host range alignment must match the kernel's batch");
 
@@ -124,55 +124,14 @@ int launch_xscan_mfma(admm_handle* h) {
 
 int launch_xscan(admm_handle* h) {
   if (!(h->opt.flags & ADMM_FLAG_SCAN_CHAIN)) return launch_xscan_mfma(h);
-  dim3 grid(h->pitch / 64), block(64);
-  switch (h->n) {
-#define C(NX)                                                                                        \
-  case NX:                                                                                           \
-    hipLaunchKernelGGL((admm::xscan_kernel<NX>), grid, block, 0, h->stream, h->tseg, h->eseg, h->x0, \
-                       h->recS, h->tin, h->xin, h->S, h->pitch);                                     \
-    return ADMM_OK;
-    C(2) C(3) C(4) C(6) C(8) C(12)
-#undef C
-    default:
-      return fail(ADMM_ERR_UNSUPPORTED, "no scan kernel for this n");
-  }
+  return launch_x(h, admm::XKernel::XSCAN_CHAIN, false, false);
 }
 
-int launch_xf(admm_handle* h) {
-  dim3 grid((h->pitch + XB_THREADS - 1) / XB_THREADS, h->S), block(XB_THREADS);
-#define X(NX, NU)                                                                                 \
-  if (h->n == NX && h->m == NU) {                                                                 \
-    hipLaunchKernelGGL((admm::xf_kernel<NX, NU>), grid, block, 0, h->stream, h->dbuf, h->tin,     \
-                       h->xin, h->recF, h->seg_start, h->w, h->pitch);                            \
-    return ADMM_OK;                                                                               \
-  }
-  ADMM_FOR_EACH_DIM(X)
-#undef X
-  return fail(ADMM_ERR_UNSUPPORTED, "no x-update kernel for this (n, m)");
-}
+int launch_xf(admm_handle* h) { return launch_x(h, admm::XKernel::XF, false, false); }
 
 // fused forward rollout + z/dual (+ residual partials per segment); writes v+ into h->v.
 // vin: previous state read from h->v, otherwise from h->z / h->y.
-int launch_xfz(admm_handle* h, bool resid, bool vin) {
-  dim3 grid((h->pitch + XB_THREADS - 1) / XB_THREADS, h->S), block(XB_THREADS);
-  const bool relax = h->opt.alpha != 1.0;
-#define XFZ(NX, NU, RS, RX, VI)                                                                          \
-  hipLaunchKernelGGL((admm::xfz_kernel<NX, NU, RS, RX, VI>), grid, block, 0, h->stream, h->dbuf, h->tin, \
-                     h->xin, h->recF, h->seg_start, (const double*)h->z, (const double*)h->y, h->v,      \
-                     h->part, h->opt.alpha, h->pitch)
-#define XFZ2(NX, NU, RS, RX) do { if (vin) XFZ(NX, NU, RS, RX, true); else XFZ(NX, NU, RS, RX, false); } while (0)
-#define X(NX, NU)                                                        \
-  if (h->n == NX && h->m == NU) {                                        \
-    if (resid) { if (relax) XFZ2(NX, NU, true, true); else XFZ2(NX, NU, true, false); }   \
-    else       { if (relax) XFZ2(NX, NU, false, true); else XFZ2(NX, NU, false, false); } \
-    return ADMM_OK;                                                      \
-  }
-  ADMM_FOR_EACH_DIM(X)
-#undef X
-#undef XFZ2
-#undef XFZ
-  return fail(ADMM_ERR_UNSUPPORTED, "no x-update kernel for this (n, m)");
-}
+int launch_xfz(admm_handle* h, bool resid, bool vin) { return launch_x(h, admm::XKernel::XFZ, vin, resid); }
 
 // z = clip(v), y = v - z into the z / y arrays (read-out and mode switches)
 int ensure_zy(admm_handle* h) {

@@ -1,0 +1,71 @@
+// admm_dims_impl.hpp -- body shared by admm_dims_g*.hip.  The including file defines
+//   ADMM_GROUP_FN    launch_groupK
+//   ADMM_GROUP_LIST  dims_groupK
+//   ADMM_GROUP_DIMS(X)   X(n, m) X(n, m) ...
+#include "admm_dispatch.hpp"
+#include "admm_kernels.hpp"
+
+namespace admm {
+
+#define ADMM_STR2(x) #x
+#define ADMM_STR(x) ADMM_STR2(x)
+
+const char* ADMM_GROUP_LIST() {
+#define X(NX, NU) "(" ADMM_STR(NX) "," ADMM_STR(NU) ") "
+  return ADMM_GROUP_DIMS(X);
+#undef X
+}
+
+namespace {
+
+template <int NX, int NU>
+void launch_dim(const XLaunch& l, XKernel k, bool a, bool b) {
+  const dim3 grid((l.pitch + XB_THREADS - 1) / XB_THREADS, l.S), block(XB_THREADS);
+  switch (k) {
+    case XKernel::XB: {
+      const double* zin = a ? l.v : l.z;
+#define XB(HQ, VF)                                                                                       \
+  hipLaunchKernelGGL((xb_kernel<NX, NU, HQ, VF>), grid, block, 0, l.stream, zin, l.y, l.q, l.recB,       \
+                     l.seg_start, l.dbuf, l.tseg, l.eseg, l.rho, l.pitch)
+      if (l.has_q) { if (a) XB(true, true); else XB(true, false); }
+      else         { if (a) XB(false, true); else XB(false, false); }
+#undef XB
+      break;
+    }
+    case XKernel::XF:
+      hipLaunchKernelGGL((xf_kernel<NX, NU>), grid, block, 0, l.stream, l.dbuf, l.tin, l.xin, l.recF,
+                         l.seg_start, l.w, l.pitch);
+      break;
+    case XKernel::XFZ: {
+      const bool relax = l.alpha != 1.0;
+#define XFZ(RS, RX, VI)                                                                                  \
+  hipLaunchKernelGGL((xfz_kernel<NX, NU, RS, RX, VI>), grid, block, 0, l.stream, l.dbuf, l.tin, l.xin,   \
+                     l.recF, l.seg_start, l.z, l.y, l.v, l.part, l.alpha, l.pitch)
+#define XFZ2(RS, RX) do { if (a) XFZ(RS, RX, true); else XFZ(RS, RX, false); } while (0)
+      if (b) { if (relax) XFZ2(true, true); else XFZ2(true, false); }
+      else   { if (relax) XFZ2(false, true); else XFZ2(false, false); }
+#undef XFZ2
+#undef XFZ
+      break;
+    }
+    case XKernel::XSCAN_CHAIN:
+      hipLaunchKernelGGL((xscan_kernel<NX>), dim3(l.pitch / 64), dim3(64), 0, l.stream, l.tseg, l.eseg, l.x0,
+                         l.recS, l.tin, l.xin, l.S, l.pitch);
+      break;
+  }
+}
+
+}  // namespace
+
+bool ADMM_GROUP_FN(const XLaunch& l, XKernel k, bool a, bool b, bool query_only) {
+#define X(NX, NU)                               \
+  if (l.n == NX && l.m == NU) {                 \
+    if (!query_only) launch_dim<NX, NU>(l, k, a, b); \
+    return true;                                \
+  }
+  ADMM_GROUP_DIMS(X)
+#undef X
+  return false;
+}
+
+}  // namespace admm

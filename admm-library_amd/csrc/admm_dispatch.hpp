@@ -1,0 +1,37 @@
+// admm_dispatch.hpp -- boundary between the solver runtime (admm_api.hip) and the
+// dimension-templated kernels.  The (n, m) instantiations are split over several translation
+// units (admm_dims_g*.hip) so that they compile in parallel; each exports one launcher.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+namespace admm {
+
+struct XLaunch {
+  hipStream_t stream;
+  int n, m, S, pitch;
+  bool has_q;
+  double rho, alpha;
+  const double *z, *y, *q;      // state in (z, y) form and the linear term
+  double *v, *w;                // state in v-form; materialised w
+  const double *recB, *recF, *recS;
+  const int* seg_start;
+  double *dbuf, *tseg, *eseg, *tin, *xin, *part;
+  const double* x0;
+};
+
+enum class XKernel { XB, XF, XFZ, XSCAN_CHAIN };
+
+// Each returns true if (n, m) is compiled in that group (and, unless query_only, the kernel
+// was enqueued on l.stream).  a = VFORM (XB) / VIN (XFZ); b = RESID (XFZ).
+bool launch_group0(const XLaunch& l, XKernel k, bool a, bool b, bool query_only);
+bool launch_group1(const XLaunch& l, XKernel k, bool a, bool b, bool query_only);
+bool launch_group2(const XLaunch& l, XKernel k, bool a, bool b, bool query_only);
+bool launch_group3(const XLaunch& l, XKernel k, bool a, bool b, bool query_only);
+// " (n,m) (n,m) ..." of a group, for error messages
+const char* dims_group0();
+const char* dims_group1();
+const char* dims_group2();
+const char* dims_group3();
+
+}  // namespace admm

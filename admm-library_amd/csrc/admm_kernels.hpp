@@ -9,6 +9,7 @@
 // 512-B / 1-KiB segment of a row, and all per-stage matrices and bounds are
 // wave-uniform: they travel through the scalar unit (s_load -> SGPR operand of
 // v_fma_f64) and cost no VGPRs and no LDS bandwidth.
+// (Non-template kernels are `static`: this header is included by several translation units.)
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -824,7 +825,7 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_X_OCCUPANCY void xfz_kernel(
 
 // y *= c over the whole array (rho change: the scaled dual y = lambda / rho is rescaled so that
 // the multiplier lambda is unchanged).  16-byte accesses, grid-stride.
-__global__ __launch_bounds__(256) void scale_kernel(double* __restrict__ y, double c, size_t count2) {
+static __global__ __launch_bounds__(256) void scale_kernel(double* __restrict__ y, double c, size_t count2) {
   double2* y2 = reinterpret_cast<double2*>(y);
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count2; i += (size_t)gridDim.x * 256) {
     double2 v = y2[i];
@@ -836,7 +837,7 @@ __global__ __launch_bounds__(256) void scale_kernel(double* __restrict__ y, doub
 
 // v -> (z, y): z = clip(v), y = v - z.  Read-out / mode switches only.  One lane =
 // two adjacent QPs, blockIdx.y = row chunk (same geometry as zdual_kernel).
-__global__ __launch_bounds__(Z_THREADS) void v_to_zy_kernel(
+static __global__ __launch_bounds__(Z_THREADS) void v_to_zy_kernel(
     const double* __restrict__ v, double* __restrict__ z, double* __restrict__ y,
     const double* __restrict__ lo_, const double* __restrict__ hi_, int L, int zrows, int pitch) {
   const int col = (blockIdx.x * Z_THREADS + threadIdx.x) * 2;
@@ -977,7 +978,7 @@ __global__ __launch_bounds__(Z_THREADS) void zdual_kernel(
 constexpr int FIN_COLS = 64;     // columns (QPs) per finalise workgroup: one wave wide
 constexpr int FIN_GROUPS = 16;   // chunk groups per workgroup (one wave each)
 
-__global__ __launch_bounds__(FIN_COLS * FIN_GROUPS) void resid_finalize_kernel(
+static __global__ __launch_bounds__(FIN_COLS * FIN_GROUPS) void resid_finalize_kernel(
     const double* __restrict__ part, double* __restrict__ resid, int* __restrict__ status,
     int* __restrict__ iters, int* __restrict__ nconv, double rho, double eps_abs, double eps_rel,
     double sqrtL, int nchunks, int batch, int pitch, int it) {
@@ -1035,7 +1036,7 @@ __global__ __launch_bounds__(FIN_COLS * FIN_GROUPS) void resid_finalize_kernel(
 // e < L) and the device's batch-minor  dst[e][col]  (col < pitch).  32x32 tiles
 // through padded LDS so both sides are coalesced.  Setup / read-out only.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(T_TILE * 8) void to_batch_minor_kernel(
+static __global__ __launch_bounds__(T_TILE * 8) void to_batch_minor_kernel(
     const double* __restrict__ src, double* __restrict__ dst, int batch, int L, int pitch) {
   __shared__ double tile[T_TILE][T_TILE + 1];
   const int e0 = blockIdx.x * T_TILE, b0 = blockIdx.y * T_TILE;
@@ -1051,7 +1052,7 @@ __global__ __launch_bounds__(T_TILE * 8) void to_batch_minor_kernel(
   }
 }
 
-__global__ __launch_bounds__(T_TILE * 8) void from_batch_minor_kernel(
+static __global__ __launch_bounds__(T_TILE * 8) void from_batch_minor_kernel(
     const double* __restrict__ src, double* __restrict__ dst, int batch, int L, int pitch) {
   __shared__ double tile[T_TILE][T_TILE + 1];
   const int e0 = blockIdx.x * T_TILE, b0 = blockIdx.y * T_TILE;

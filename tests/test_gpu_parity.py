@@ -43,6 +43,12 @@ CASES = [
     (lambda: pkg.random_ltv(N=40, n=12, m=6, batch=3, seed=17), 0.4, 2),
     (lambda: pkg.cw_rendezvous(N=200, batch=70), 0.05, 2),
     (lambda: pkg.cw_formation(N=120, batch=66), 0.05, 0),       # configs[4] shape, full Q / QN
+    # the wider compiled set (admm_dims_g*.hip)
+    (lambda: pkg.random_ltv(N=14, n=1, m=1, batch=5, seed=51), 0.3, 2),
+    (lambda: pkg.random_ltv(N=14, n=5, m=3, batch=5, seed=52), 0.3, 2),
+    (lambda: pkg.random_ltv(N=14, n=7, m=3, batch=5, seed=53), 0.3, 2),
+    (lambda: pkg.random_ltv(N=14, n=9, m=3, batch=5, seed=54), 0.3, 2),
+    (lambda: pkg.random_ltv(N=14, n=10, m=4, batch=5, seed=55), 0.3, 2),
     # degenerate horizons
     (lambda: pkg.random_ltv(N=1, n=4, m=2, batch=3, seed=18), 0.3, 0),
     (lambda: pkg.random_ltv(N=2, n=6, m=3, batch=2, seed=19), 0.3, 0),
@@ -272,10 +278,10 @@ def test_properties_at_full_size(gpu):
 
 
 def test_errors_are_loud(gpu):
-    p = pkg.random_ltv(N=5, n=5, m=2, batch=2)
+    p = pkg.random_ltv(N=5, n=11, m=5, batch=2)
     with pytest.raises(pkg.AdmmError) as e:
         pkg.Solver(p)
-    assert e.value.code == 2            # ADMM_ERR_UNSUPPORTED: (5, 2) not compiled
+    assert e.value.code == 2            # ADMM_ERR_UNSUPPORTED: (11, 5) not compiled
     p = pkg.double_integrator(N=10)
     with pytest.raises(pkg.AdmmError) as e:
         pkg.Solver(p, pkg.Options(rho=-1.0))

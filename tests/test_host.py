@@ -145,7 +145,7 @@ def test_input_validation_through_the_abi(lib):
     cp.batch = 0
     assert lib.admm_setup(C.byref(h), C.byref(cp), None) == 1
     # unsupported dimensions are reported before any device is touched
-    rc, msg = _setup_rc(lib, pkg.random_ltv(N=5, n=5, m=2, batch=2))
+    rc, msg = _setup_rc(lib, pkg.random_ltv(N=5, n=11, m=5, batch=2))
     assert rc == 2 and "supported" in msg
     # NULL handle -> error code, not a crash
     assert lib.admm_sync(None) == 1 and lib.admm_iterate(None, 3) == 1
