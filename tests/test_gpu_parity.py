@@ -286,3 +286,34 @@ def test_errors_are_loud(gpu):
     with pytest.raises(pkg.AdmmError) as e:
         pkg.Solver(p, pkg.Options(rho=-1.0))
     assert e.value.code == 1
+
+
+def test_randomised_configurations(gpu):
+    """40 seeded random configurations over the compiled (n, m) set: horizon, batch (pad columns),
+    segment count (incl. S = 1 and S = N), prefetch-ring tails, LDS record chunking, q on/off, box
+    per stage or shared, over-relaxation, fused / unfused / chain-scan paths, residual cadence --
+    8 iterations each against the C oracle."""
+    dims = [(1, 1), (2, 1), (2, 2), (3, 2), (4, 1), (4, 3), (5, 2), (6, 1), (6, 3), (6, 4), (7, 3), (8, 2),
+            (8, 4), (9, 3), (10, 2), (12, 4), (12, 6)]
+    rng = np.random.default_rng(2024)
+    for trial in range(40):
+        n, m = dims[rng.integers(len(dims))]
+        N = int(rng.integers(1, 90))
+        batch = int(rng.choice([1, 2, 63, 64, 65, 100, 129, 257]))
+        segs = int(rng.choice([0, 1, 2, 3, 5, 8, N]))
+        alpha = float(rng.choice([1.0, 1.0, 1.4]))
+        flags = int(rng.choice([0, 0, 2, 4, 6]))
+        with_q = bool(rng.integers(2))
+        p = pkg.random_ltv(N=N, n=n, m=m, batch=batch, seed=1000 + trial, with_q=with_q,
+                           state_bounds=bool(rng.integers(2)))
+        if rng.integers(2):                       # one box for every stage
+            p.lo, p.hi = p.lo[0].copy(), p.hi[0].copy()
+        rho = float(rng.choice([0.1, 0.5, 2.0]))
+        every = int(rng.choice([0, 1, 3]))
+        ref = oc.solve(p, rho=rho, alpha=alpha, max_iter=8, check_interval=1, eps_abs=0, eps_rel=0, stop=False)
+        with pkg.Solver(p, pkg.Options(rho=rho, alpha=alpha, segments=segs, flags=flags)) as s:
+            s.run(8, residual_every=every)
+            w, z, y = s.get()
+        ctx = dict(trial=trial, n=n, m=m, N=N, batch=batch, segs=segs, alpha=alpha, flags=flags, q=with_q)
+        for a, b in ((w, ref["w"]), (z, ref["z"]), (y, ref["y"])):
+            assert np.abs(a - b).max() <= TOL * max(1.0, np.abs(b).max()), ctx
