@@ -47,6 +47,8 @@ struct admm_handle {
   std::vector<double> pA, pB, pQ, pR, pQN, plo, phi;
   int time_varying = 0, stage_bounds = 0;
   int rho_updates = 0;
+  int solve_it = 0, solve_nconv = 0;     // admm_solve_begin / _step / _end state
+  std::chrono::steady_clock::time_point solve_t0;
   hipStream_t stream = nullptr;
   // batch-minor state and work buffers
   double *w = nullptr, *z = nullptr, *y = nullptr, *v = nullptr, *q = nullptr, *x0 = nullptr;
@@ -698,10 +700,10 @@ int admm_sync(admm_handle* h) {
   return ADMM_OK;
 }
 
-int admm_solve(admm_handle* h, const double* z0, const double* y0, admm_info* info) {
+int admm_solve_begin(admm_handle* h, const double* z0, const double* y0) {
   if (!h) return fail(ADMM_ERR_INVALID, "NULL handle");
   HIP_TRY(hipSetDevice(h->device));
-  const auto t0 = std::chrono::steady_clock::now();
+  h->solve_t0 = std::chrono::steady_clock::now();
   int rc;
   if ((rc = admm_set_state(h, nullptr, z0, y0))) return rc;
   const size_t P = h->pitch;
@@ -714,9 +716,22 @@ int admm_solve(admm_handle* h, const double* z0, const double* y0, admm_info* in
   const bool use_graph = !(h->opt.flags & ADMM_FLAG_NO_GRAPH);
   if (use_graph && !h->graph_exec[0] && (rc = capture_iterations(h))) return rc;
   h->rho_updates = 0;
-  int it = 0, nconv = 0;
+  h->solve_it = 0;
+  h->solve_nconv = 0;
+  return ADMM_OK;
+}
+
+int admm_solve_step(admm_handle* h, int32_t* iters_done, int32_t* n_converged, double* R_out, double* S_out) {
+  if (!h) return fail(ADMM_ERR_INVALID, "NULL handle");
+  if (h->solve_it >= h->opt.max_iter) return fail(ADMM_ERR_INVALID, "admm_solve_step: max_iter already reached");
+  HIP_TRY(hipSetDevice(h->device));
+  const bool use_graph = !(h->opt.flags & ADMM_FLAG_NO_GRAPH);
+  if (use_graph && !h->graph_exec[0]) { int rc0 = capture_iterations(h); if (rc0) return rc0; }
   const int ci = h->opt.check_interval;
-  for (it = 1; it <= h->opt.max_iter; ++it) {
+  const size_t P = h->pitch;
+  int rc;
+  for (;;) {
+    const int it = ++h->solve_it;
     const bool check = (it % ci == 0) || it == h->opt.max_iter;
     if (!check) {
       if ((rc = enqueue_one(h, false, use_graph))) return rc;
@@ -730,37 +745,58 @@ int admm_solve(admm_handle* h, const double* z0, const double* y0, admm_info* in
     launch_finalize(h, it, chunks_of_iteration(h));
     HIP_TRY(hipMemcpyAsync(h->h_nconv, h->nconv, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
-    nconv = *h->h_nconv;
+    h->solve_nconv = *h->h_nconv;
     h->resid_valid = true;
-    if (nconv >= h->batch) break;
-    // adaptive rho: batch-level residual balancing over the unconverged QPs
-    if (h->opt.adapt_interval > 0 && it % h->opt.adapt_interval == 0 && h->rho_updates < h->opt.adapt_max &&
-        it < h->opt.max_iter) {
-      std::vector<double> rs(2 * P);
-      std::vector<int> st(P);
-      HIP_TRY(hipMemcpy(rs.data(), h->resid, sizeof(double) * 2 * P, hipMemcpyDeviceToHost));
-      HIP_TRY(hipMemcpy(st.data(), h->status, sizeof(int) * P, hipMemcpyDeviceToHost));
-      double R = 0.0, S = 0.0;
-      for (int b = 0; b < h->batch; ++b)
-        if (!st[b]) { R += rs[b] * rs[b]; S += rs[P + b] * rs[P + b]; }
-      const double mu2 = h->opt.adapt_mu * h->opt.adapt_mu;
-      double rho_new = h->opt.rho;
-      if (R > mu2 * S) rho_new = h->opt.rho * h->opt.adapt_tau;
-      else if (S > mu2 * R) rho_new = h->opt.rho / h->opt.adapt_tau;
-      if (rho_new != h->opt.rho) {
-        if ((rc = set_rho_internal(h, rho_new))) return rc;
-        ++h->rho_updates;
-        if (use_graph && (rc = capture_iterations(h))) return rc;
-      }
-    }
+    break;
   }
-  if (it > h->opt.max_iter) it = h->opt.max_iter;
+  if (iters_done) *iters_done = h->solve_it;
+  if (n_converged) *n_converged = h->solve_nconv;
+  if (R_out || S_out) {
+    // sums of r^2 and s^2 over the QPs that have not converged, in batch order (adaptive-rho rule)
+    std::vector<double> rs(2 * P);
+    std::vector<int> st(P);
+    HIP_TRY(hipMemcpy(rs.data(), h->resid, sizeof(double) * 2 * P, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(st.data(), h->status, sizeof(int) * P, hipMemcpyDeviceToHost));
+    double R = 0.0, S = 0.0;
+    for (int b = 0; b < h->batch; ++b)
+      if (!st[b]) { R += rs[b] * rs[b]; S += rs[P + b] * rs[P + b]; }
+    if (R_out) *R_out = R;
+    if (S_out) *S_out = S;
+  }
+  return ADMM_OK;
+}
+
+int admm_solve_adapt(admm_handle* h, double R, double S, int32_t* changed) {
+  if (!h) return fail(ADMM_ERR_INVALID, "NULL handle");
+  HIP_TRY(hipSetDevice(h->device));
+  if (changed) *changed = 0;
+  const int it = h->solve_it;
+  if (!(h->opt.adapt_interval > 0 && it % h->opt.adapt_interval == 0 && h->rho_updates < h->opt.adapt_max &&
+        it < h->opt.max_iter))
+    return ADMM_OK;
+  const double mu2 = h->opt.adapt_mu * h->opt.adapt_mu;
+  double rho_new = h->opt.rho;
+  if (R > mu2 * S) rho_new = h->opt.rho * h->opt.adapt_tau;
+  else if (S > mu2 * R) rho_new = h->opt.rho / h->opt.adapt_tau;
+  if (rho_new != h->opt.rho) {
+    int rc = set_rho_internal(h, rho_new);
+    if (rc) return rc;
+    ++h->rho_updates;
+    if (changed) *changed = 1;
+  }
+  return ADMM_OK;
+}
+
+int admm_solve_end(admm_handle* h, admm_info* info) {
+  if (!h) return fail(ADMM_ERR_INVALID, "NULL handle");
+  HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(h->stream));
-  h->iters_run = it;
+  h->iters_run = h->solve_it;
+  const size_t P = h->pitch;
   if (info) {
-    info->iters_run = it;
-    info->n_converged = nconv;
+    info->iters_run = h->solve_it;
+    info->n_converged = h->solve_nconv;
     std::vector<double> rs(2 * P);
     HIP_TRY(hipMemcpy(rs.data(), h->resid, sizeof(double) * 2 * P, hipMemcpyDeviceToHost));
     double mr = 0, ms = 0;
@@ -770,12 +806,26 @@ int admm_solve(admm_handle* h, const double* z0, const double* y0, admm_info* in
     }
     info->max_r = mr;
     info->max_s = ms;
-    info->solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    info->solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - h->solve_t0).count();
     info->rho = h->opt.rho;
     info->rho_updates = h->rho_updates;
     info->reserved = 0;
   }
   return ADMM_OK;
+}
+
+int admm_solve(admm_handle* h, const double* z0, const double* y0, admm_info* info) {
+  int rc = admm_solve_begin(h, z0, y0);
+  if (rc) return rc;
+  const bool adaptive = h->opt.adapt_interval > 0;
+  for (;;) {
+    int32_t it = 0, nconv = 0;
+    double R = 0.0, S = 0.0;
+    if ((rc = admm_solve_step(h, &it, &nconv, adaptive ? &R : nullptr, adaptive ? &S : nullptr))) return rc;
+    if (nconv >= h->batch || it >= h->opt.max_iter) break;
+    if (adaptive && (rc = admm_solve_adapt(h, R, S, nullptr))) return rc;
+  }
+  return admm_solve_end(h, info);
 }
 
 int admm_get_residuals(admm_handle* h, double* r, double* s, double* nw, double* nz, double* ny) {

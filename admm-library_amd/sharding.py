@@ -56,3 +56,28 @@ def global_residual_max(r_max: float, s_max: float, device="cpu", group=None):
     t = torch.tensor([r_max, s_max], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return float(t[0]), float(t[1])
+
+
+def solve_sharded(solver, global_batch: int, group=None, device="cpu"):
+    """Multi-GPU admm_solve: every rank holds a Solver over its shard (shard_problem) and calls
+    this collectively.  The iterations need no communication; at every checked iteration ONE
+    all-reduce (SUM) of three doubles -- unconverged QPs, sum r^2, sum s^2 -- makes the stop
+    decision and the adaptive-rho decision global, so every QP runs exactly the iterations it would
+    run in an unsharded solve of the whole batch (with adaptive rho: up to the summation order of
+    R and S).  `device` = where the 3-double tensor lives ("cpu" for gloo, "cuda:i" for RCCL).
+    Returns this rank's SolveInfo (per-QP arrays are the shard's; use gather_batch to assemble)."""
+    import torch
+    import torch.distributed as dist
+    opt = solver.options
+    adaptive = opt.adapt_interval > 0
+    solver.solve_begin()
+    while True:
+        it, nconv, R, S = solver.solve_step(sums=adaptive)
+        t = torch.tensor([float(solver.batch - nconv), R, S], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        left, Rg, Sg = float(t[0]), float(t[1]), float(t[2])
+        if left == 0 or it >= opt.max_iter:
+            break
+        if adaptive:
+            solver.solve_adapt(Rg, Sg)
+    return solver.solve_end()

@@ -46,6 +46,10 @@ _SIGNATURES = {
     "admm_set_state": (C.c_int, [C.c_void_p, c_double_p, c_double_p, c_double_p]),
     "admm_set_rho": (C.c_int, [C.c_void_p, C.c_double]),
     "admm_solve": (C.c_int, [C.c_void_p, c_double_p, c_double_p, C.POINTER(CInfo)]),
+    "admm_solve_begin": (C.c_int, [C.c_void_p, c_double_p, c_double_p]),
+    "admm_solve_step": (C.c_int, [C.c_void_p, c_int32_p, c_int32_p, c_double_p, c_double_p]),
+    "admm_solve_adapt": (C.c_int, [C.c_void_p, C.c_double, C.c_double, c_int32_p]),
+    "admm_solve_end": (C.c_int, [C.c_void_p, C.POINTER(CInfo)]),
     "admm_iterate": (C.c_int, [C.c_void_p, C.c_int32]),
     "admm_run": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "admm_sync": (C.c_int, [C.c_void_p]),
@@ -189,10 +193,7 @@ class Solver:
         w, z, y = self._vec(w), self._vec(z), self._vec(y)
         _check(self._lib, self._lib.admm_set_state(self._h, dptr(w), dptr(z), dptr(y)))
 
-    def solve(self, z0=None, y0=None) -> SolveInfo:
-        z0, y0 = self._vec(z0), self._vec(y0)
-        ci = CInfo()
-        _check(self._lib, self._lib.admm_solve(self._h, dptr(z0), dptr(y0), C.byref(ci)))
+    def _info(self, ci: CInfo) -> SolveInfo:
         iters = np.empty(self.batch, np.int32)
         status = np.empty(self.batch, np.int32)
         r = np.empty(self.batch)
@@ -200,6 +201,36 @@ class Solver:
         _check(self._lib, self._lib.admm_get_info(self._h, iptr(iters), iptr(status), dptr(r), dptr(s)))
         return SolveInfo(ci.iters_run, ci.n_converged, ci.max_r, ci.max_s, ci.solve_ms, ci.rho, ci.rho_updates,
                          iters, status, r, s)
+
+    def solve(self, z0=None, y0=None) -> SolveInfo:
+        z0, y0 = self._vec(z0), self._vec(y0)
+        ci = CInfo()
+        _check(self._lib, self._lib.admm_solve(self._h, dptr(z0), dptr(y0), C.byref(ci)))
+        return self._info(ci)
+
+    # admm_solve in pieces (global stop / adaptive-rho decisions of a sharded solve)
+    def solve_begin(self, z0=None, y0=None):
+        z0, y0 = self._vec(z0), self._vec(y0)
+        _check(self._lib, self._lib.admm_solve_begin(self._h, dptr(z0), dptr(y0)))
+
+    def solve_step(self, sums: bool = False):
+        """Run up to and including the next checked iteration.
+        Returns (iterations so far, converged QPs of this handle, R, S)."""
+        it, nc = C.c_int32(), C.c_int32()
+        R, S = C.c_double(), C.c_double()
+        _check(self._lib, self._lib.admm_solve_step(self._h, C.byref(it), C.byref(nc),
+                                                    C.byref(R) if sums else None, C.byref(S) if sums else None))
+        return it.value, nc.value, R.value, S.value
+
+    def solve_adapt(self, R: float, S: float) -> bool:
+        ch = C.c_int32()
+        _check(self._lib, self._lib.admm_solve_adapt(self._h, float(R), float(S), C.byref(ch)))
+        return bool(ch.value)
+
+    def solve_end(self) -> SolveInfo:
+        ci = CInfo()
+        _check(self._lib, self._lib.admm_solve_end(self._h, C.byref(ci)))
+        return self._info(ci)
 
     def iterate(self, iters: int, sync: bool = True):
         _check(self._lib, self._lib.admm_iterate(self._h, int(iters)))

@@ -133,6 +133,22 @@ int admm_set_state(admm_handle* h, const double* w, const double* z, const doubl
  * z0/y0 (L*batch) may be NULL: continue from the handle's current state. */
 int admm_solve(admm_handle* h, const double* z0, const double* y0, admm_info* info);
 
+/* admm_solve in pieces, for callers that need a decision between checks -- in particular a
+ * multi-GPU solve, where each rank owns a shard of the batch and the stop decision (and the
+ * adaptive-rho sums) must be global:
+ *   admm_solve_begin(h, z0, y0);
+ *   loop: admm_solve_step(h, &it, &nconv, &R, &S);       // runs up to and including the next check
+ *         [all-reduce  batch - nconv  (SUM),  R, S (SUM)  over the ranks]
+ *         stop if nothing is left unconverged or it >= max_iter;
+ *         admm_solve_adapt(h, R_global, S_global, &changed);   // no-op unless an adaptation is due
+ *   admm_solve_end(h, &info);
+ * admm_solve is exactly this loop with local values.  R, S = sums of r^2, s^2 over the QPs that
+ * have not converged (NULL to skip the read-back). */
+int admm_solve_begin(admm_handle* h, const double* z0, const double* y0);
+int admm_solve_step(admm_handle* h, int32_t* iters_done, int32_t* n_converged, double* R, double* S);
+int admm_solve_adapt(admm_handle* h, double R, double S, int32_t* changed);
+int admm_solve_end(admm_handle* h, admm_info* info);
+
 /* Run exactly `iters` iterations, no residuals, no stop test (benchmark and
  * iterate-parity path).  Asynchronous on the handle's stream; admm_sync waits. */
 int admm_iterate(admm_handle* h, int32_t iters);

@@ -1,0 +1,61 @@
+"""N > 1 on the GPU path: two processes, each with its own handle over its shard of the batch,
+a global stop decision through one all-reduce per check.  The box has one GPU, so
+both ranks share it and the collective runs over gloo; with one GPU per rank the same code runs
+over RCCL (backend "nccl", device="cuda:i") -- what bench.py --gpus N uses."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, batch, adapt, out_dir):
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    import admm_library_amd as pkg
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    full = pkg.cw_rendezvous(N=120, batch=batch)
+    shard = pkg.shard_problem(full, world, rank)
+    opt = pkg.Options(rho=0.05, eps_abs=1e-6, eps_rel=1e-6, max_iter=3000, check_interval=10, device=0, **adapt)
+    with pkg.Solver(shard, opt) as s:
+        info = pkg.solve_sharded(s, batch)
+        _, z, _ = s.get(False, True, False)
+    zf = pkg.gather_batch(torch.from_numpy(z), batch)
+    itf = pkg.gather_batch(torch.from_numpy(info.iters), batch)
+    dist.barrier()
+    if rank == 0:
+        np.savez(os.path.join(out_dir, "sharded.npz"), z=zf.numpy(), iters=itf.numpy(), iters_run=info.iters_run,
+                 rho=info.rho)
+    dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("adapt", [{}, {"adapt_interval": 20}], ids=["fixed_rho", "adaptive_rho"])
+def test_two_rank_sharded_solve_equals_unsharded(gpu, tmp_path, adapt):
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import admm_library_amd as pkg
+    import oracle_c as oc
+    batch = 37                                    # uneven shards: 19 + 18
+    mp.spawn(_worker, args=(2, _free_port(), batch, adapt, str(tmp_path)), nprocs=2, join=True)
+    got = np.load(tmp_path / "sharded.npz")
+    ref = oc.solve(pkg.cw_rendezvous(N=120, batch=batch), rho=0.05, eps_abs=1e-6, eps_rel=1e-6, max_iter=3000,
+                   check_interval=10, **adapt)
+    # the stop decision is global: every QP ran as many iterations as in the unsharded solve
+    assert int(got["iters_run"]) == ref["iters_run"]
+    assert float(got["rho"]) == ref["rho"]
+    assert (np.abs(got["iters"] - ref["iters"]) <= 10).all()
+    assert np.abs(got["z"] - ref["z"]).max() <= 1e-10
