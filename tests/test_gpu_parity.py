@@ -317,3 +317,19 @@ def test_randomised_configurations(gpu):
         ctx = dict(trial=trial, n=n, m=m, N=N, batch=batch, segs=segs, alpha=alpha, flags=flags, q=with_q)
         for a, b in ((w, ref["w"]), (z, ref["z"]), (y, ref["y"])):
             assert np.abs(a - b).max() <= TOL * max(1.0, np.abs(b).max()), ctx
+
+
+def test_plain_c_program_over_the_abi(gpu, tmp_path):
+    """examples/c_abi_demo.c: the boundary really is a C ABI -- a C11 program compiled with gcc,
+    linked against libadmm_hip.so only, sets up, solves and reads back a batch."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "c_abi_demo")
+    libdir = os.path.join(root, "admm-library_amd")
+    subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(root, "include"),
+                    os.path.join(root, "examples", "c_abi_demo.c"), "-L", libdir, "-ladmm_hip", "-lm", "-o", exe], check=True)
+    env = dict(os.environ, LD_LIBRARY_PATH=libdir + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    out = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "converged 5/5" in out.stdout
