@@ -12,7 +12,7 @@ import numpy as np
 
 from .problems import Problem
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 ADMM_OK = 0
 STATUS_NAMES = {0: "ADMM_OK", 1: "ADMM_ERR_INVALID", 2: "ADMM_ERR_UNSUPPORTED",
@@ -33,7 +33,7 @@ class CProblem(C.Structure):
                 ("time_varying", C.c_int32), ("stage_bounds", C.c_int32),
                 ("A", c_double_p), ("B", c_double_p), ("Q", c_double_p), ("R", c_double_p),
                 ("QN", c_double_p), ("x0", c_double_p), ("lo", c_double_p), ("hi", c_double_p),
-                ("q", c_double_p)]
+                ("q", c_double_p), ("unorm", c_double_p)]
 
 
 class COptions(C.Structure):
@@ -80,12 +80,14 @@ def marshal_problem(p: Problem):
         "lo": np.ascontiguousarray(p.lo, np.float64),
         "hi": np.ascontiguousarray(p.hi, np.float64),
         "q": None if p.q is None else np.ascontiguousarray(p.q, np.float64),
+        "unorm": None if p.unorm is None else np.array(
+            np.broadcast_to(np.asarray(p.unorm, np.float64), (p.N,) if p.lo.ndim == 2 else (1,)), np.float64),
     }
     cp = CProblem(N=p.N, n=p.n, m=p.m, batch=p.batch,
                   time_varying=int(p.time_varying), stage_bounds=int(p.lo.ndim == 2),
                   A=dptr(keep["A"]), B=dptr(keep["B"]), Q=dptr(keep["Q"]), R=dptr(keep["R"]),
                   QN=dptr(keep["QN"]), x0=dptr(keep["x0"]), lo=dptr(keep["lo"]),
-                  hi=dptr(keep["hi"]), q=dptr(keep["q"]))
+                  hi=dptr(keep["hi"]), q=dptr(keep["q"]), unorm=dptr(keep["unorm"]))
     return cp, keep
 
 

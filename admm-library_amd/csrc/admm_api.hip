@@ -41,10 +41,11 @@ struct admm_handle {
   int S = 0, zrows = 0, zchunks = 0;
   int device = 0;
   bool has_q = false;
+  bool has_soc = false;          // some stage has a finite thrust-magnitude bound
   admm_options opt{};
   admm::Factor fac;
   // host copy of the shared problem data (the caller's pointers are never kept): admm_set_rho refactors from it
-  std::vector<double> pA, pB, pQ, pR, pQN, plo, phi;
+  std::vector<double> pA, pB, pQ, pR, pQN, plo, phi, pun;
   int time_varying = 0, stage_bounds = 0;
   int rho_updates = 0;
   int solve_it = 0, solve_nconv = 0;     // admm_solve_begin / _step / _end state
@@ -53,7 +54,7 @@ struct admm_handle {
   // batch-minor state and work buffers
   double *w = nullptr, *z = nullptr, *y = nullptr, *v = nullptr, *q = nullptr, *x0 = nullptr;
   double *dbuf = nullptr, *tseg = nullptr, *eseg = nullptr, *tin = nullptr, *xin = nullptr;
-  double *part = nullptr, *resid = nullptr, *lo = nullptr, *hi = nullptr;
+  double *part = nullptr, *resid = nullptr, *lo = nullptr, *hi = nullptr, *ub = nullptr;
   double *recB = nullptr, *recF = nullptr, *recS = nullptr;
   double *scan_in = nullptr, *scan_out = nullptr, *scanWp = nullptr;   // tseg|x0|eseg and t_in|x_in live inside these
   int* scan_range = nullptr;
@@ -83,6 +84,7 @@ admm::XLaunch xlaunch_of(const admm_handle* h) {
   l.stream = h->stream;
   l.n = h->n; l.m = h->m; l.S = h->S; l.pitch = h->pitch;
   l.has_q = h->has_q;
+  l.has_soc = h->has_soc;
   l.rho = h->opt.rho; l.alpha = h->opt.alpha;
   l.z = h->z; l.y = h->y; l.q = h->q; l.v = h->v; l.w = h->w;
   l.recB = h->recB; l.recF = h->recF; l.recS = h->recS; l.seg_start = h->seg_start;
@@ -139,8 +141,12 @@ int launch_xfz(admm_handle* h, bool resid, bool vin) { return launch_x(h, admm::
 int ensure_zy(admm_handle* h) {
   if (h->zy_valid) return ADMM_OK;
   dim3 grid((h->pitch / 2 + Z_THREADS - 1) / Z_THREADS, h->zchunks), block(Z_THREADS);
-  hipLaunchKernelGGL(admm::v_to_zy_kernel, grid, block, 0, h->stream, (const double*)h->v, h->z, h->y,
-                     h->lo, h->hi, h->L, h->zrows, h->pitch);
+  if (h->has_soc)
+    hipLaunchKernelGGL(admm::v_to_zy_soc_kernel, grid, block, 0, h->stream, (const double*)h->v, h->z, h->y,
+                       h->lo, h->hi, h->ub, h->L, h->zrows, h->pitch, h->nb, h->m);
+  else
+    hipLaunchKernelGGL(admm::v_to_zy_kernel, grid, block, 0, h->stream, (const double*)h->v, h->z, h->y,
+                       h->lo, h->hi, h->L, h->zrows, h->pitch);
   h->zy_valid = true;
   return ADMM_OK;
 }
@@ -148,9 +154,15 @@ int ensure_zy(admm_handle* h) {
 int launch_z(admm_handle* h, bool resid) {
   dim3 grid((h->pitch / 2 + Z_THREADS - 1) / Z_THREADS, h->zchunks), block(Z_THREADS);
   const bool relax = h->opt.alpha != 1.0;
-#define ZL(RS, RX)                                                                                  \
-  hipLaunchKernelGGL((admm::zdual_kernel<RS, RX>), grid, block, 0, h->stream, h->w, h->z, h->y,     \
-                     h->lo, h->hi, h->part, h->opt.alpha, h->L, h->zrows, h->pitch)
+#define ZL(RS, RX)                                                                                       \
+  do {                                                                                                   \
+    if (h->has_soc)                                                                                      \
+      hipLaunchKernelGGL((admm::zdual_soc_kernel<RS, RX>), grid, block, 0, h->stream, h->w, h->z, h->y,  \
+                         h->lo, h->hi, h->ub, h->part, h->opt.alpha, h->L, h->zrows, h->pitch, h->nb, h->m); \
+    else                                                                                                 \
+      hipLaunchKernelGGL((admm::zdual_kernel<RS, RX>), grid, block, 0, h->stream, h->w, h->z, h->y,      \
+                         h->lo, h->hi, h->part, h->opt.alpha, h->L, h->zrows, h->pitch);                 \
+  } while (0)
   if (resid) {
     if (relax) ZL(true, true); else ZL(true, false);
   } else {
@@ -270,6 +282,17 @@ int validate_problem(const admm_problem* p) {
     if (p->lo[i] > p->hi[i]) return fail(ADMM_ERR_INVALID, "lo > hi at bound index " + std::to_string(i));
     if (p->lo[i] == INFINITY || p->hi[i] == -INFINITY) return fail(ADMM_ERR_INVALID, "lo = +inf or hi = -inf");
   }
+  if (p->unorm) {
+    const int cnt = p->stage_bounds ? p->N : 1;
+    for (int k = 0; k < cnt; ++k) {
+      const double ub = p->unorm[k];
+      if (std::isnan(ub) || !(ub > 0.0)) return fail(ADMM_ERR_INVALID, "unorm entries must be positive (inf = off)");
+      if (std::isfinite(ub))
+        for (int j = 0; j < p->m; ++j)
+          if (std::isfinite(p->lo[(size_t)k * nb + j]) || std::isfinite(p->hi[(size_t)k * nb + j]))
+            return fail(ADMM_ERR_INVALID, "control rows must be unbounded (-inf, inf) where unorm is finite");
+    }
+  }
   if (!finite_all(p->x0, (size_t)p->n * p->batch)) return fail(ADMM_ERR_INVALID, "non-finite entry in x0");
   if (p->q && !finite_all(p->q, L * p->batch)) return fail(ADMM_ERR_INVALID, "non-finite entry in q");
   return ADMM_OK;
@@ -287,7 +310,7 @@ void release(admm_handle* h) {
   (void)hipSetDevice(h->device);
   destroy_graph(h);
   double** bufs[] = {&h->w, &h->z, &h->y, &h->v, &h->q, &h->dbuf, &h->scan_in, &h->scan_out, &h->scanWp,
-                     &h->part, &h->resid, &h->lo, &h->hi, &h->recB, &h->recF, &h->recS, &h->stage};
+                     &h->part, &h->resid, &h->lo, &h->hi, &h->ub, &h->recB, &h->recF, &h->recS, &h->stage};
   for (auto b : bufs)
     if (*b) { (void)hipFree(*b); *b = nullptr; }
   int** ibufs[] = {&h->seg_start, &h->status, &h->iters, &h->nconv, &h->scan_range};
@@ -416,6 +439,8 @@ int admm_setup(admm_handle** out, const admm_problem* p, const admm_options* o_i
   h->L = p->N * h->nb;
   h->pitch = ((p->batch + 63) / 64) * 64;
   h->has_q = p->q != nullptr;
+  if (p->unorm)
+    for (int k = 0; k < (p->stage_bounds ? p->N : 1); ++k) h->has_soc = h->has_soc || std::isfinite(p->unorm[k]);
 
   // x-update segments: one (column-wave x segment) wave per SIMD (1024 SIMDs).  Measured on
   // MI355X: the x kernels run as fast at 1 wave/SIMD as at 2, and the scan's
@@ -443,6 +468,7 @@ int admm_setup(admm_handle** out, const admm_problem* p, const admm_options* o_i
       zr = ((zr + 3) / 4) * 4;
       if (zr < 4) zr = 4;
     }
+    if (h->has_soc) zr = ((zr + h->nb - 1) / h->nb) * h->nb;   // block-structured kernels: whole blocks per chunk
     h->zrows = zr;
     h->zchunks = (h->L + zr - 1) / zr;
   }
@@ -460,6 +486,7 @@ int admm_setup(admm_handle** out, const admm_problem* p, const admm_options* o_i
     h->pQN.assign(p->QN, p->QN + (size_t)p->n * p->n);
     h->plo.assign(p->lo, p->lo + nbd);
     h->phi.assign(p->hi, p->hi + nbd);
+    if (p->unorm) h->pun.assign(p->unorm, p->unorm + (p->stage_bounds ? p->N : 1));
     h->time_varying = p->time_varying;
     h->stage_bounds = p->stage_bounds;
   }
@@ -502,6 +529,7 @@ int admm_setup(admm_handle** out, const admm_problem* p, const admm_options* o_i
   TRY_RELEASE(dalloc(&h->resid, 5 * P));
   TRY_RELEASE(dalloc(&h->lo, L));
   TRY_RELEASE(dalloc(&h->hi, L));
+  TRY_RELEASE(dalloc(&h->ub, (size_t)h->N));
   TRY_RELEASE(dalloc(&h->recB, h->fac.recB.size()));
   TRY_RELEASE(dalloc(&h->recF, h->fac.recF.size()));
   TRY_RELEASE(dalloc(&h->recS, h->fac.recS.size()));
@@ -532,6 +560,10 @@ int admm_setup(admm_handle** out, const admm_problem* p, const admm_options* o_i
     }
     HIP_TRY_RELEASE(hipMemcpy(h->lo, lo.data(), sizeof(double) * L, hipMemcpyHostToDevice));
     HIP_TRY_RELEASE(hipMemcpy(h->hi, hi.data(), sizeof(double) * L, hipMemcpyHostToDevice));
+    std::vector<double> ub(h->N, INFINITY);
+    if (p->unorm)
+      for (int k = 0; k < h->N; ++k) ub[k] = p->unorm[p->stage_bounds ? k : 0];
+    HIP_TRY_RELEASE(hipMemcpy(h->ub, ub.data(), sizeof(double) * h->N, hipMemcpyHostToDevice));
   }
   HIP_TRY_RELEASE(hipMemcpy(h->recB, h->fac.recB.data(), sizeof(double) * h->fac.recB.size(), hipMemcpyHostToDevice));
   HIP_TRY_RELEASE(hipMemcpy(h->recF, h->fac.recF.data(), sizeof(double) * h->fac.recF.size(), hipMemcpyHostToDevice));
@@ -575,6 +607,7 @@ static int set_rho_internal(admm_handle* h, double rho_new) {
   p.time_varying = h->time_varying; p.stage_bounds = h->stage_bounds;
   p.A = h->pA.data(); p.B = h->pB.data(); p.Q = h->pQ.data(); p.R = h->pR.data(); p.QN = h->pQN.data();
   p.lo = h->plo.data(); p.hi = h->phi.data();
+  p.unorm = h->pun.empty() ? nullptr : h->pun.data();
   admm::Factor f;
   std::string err;
   int rc = admm::factorise(p, rho_new, h->S, f, err);

@@ -11,6 +11,7 @@ struct XLaunch {
   hipStream_t stream;
   int n, m, S, pitch;
   bool has_q;
+  bool has_soc;                 // thrust-magnitude bound on some stage: SOC kernel forms
   double rho, alpha;
   const double *z, *y, *q;      // state in (z, y) form and the linear term
   double *v, *w;                // state in v-form; materialised w

@@ -180,6 +180,9 @@ int factorise(const admm_problem& p, double rho, int segments, Factor& f, std::s
       rf[lf.LO + r] = blo[r];
       rf[lf.HI + r] = bhi[r];
     }
+    const double ub = p.unorm ? p.unorm[p.stage_bounds ? k : 0] : INFINITY;   // thrust-magnitude bound
+    rb[lb.UB] = ub;
+    rf[lf.UB] = ub;
   }
 
   // ---- segment algebra ----

@@ -175,6 +175,20 @@ __device__ __forceinline__ void lds_matvec_acc(const double* blk, const double (
   }
 }
 
+// Thrust-magnitude (second-order-cone) projection factor of one block: the control
+// rows u of a stage with a finite bound ub are scaled onto the ball ||u||_2 <= ub,
+//     c = ||u|| > ub ? ub / ||u|| : 1,      z_u = c u.
+// sqrt and the division are the correctly rounded fp64 forms, accumulated in row order with fma --
+// the same operations as the CPU oracle.
+template <int NU, int NB>
+__device__ __forceinline__ double soc_scale(const double (&vblk)[NB], double ub) {
+  double ss = 0.0;
+#pragma unroll
+  for (int j = 0; j < NU; ++j) ss = fma(vblk[j], vblk[j], ss);
+  const double nrm = sqrt(ss);
+  return nrm > ub ? ub / nrm : 1.0;
+}
+
 // ---------------------------------------------------------------------------
 // State compression ("v-form").  After any z-update,
 //     z = clip(v, lo, hi),   y = v - z        with  v = w^ + y_old
@@ -199,7 +213,7 @@ __device__ __forceinline__ void lds_matvec_acc(const double* blk, const double (
 // HBM per stacked element: VFORM: read v 8 (+8 with q), write d 8 m/(n+m);
 // otherwise read z, y 16.
 // ---------------------------------------------------------------------------
-template <int NX, int NU, bool HASQ, bool VFORM>
+template <int NX, int NU, bool HASQ, bool VFORM, bool SOC>
 __global__ __launch_bounds__(XB_THREADS) ADMM_X_OCCUPANCY void xb_kernel(
     const double* __restrict__ z, const double* __restrict__ y, const double* __restrict__ q,
     const double* __restrict__ recB, const int* __restrict__ seg_start_,
@@ -266,16 +280,23 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_X_OCCUPANCY void xb_kernel(
         if (k < klo) break;
         const double* rb = rec + (k - klo) * RB;     // wave-uniform address: LDS broadcast reads
         double mLO[even_up(NB)], mHI[even_up(NB)];
+        double cs = 1.0;
+        bool soc = false;
         if (VFORM) {
           lds_block(rb + LB.LO, mLO);
           lds_block(rb + LB.HI, mHI);
+          if (SOC) {                                 // compiled only for problems with a thrust-magnitude bound
+            const double ub = rb[LB.UB];
+            soc = ub < INFINITY;                     // wave-uniform
+            if (soc) cs = soc_scale<NU, NB>(lz[j], ub);
+          }
         }
         double g[NB];
 #pragma unroll
         for (int r = 0; r < NB; ++r) {
           double zz = lz[j][r], yy;
           if (VFORM) {
-            zz = fmin(fmax(lz[j][r], mLO[r]), mHI[r]);
+            zz = (SOC && soc && r < NU) ? lz[j][r] * cs : fmin(fmax(lz[j][r], mLO[r]), mHI[r]);
             yy = lz[j][r] - zz;
           } else {
             yy = ly[j][r];
@@ -657,7 +678,7 @@ __global__ __launch_bounds__(XB_THREADS) void xf_kernel(
 // Algorithmic HBM bytes per stacked element, fp64, steady state (VIN):
 //     d read 8 m/(n+m) + v read 8 + v+ written 8        (= 18.67 for n = 6, m = 3)
 // ---------------------------------------------------------------------------
-template <int NX, int NU, bool RESID, bool RELAX, bool VIN>
+template <int NX, int NU, bool RESID, bool RELAX, bool VIN, bool SOC>
 __global__ __launch_bounds__(XB_THREADS) ADMM_X_OCCUPANCY void xfz_kernel(
     const double* __restrict__ dbuf, const double* __restrict__ tin, const double* __restrict__ xin,
     const double* __restrict__ recF, const int* __restrict__ seg_start_,
@@ -782,12 +803,33 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_X_OCCUPANCY void xfz_kernel(
         // split into rollout | row | row | ... each region gets a latency-aware schedule.
         __builtin_amdgcn_sched_barrier(0);
         const unsigned r0 = (unsigned)(k - k0) * NB * PB;
+        const double ub = SOC ? rf[LF.UB] : INFINITY;
+        const bool soc = SOC && ub < INFINITY;   // wave-uniform: thrust-magnitude bound on this stage's control rows
+        double cs_old = 1.0, cs_new = 1.0;
+        double vnew[NB];
+        if (SOC && soc) {
+          if (VIN) cs_old = soc_scale<NU, NB>(c0, ub);
+          if (RESID) {                           // z+ needs ||v+_u||: form the control rows of v+ first
+#pragma unroll
+            for (int r = 0; r < NU; ++r) {
+              double zo, yo;
+              if (VIN) { zo = c0[r] * cs_old; yo = c0[r] - zo; } else { yo = c0[r]; zo = NEEDZ ? c1[r] : 0.0; }
+              double wh = wv[r];
+              if (RELAX) wh = fma(alpha, wv[r], (1.0 - alpha) * zo);
+              vnew[r] = wh + yo;
+            }
+#pragma unroll
+            for (int r = NU; r < NB; ++r) vnew[r] = 0.0;
+            cs_new = soc_scale<NU, NB>(vnew, ub);
+          }
+        }
 #pragma unroll
         for (int r = 0; r < NB; ++r) {
           const double l = rf[LF.LO + r], h = rf[LF.HI + r];
+          const bool ball = SOC && soc && r < NU;
           double zo, yo;                       // state before this z-update
           if (VIN) {
-            zo = fmin(fmax(c0[r], l), h);
+            zo = ball ? c0[r] * cs_old : fmin(fmax(c0[r], l), h);
             yo = c0[r] - zo;
           } else {
             yo = c0[r];
@@ -798,7 +840,7 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_X_OCCUPANCY void xfz_kernel(
           const double vn = wh + yo;
           if (st) vv.store(vn, lb, r0 + r * PB);
           if (RESID) {
-            const double zn = fmin(fmax(vn, l), h);
+            const double zn = ball ? vn * cs_new : fmin(fmax(vn, l), h);
             const double yn = vn - zn;
             const double dr = wv[r] - zn, ds = zn - zo;
             a_r = fma(dr, dr, a_r);
@@ -964,6 +1006,150 @@ __global__ __launch_bounds__(Z_THREADS) void zdual_kernel(
     *reinterpret_cast<double2*>(part + o + 2 * P) = a_w;
     *reinterpret_cast<double2*>(part + o + 3 * P) = a_z;
     *reinterpret_cast<double2*>(part + o + 4 * P) = a_y;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Block-structured forms of zdual_kernel / v_to_zy_kernel for problems with a thrust-magnitude
+// bound: the projection of a stage's control rows needs their joint norm, so a
+// chunk is a whole number of blocks (zrows % nb == 0) and each block is visited twice -- once
+// over its m control rows for ||v_u|| (the re-read hits L1/L2), once to apply.  Unfused path and
+// read-out only; the fused xfz / xb kernels do the same work on register-resident blocks.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double2 soc_scale2(double2 ss, double ub) {
+  double2 c;
+  const double nx = sqrt(ss.x), ny = sqrt(ss.y);
+  c.x = nx > ub ? ub / nx : 1.0;
+  c.y = ny > ub ? ub / ny : 1.0;
+  return c;
+}
+
+template <bool RESID, bool RELAX>
+__global__ __launch_bounds__(Z_THREADS) void zdual_soc_kernel(
+    const double* __restrict__ w, double* __restrict__ z, double* __restrict__ y,
+    const double* __restrict__ lo_, const double* __restrict__ hi_, const double* __restrict__ ub_,
+    double* __restrict__ part, double alpha, int L, int zrows, int pitch, int nb, int m) {
+  const int col = (blockIdx.x * Z_THREADS + threadIdx.x) * 2;
+  if (col >= pitch) return;
+  const int chunk = blockIdx.y;
+  const int r_begin = chunk * zrows;
+  const int r_end = (r_begin + zrows < L) ? r_begin + zrows : L;
+  const size_t P = (size_t)pitch;
+  cdouble_p lo = as_const(lo_);
+  cdouble_p hi = as_const(hi_);
+  cdouble_p ubv = as_const(ub_);
+  double2 a_r = {0, 0}, a_s = {0, 0}, a_w = {0, 0}, a_z = {0, 0}, a_y = {0, 0};
+  for (int rb = r_begin; rb < r_end; rb += nb) {
+    const double ub = ubv[rb / nb];
+    const bool soc = ub < INFINITY;
+    double2 cs = {1.0, 1.0};
+    if (soc) {
+      double2 ss = {0.0, 0.0};
+      for (int j = 0; j < m; ++j) {
+        const size_t o = (size_t)(rb + j) * P + col;
+        const double2 wv = *reinterpret_cast<const double2*>(w + o);
+        const double2 yv = *reinterpret_cast<const double2*>(y + o);
+        double2 wh = wv;
+        if (RELAX) {
+          const double2 zv = *reinterpret_cast<const double2*>(z + o);
+          wh.x = fma(alpha, wv.x, (1.0 - alpha) * zv.x);
+          wh.y = fma(alpha, wv.y, (1.0 - alpha) * zv.y);
+        }
+        const double vx = wh.x + yv.x, vy = wh.y + yv.y;
+        ss.x = fma(vx, vx, ss.x);
+        ss.y = fma(vy, vy, ss.y);
+      }
+      cs = soc_scale2(ss, ub);
+    }
+    for (int r = 0; r < nb; ++r) {
+      const int row = rb + r;
+      const size_t o = (size_t)row * P + col;
+      const double2 wv = *reinterpret_cast<const double2*>(w + o);
+      const double2 yv = *reinterpret_cast<const double2*>(y + o);
+      double2 zv = {0, 0};
+      if (RESID || RELAX) zv = *reinterpret_cast<const double2*>(z + o);
+      const double l = lo[row], h = hi[row];
+      double2 wh = wv;
+      if (RELAX) {
+        wh.x = fma(alpha, wv.x, (1.0 - alpha) * zv.x);
+        wh.y = fma(alpha, wv.y, (1.0 - alpha) * zv.y);
+      }
+      double2 v, zn, yn;
+      v.x = wh.x + yv.x;
+      v.y = wh.y + yv.y;
+      if (soc && r < m) {
+        zn.x = v.x * cs.x;
+        zn.y = v.y * cs.y;
+      } else {
+        zn.x = fmin(fmax(v.x, l), h);
+        zn.y = fmin(fmax(v.y, l), h);
+      }
+      yn.x = v.x - zn.x;
+      yn.y = v.y - zn.y;
+      *reinterpret_cast<double2*>(z + o) = zn;
+      *reinterpret_cast<double2*>(y + o) = yn;
+      if (RESID) {
+        double dx = wv.x - zn.x, dy = wv.y - zn.y;
+        a_r.x = fma(dx, dx, a_r.x); a_r.y = fma(dy, dy, a_r.y);
+        dx = zn.x - zv.x; dy = zn.y - zv.y;
+        a_s.x = fma(dx, dx, a_s.x); a_s.y = fma(dy, dy, a_s.y);
+        a_w.x = fma(wv.x, wv.x, a_w.x); a_w.y = fma(wv.y, wv.y, a_w.y);
+        a_z.x = fma(zn.x, zn.x, a_z.x); a_z.y = fma(zn.y, zn.y, a_z.y);
+        a_y.x = fma(yn.x, yn.x, a_y.x); a_y.y = fma(yn.y, yn.y, a_y.y);
+      }
+    }
+  }
+  if (RESID) {
+    const size_t o = (size_t)chunk * 5 * P + col;
+    *reinterpret_cast<double2*>(part + o + 0 * P) = a_r;
+    *reinterpret_cast<double2*>(part + o + 1 * P) = a_s;
+    *reinterpret_cast<double2*>(part + o + 2 * P) = a_w;
+    *reinterpret_cast<double2*>(part + o + 3 * P) = a_z;
+    *reinterpret_cast<double2*>(part + o + 4 * P) = a_y;
+  }
+}
+
+static __global__ __launch_bounds__(Z_THREADS) void v_to_zy_soc_kernel(
+    const double* __restrict__ v, double* __restrict__ z, double* __restrict__ y,
+    const double* __restrict__ lo_, const double* __restrict__ hi_, const double* __restrict__ ub_,
+    int L, int zrows, int pitch, int nb, int m) {
+  const int col = (blockIdx.x * Z_THREADS + threadIdx.x) * 2;
+  if (col >= pitch) return;
+  const int r_begin = blockIdx.y * zrows;
+  const int r_end = (r_begin + zrows < L) ? r_begin + zrows : L;
+  cdouble_p lo = as_const(lo_);
+  cdouble_p hi = as_const(hi_);
+  cdouble_p ubv = as_const(ub_);
+  for (int rb = r_begin; rb < r_end; rb += nb) {
+    const double ub = ubv[rb / nb];
+    const bool soc = ub < INFINITY;
+    double2 cs = {1.0, 1.0};
+    if (soc) {
+      double2 ss = {0.0, 0.0};
+      for (int j = 0; j < m; ++j) {
+        const double2 vv = *reinterpret_cast<const double2*>(v + (size_t)(rb + j) * pitch + col);
+        ss.x = fma(vv.x, vv.x, ss.x);
+        ss.y = fma(vv.y, vv.y, ss.y);
+      }
+      cs = soc_scale2(ss, ub);
+    }
+    for (int r = 0; r < nb; ++r) {
+      const int row = rb + r;
+      const size_t o = (size_t)row * pitch + col;
+      const double2 vv = *reinterpret_cast<const double2*>(v + o);
+      double2 zz, yy;
+      if (soc && r < m) {
+        zz.x = vv.x * cs.x;
+        zz.y = vv.y * cs.y;
+      } else {
+        zz.x = fmin(fmax(vv.x, lo[row]), hi[row]);
+        zz.y = fmin(fmax(vv.y, lo[row]), hi[row]);
+      }
+      yy.x = vv.x - zz.x;
+      yy.y = vv.y - zz.y;
+      *reinterpret_cast<double2*>(z + o) = zz;
+      *reinterpret_cast<double2*>(y + o) = yy;
+    }
   }
 }
 

@@ -11,9 +11,10 @@ namespace admm {
 
 constexpr int even_up(int v) { return (v + 1) & ~1; }
 
-// Backward record:  AT [n][n] | BT [m][n] | SI [m][m] | KT [n][m] | OM [n][m] | LO [m+n] | HI [m+n]
+// Backward record:  AT [n][n] | BT [m][n] | SI [m][m] | KT [n][m] | OM [n][m] | LO [m+n] | HI [m+n] | UB [1]
+// (UB = thrust-magnitude bound of the stage, +inf when the control rows use their box)
 struct RecBLayout {
-  int AT, BT, SI, KT, OM, LO, HI, SIZE;
+  int AT, BT, SI, KT, OM, LO, HI, UB, SIZE;
 };
 constexpr RecBLayout rec_b_layout(int n, int m) {
   RecBLayout l{};
@@ -24,13 +25,14 @@ constexpr RecBLayout rec_b_layout(int n, int m) {
   l.OM = l.KT + even_up(n * m);
   l.LO = l.OM + even_up(n * m);
   l.HI = l.LO + even_up(n + m);
-  l.SIZE = l.HI + even_up(n + m);
+  l.UB = l.HI + even_up(n + m);
+  l.SIZE = l.UB + 2;
   return l;
 }
 
-// Forward record:  PSI [m][n] | K [m][n] | A [n][n] | B [n][m] | LO [m+n] | HI [m+n]
+// Forward record:  PSI [m][n] | K [m][n] | A [n][n] | B [n][m] | LO [m+n] | HI [m+n] | UB [1]
 struct RecFLayout {
-  int PSI, K, A, B, LO, HI, SIZE;
+  int PSI, K, A, B, LO, HI, UB, SIZE;
 };
 constexpr RecFLayout rec_f_layout(int n, int m) {
   RecFLayout l{};
@@ -40,7 +42,8 @@ constexpr RecFLayout rec_f_layout(int n, int m) {
   l.B = l.A + even_up(n * n);
   l.LO = l.B + even_up(n * m);
   l.HI = l.LO + even_up(n + m);
-  l.SIZE = l.HI + even_up(n + m);
+  l.UB = l.HI + even_up(n + m);
+  l.SIZE = l.UB + 2;
   return l;
 }
 

@@ -39,6 +39,9 @@ class Problem:
     lo: np.ndarray                # (m + n,) or (N, m + n); -inf allowed
     hi: np.ndarray                # (m + n,) or (N, m + n); +inf allowed
     q: Optional[np.ndarray] = None  # (batch, L) or None
+    # thrust-magnitude bound ||u_k||_2 <= unorm (scalar, or (N,) when the box is per stage); None = off.
+    # Where finite, the box of the control rows must be (-inf, inf).
+    unorm: Optional[np.ndarray] = None
     name: str = ""
 
     @property
@@ -94,6 +97,17 @@ class Problem:
             raise ValueError("bounds must satisfy lo <= hi and contain no NaN")
         if self.q is not None and self.q.shape != (self.batch, self.L):
             raise ValueError("q must be (batch, L)")
+        if self.unorm is not None:
+            un = np.asarray(self.unorm, np.float64)
+            if un.ndim > 1 or (un.ndim == 1 and (self.lo.ndim != 2 or un.shape != (N,))):
+                raise ValueError("unorm must be a scalar, or (N,) together with per-stage bounds")
+            if np.any(np.isnan(un)) or np.any(un <= 0):
+                raise ValueError("unorm must be positive (inf = off)")
+            lo_u = np.atleast_2d(self.lo)[:, :m]           # (1 or N, m)
+            hi_u = np.atleast_2d(self.hi)[:, :m]
+            fin = np.isfinite(np.broadcast_to(un, (lo_u.shape[0],)))
+            if np.any(np.isfinite(lo_u[fin])) or np.any(np.isfinite(hi_u[fin])):
+                raise ValueError("control rows must be unbounded (-inf, inf) where unorm is finite")
         for a in (self.A, self.B, self.Q, self.R, self.QN, self.x0):
             if not np.all(np.isfinite(a)):
                 raise ValueError("non-finite problem data")
@@ -157,13 +171,15 @@ def mean_motion(mu: float = MU_EARTH, a: float = A_REF) -> float:
 
 
 def cw_rendezvous(N: int = 1000, batch: int = 1, seed0: int = SEED0,
-                  u_max: float = 0.2) -> Problem:
+                  u_max: float = 0.2, thrust_norm: bool = False) -> Problem:
     """BASELINE.json configs[1..3]: orbit-transfer (rendezvous) QP, n = 6, m = 3.
 
     Horizon = one orbital period, dt = 2 pi / N in units of 1/mean-motion; length
     unit 1 km, so velocities are km * mean-motion and thrust accelerations are
     km * mean-motion^2: all variables are O(1).  Input box |u_i| <= u_max, states
-    unbounded, q = 0.  x0 of instance i ~ U(box) from default_rng(seed0 + i)."""
+    unbounded, q = 0.  x0 of instance i ~ U(box) from default_rng(seed0 + i).
+    thrust_norm=True replaces the input box by the thrust-magnitude bound ||u_k||_2 <= u_max
+    (the natural constraint of a single gimballed thruster)."""
     dt = 2.0 * np.pi / N
     A, B = cw_matrices(dt)
     Q = np.diag([1.0, 1.0, 1.0, 0.1, 0.1, 0.1]) * dt
@@ -175,6 +191,9 @@ def cw_rendezvous(N: int = 1000, batch: int = 1, seed0: int = SEED0,
         rng = np.random.default_rng(seed0 + i)
         x0[i] = rng.uniform(-box, box)
     inf = np.inf
+    if thrust_norm:
+        return Problem(N=N, A=A, B=B, Q=Q, R=R, QN=QN, x0=x0, lo=np.full(9, -inf), hi=np.full(9, inf),
+                       unorm=np.float64(u_max), name=f"cw_rendezvous_soc_N{N}_b{batch}")
     lo = np.array([-u_max] * 3 + [-inf] * 6)
     hi = np.array([u_max] * 3 + [inf] * 6)
     return Problem(N=N, A=A, B=B, Q=Q, R=R, QN=QN, x0=x0, lo=lo, hi=hi,
@@ -210,7 +229,7 @@ def cw_formation(N: int = 1000, batch: int = 1, seed0: int = SEED0, u_max: float
 
 
 def random_ltv(N: int, n: int, m: int, batch: int, seed: int = SEED0,
-               with_q: bool = True, state_bounds: bool = True) -> Problem:
+               with_q: bool = True, state_bounds: bool = True, thrust_norm: bool = False) -> Problem:
     """Random stable-ish time-varying problem with full weights, per-stage
     bounds and a linear term: exercises every code path in the parity tests."""
     rng = np.random.default_rng(seed)
@@ -234,5 +253,12 @@ def random_ltv(N: int, n: int, m: int, batch: int, seed: int = SEED0,
         lo[:, m:] = -np.inf
         hi[:, m:] = np.inf
     q = 0.1 * rng.standard_normal((batch, N * (n + m))) if with_q else None
-    return Problem(N=N, A=A, B=B, Q=Q, R=R, QN=QN, x0=x0, lo=lo, hi=hi, q=q,
+    unorm = None
+    if thrust_norm:      # per-stage thrust-magnitude bounds on most stages, box on the rest
+        unorm = rng.uniform(0.15, 0.7, N)
+        unorm[::4] = np.inf
+        soc = np.isfinite(unorm)
+        lo[soc, :m] = -np.inf
+        hi[soc, :m] = np.inf
+    return Problem(N=N, A=A, B=B, Q=Q, R=R, QN=QN, x0=x0, lo=lo, hi=hi, q=q, unorm=unorm,
                    name=f"random_ltv_N{N}_n{n}_m{m}_b{batch}")

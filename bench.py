@@ -52,7 +52,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=4096, help="QPs per GPU")
     ap.add_argument("--horizon", type=int, default=1000)
-    ap.add_argument("--workload", choices=["cw_rendezvous", "cw_formation"], default="cw_rendezvous",
+    ap.add_argument("--workload", choices=["cw_rendezvous", "cw_formation", "cw_rendezvous_soc"], default="cw_rendezvous",
                     help="cw_rendezvous = configs[1..3] (n=6, m=3, the metric's workload); cw_formation = configs[4]'s "
                          "shape (n=12, m=6) in fp64 -- a side measurement, never the reported metric's config")
     ap.add_argument("--segments", type=int, default=0)
@@ -140,8 +140,11 @@ def main():
     # global problem = batch * world QPs; this rank's contiguous shard
     gbatch = a.batch * world
     lo_i, hi_i = pkg.shard_bounds(gbatch, world, rank)
-    make = pkg.cw_rendezvous if a.workload == "cw_rendezvous" else pkg.cw_formation
-    full = make(N=a.horizon, batch=hi_i - lo_i, seed0=pkg.SEED0 + lo_i)
+    if a.workload == "cw_rendezvous_soc":      # side measurement: thrust-magnitude bound instead of the input box
+        full = pkg.cw_rendezvous(N=a.horizon, batch=hi_i - lo_i, seed0=pkg.SEED0 + lo_i, thrust_norm=True)
+    else:
+        make = pkg.cw_rendezvous if a.workload == "cw_rendezvous" else pkg.cw_formation
+        full = make(N=a.horizon, batch=hi_i - lo_i, seed0=pkg.SEED0 + lo_i)
     opt = pkg.Options(rho=0.05, check_interval=1, segments=a.segments, zrows=a.zrows, device=dev_index)
     solver = pkg.Solver(full, opt)
     geo = solver.geometry()
@@ -247,8 +250,8 @@ def main():
             "config": {"workload": (f"configs[2]: batch of {a.batch} independent N={a.horizon} n=6 m=3 "
                                     f"Clohessy-Wiltshire QPs per GPU, residuals every iteration")
                        if a.workload == "cw_rendezvous" else
-                       (f"SIDE MEASUREMENT, configs[4] shape in fp64: batch of {a.batch} N={a.horizon} n=12 m=6 "
-                        f"two-craft Clohessy-Wiltshire QPs per GPU, residuals every iteration"),
+                       (f"SIDE MEASUREMENT ({a.workload}): batch of {a.batch} N={a.horizon} n={n_} m={m_} "
+                        f"Clohessy-Wiltshire QPs per GPU, residuals every iteration"),
                        "N": a.horizon, "n": n_, "m": m_, "batch_per_gpu": a.batch, "global_batch": gbatch,
                        "rho": 0.05, "sharding": f"batch/{world}, no collective in the iteration",
                        **geo},

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ADMM_HIP_ABI_VERSION 2
+#define ADMM_HIP_ABI_VERSION 3
 
 typedef enum admm_status {
   ADMM_OK = 0,
@@ -44,7 +44,7 @@ typedef enum admm_status {
 } admm_status;
 
 /* minimise  1/2 sum_k [u_k' R u_k + x_{k+1}' Q_{k+1} x_{k+1}] + q' w
- * s.t.      x_{k+1} = A_k x_k + B_k u_k,  x_0 given,   lo <= w <= hi
+ * s.t.      x_{k+1} = A_k x_k + B_k u_k,  x_0 given,   lo <= w <= hi   [and/or ||u_k||_2 <= unorm_k]
  * Dynamics, weights and the box are shared by the whole batch; x0 and q are
  * per instance. */
 typedef struct admm_problem {
@@ -63,6 +63,11 @@ typedef struct admm_problem {
   const double* lo;       /* block order (u then x); -inf allowed */
   const double* hi;       /* +inf allowed */
   const double* q;        /* L*batch linear cost, or NULL for q = 0 */
+  /* Optional thrust-magnitude (second-order-cone) constraint ||u_k||_2 <= unorm_k on the control
+   * rows, replacing their box: NULL = off; otherwise 1 entry (stage_bounds = 0) or N entries
+   * (stage_bounds = 1), +inf = no constraint at that stage.  Where it is finite the box of the
+   * control rows must be (-inf, +inf); the state rows keep their box. */
+  const double* unorm;
 } admm_problem;
 
 typedef struct admm_options {

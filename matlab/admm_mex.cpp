@@ -108,6 +108,10 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     p.Q = dbl(field(P, "Q", true), "Q"); p.R = dbl(field(P, "R", true), "R"); p.QN = dbl(field(P, "QN", true), "QN");
     p.x0 = dbl(x0, "x0"); p.lo = dbl(lo, "lo"); p.hi = dbl(hi, "hi");
     p.q = dbl(q, "q");
+    const mxArray* un = field(P, "unorm", false);     // thrust-magnitude bound, optional: 1 or N entries
+    p.unorm = dbl(un, "unorm");
+    if (p.unorm && static_cast<int32_t>(mxGetNumberOfElements(un)) != (p.stage_bounds ? p.N : 1))
+      fail("admm:input", "unorm must have 1 entry, or N entries together with per-stage bounds");
     const int L = p.N * (p.n + p.m);
     if (p.q && (static_cast<int>(mxGetM(q)) != L || static_cast<int32_t>(mxGetN(q)) != p.batch)) fail("admm:input", "q must be L x batch");
     admm_options o;

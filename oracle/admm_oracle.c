@@ -251,14 +251,32 @@ int oracle_solve(const admm_problem* p, const admm_options* o, int32_t stop,
                    p->x0 + (size_t)b * n, wb, d);
       free(d);
       double a_r = 0, a_s = 0, a_w = 0, a_z = 0, a_y = 0;
+      double cscale = 1.0;      /* thrust-magnitude projection factor of the current block */
+      int soc = 0;
       for (size_t e = 0; e < L; ++e) {
         const size_t blk = e / nb, row = e % nb;
         const double lo = p->lo[(p->stage_bounds ? blk * nb : 0) + row];
         const double hi = p->hi[(p->stage_bounds ? blk * nb : 0) + row];
+        if (row == 0) {           /* block start: ||v_u|| of this block decides the scaling of its control rows */
+          const double ub = p->unorm ? p->unorm[p->stage_bounds ? blk : 0] : INFINITY;
+          soc = isfinite(ub);
+          cscale = 1.0;
+          if (soc) {
+            double ss = 0.0;
+            for (int j = 0; j < m; ++j) {
+              const double wj = wb[e + j], zj = zb[e + j];
+              const double whj = (alpha == 1.0) ? wj : alpha * wj + (1.0 - alpha) * zj;
+              const double vj = whj + yb[e + j];
+              ss = fma(vj, vj, ss);
+            }
+            const double nrm = sqrt(ss);
+            if (nrm > ub) cscale = ub / nrm;
+          }
+        }
         const double wv = wb[e], zo = zb[e];
         const double wh = (alpha == 1.0) ? wv : alpha * wv + (1.0 - alpha) * zo;
         const double v = wh + yb[e];
-        const double zn = fmin(fmax(v, lo), hi);
+        const double zn = (soc && (int)row < m) ? ((cscale == 1.0) ? v : v * cscale) : fmin(fmax(v, lo), hi);
         const double yn = v - zn;
         zb[e] = zn; yb[e] = yn;
         if (check) {

@@ -122,11 +122,35 @@ def x_update(f: Factor, g, x0):
     return w.reshape(batch, N * nb)
 
 
-def z_update(w, z, y, lo, hi, alpha=1.0):
+def expand_unorm(unorm, N):
+    """None / scalar / (N,) -> (N,) with inf = off."""
+    if unorm is None:
+        return np.full(N, np.inf)
+    return np.broadcast_to(np.asarray(unorm, np.float64), (N,)).copy()
+
+
+def project(v, lo, hi, unorm=None, m=0):
+    """Projection onto the constraint set: box on every row, except that
+    the control rows of a stage with a finite thrust bound are scaled onto the ball
+    ||u_k||_2 <= unorm_k.  v: (batch, L);  unorm: (N,) or None."""
+    zn = np.minimum(np.maximum(v, lo), hi)
+    if unorm is not None and np.isfinite(unorm).any():
+        N = unorm.shape[0]
+        nb = v.shape[1] // N
+        vb = v.reshape(v.shape[0], N, nb)
+        zb = zn.reshape(v.shape[0], N, nb)
+        nrm = np.sqrt(np.sum(vb[:, :, :m] ** 2, axis=2))
+        scale = np.where(nrm > unorm[None, :], unorm[None, :] / np.where(nrm > 0, nrm, 1.0), 1.0)
+        soc = np.isfinite(unorm)
+        zb[:, soc, :m] = vb[:, soc, :m] * scale[:, soc, None]
+    return zn
+
+
+def z_update(w, z, y, lo, hi, alpha=1.0, unorm=None, m=0):
     """Fused z-update + dual ascent.  Returns z+, y+."""
     wh = alpha * w + (1.0 - alpha) * z if alpha != 1.0 else w
     v = wh + y
-    zn = np.minimum(np.maximum(v, lo), hi)
+    zn = project(v, lo, hi, unorm, m)
     yn = v - zn
     return zn, yn
 
@@ -165,7 +189,7 @@ class Result:
 def solve(A, B, Q, R, QN, x0, lo, hi, N, q=None, rho=1.0, alpha=1.0,
           eps_abs=1e-6, eps_rel=1e-6, max_iter=1000, check_interval=10,
           z0=None, y0=None, record=None, stop=True,
-          adapt_interval=0, adapt_max=16, adapt_mu=10.0, adapt_tau=2.0) -> Result:
+          adapt_interval=0, adapt_max=16, adapt_mu=10.0, adapt_tau=2.0, unorm=None) -> Result:
     """Run the batch loop.  All QPs iterate together until every one has met
     the stopping rule at a checked iteration (iterations that are multiples of
     ``check_interval``, and ``max_iter``), or ``max_iter`` is reached.
@@ -181,6 +205,7 @@ def solve(A, B, Q, R, QN, x0, lo, hi, N, q=None, rho=1.0, alpha=1.0,
     nb = n + m
     L = N * nb
     lo, hi = expand_bounds(lo, hi, N, nb)
+    un = None if unorm is None else expand_unorm(unorm, N)
     z = np.zeros((batch, L)) if z0 is None else np.array(z0, np.float64).reshape(batch, L)
     y = np.zeros((batch, L)) if y0 is None else np.array(y0, np.float64).reshape(batch, L)
     qq = None if q is None else np.asarray(q, np.float64).reshape(batch, L)
@@ -197,7 +222,7 @@ def solve(A, B, Q, R, QN, x0, lo, hi, N, q=None, rho=1.0, alpha=1.0,
         if qq is not None:
             g = g + qq
         w = x_update(f, g, x0)
-        zn, yn = z_update(w, z, y, lo, hi, alpha)
+        zn, yn = z_update(w, z, y, lo, hi, alpha, un, m)
         check = (it % check_interval == 0) or it == max_iter
         if check:
             r, s, nw, nz, ny = residuals(w, z, zn, yn, rho)

@@ -32,6 +32,7 @@ def unpack(rec, n, m):
     OM, o = take(rb, o, n, m)
     LO = rb[:, o:o + nb]; o += _even(nb)
     HI = rb[:, o:o + nb]; o += _even(nb)
+    UB = rb[:, o]; o += 2
     assert o == rb.shape[1]
     o = 0
     PSI, o = take(rf, o, m, n)
@@ -40,6 +41,8 @@ def unpack(rec, n, m):
     B, o = take(rf, o, n, m)
     assert np.array_equal(rf[:, o:o + nb], LO) and np.array_equal(rf[:, o + _even(nb):o + _even(nb) + nb], HI)
     o += 2 * _even(nb)
+    assert np.array_equal(rf[:, o], UB)
+    o += 2
     assert o == rf.shape[1]
     S = rs.shape[0]
     PHI = rs[:, :n * n].reshape(S, n, n)
@@ -48,7 +51,7 @@ def unpack(rec, n, m):
     AT, BT, SI, KT, OM, PSI, K, A, B = [np.asarray(x).reshape(N, r, c) for x, (r, c) in
                                         zip((AT, BT, SI, KT, OM, PSI, K, A, B),
                                             ((n, n), (m, n), (m, m), (n, m), (n, m), (m, n), (m, n), (n, n), (n, m)))]
-    return dict(AT=AT, BT=BT, SI=SI, KT=KT, OM=OM, PSI=PSI, K=K, A=A, B=B, PHI=PHI, XI=XI, TH=TH, LO=LO, HI=HI)
+    return dict(AT=AT, BT=BT, SI=SI, KT=KT, OM=OM, PSI=PSI, K=K, A=A, B=B, PHI=PHI, XI=XI, TH=TH, LO=LO, HI=HI, UB=UB)
 
 
 def x_update_segmented(rec, n, m, g, x0, scan="chain", return_parts=False):

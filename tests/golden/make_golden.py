@@ -34,13 +34,17 @@ def cut(name, p, rho, alpha, iters, solve_kw):
              rho=rho, alpha=alpha, iters=np.array(iters, np.int32))
     if p.q is not None:
         d["q"] = p.q
+    if p.unorm is not None:
+        d["unorm"] = np.asarray(p.unorm, np.float64)
     res = ar.solve(p.A, p.B, p.Q, p.R, p.QN, p.x0, p.lo, p.hi, p.N, q=p.q, rho=rho, alpha=alpha,
-                   max_iter=max(iters), stop=False, record=set(iters))
+                   max_iter=max(iters), stop=False, record=set(iters), unorm=p.unorm)
     for it, w, z, y in res.history:
         d[f"w_{it}"], d[f"z_{it}"], d[f"y_{it}"] = w, z, y
-    full = ar.solve(p.A, p.B, p.Q, p.R, p.QN, p.x0, p.lo, p.hi, p.N, q=p.q, rho=rho, alpha=alpha, **solve_kw)
+    full = ar.solve(p.A, p.B, p.Q, p.R, p.QN, p.x0, p.lo, p.hi, p.N, q=p.q, rho=rho, alpha=alpha, unorm=p.unorm,
+                    **solve_kw)
     d.update(solve_eps_abs=solve_kw["eps_abs"], solve_eps_rel=solve_kw["eps_rel"],
              solve_max_iter=solve_kw["max_iter"], solve_check_interval=solve_kw["check_interval"],
+             solve_adapt_interval=solve_kw.get("adapt_interval", 0), solve_rho_final=full.rho,
              solve_iters_run=full.iters_run, solve_iters=full.iters, solve_status=full.status,
              solve_z=full.z, solve_y=full.y, solve_w=full.w)
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **d)
@@ -55,6 +59,9 @@ def main():
         dict(eps_abs=1e-6, eps_rel=1e-6, max_iter=2000, check_interval=10))
     cut("golden_ltv_relaxed", pkg.random_ltv(N=16, n=4, m=2, batch=3, seed=77), 0.4, 1.5, [1, 5, 30],
         dict(eps_abs=1e-6, eps_rel=1e-6, max_iter=2000, check_interval=5))
+    # thrust-magnitude bound + adaptive rho
+    cut("golden_cw_soc_adaptive", pkg.cw_rendezvous(N=60, batch=4, thrust_norm=True), 0.05, 1.0, [1, 2, 10, 60],
+        dict(eps_abs=1e-6, eps_rel=1e-6, max_iter=3000, check_interval=10, adapt_interval=20))
 
 
 if __name__ == "__main__":

@@ -20,15 +20,16 @@ def test_oracles_reproduce_golden(name):
         it = int(it)
         c = oc.solve(p, rho=rho, alpha=alpha, max_iter=it, stop=False)
         n = ar.solve(p.A, p.B, p.Q, p.R, p.QN, p.x0, p.lo, p.hi, p.N, q=p.q, rho=rho, alpha=alpha,
-                     max_iter=it, stop=False)
+                     max_iter=it, stop=False, unorm=p.unorm)
         for k in "wzy":
             ref = d[f"{k}_{it}"]
             assert np.abs(c[k] - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
             assert np.abs(getattr(n, k) - ref).max() <= 1e-13 * max(1.0, np.abs(ref).max())
     kw = dict(eps_abs=float(d["solve_eps_abs"]), eps_rel=float(d["solve_eps_rel"]),
-              max_iter=int(d["solve_max_iter"]), check_interval=int(d["solve_check_interval"]))
+              max_iter=int(d["solve_max_iter"]), check_interval=int(d["solve_check_interval"]),
+              adapt_interval=int(d["solve_adapt_interval"]))
     c = oc.solve(p, rho=rho, alpha=alpha, **kw)
-    assert c["iters_run"] == int(d["solve_iters_run"])
+    assert c["iters_run"] == int(d["solve_iters_run"]) and c["rho"] == float(d["solve_rho_final"])
     np.testing.assert_array_equal(c["iters"], d["solve_iters"])
     np.testing.assert_array_equal(c["status"], d["solve_status"])
     assert np.abs(c["z"] - d["solve_z"]).max() <= 1e-11
@@ -59,11 +60,12 @@ def test_hip_reproduces_golden(gpu, name, flags):
                 ref = d[f"{k}_{it}"]
                 assert np.abs(got[k] - ref).max() <= 1e-10 * max(1.0, np.abs(ref).max()), (k, it)
     kw = dict(eps_abs=float(d["solve_eps_abs"]), eps_rel=float(d["solve_eps_rel"]),
-              max_iter=int(d["solve_max_iter"]), check_interval=int(d["solve_check_interval"]))
+              max_iter=int(d["solve_max_iter"]), check_interval=int(d["solve_check_interval"]),
+              adapt_interval=int(d["solve_adapt_interval"]))
     with pkg.Solver(p, pkg.Options(rho=rho, alpha=alpha, flags=flags, **kw)) as s:
         info = s.solve()
         _, z, y = s.get(False, True, True)
-    assert info.iters_run == int(d["solve_iters_run"])
+    assert info.iters_run == int(d["solve_iters_run"]) and info.rho == float(d["solve_rho_final"])
     assert (np.abs(info.iters - d["solve_iters"]) <= kw["check_interval"]).all()
     np.testing.assert_array_equal(info.status, d["solve_status"])
     assert np.abs(z - d["solve_z"]).max() <= 1e-10

@@ -228,6 +228,46 @@ def test_set_rho_keeps_the_multiplier(gpu):
         assert np.abs(got - ref).max() <= TOL * max(1.0, np.abs(ref).max())
 
 
+SOC_CASES = [
+    (lambda: pkg.cw_rendezvous(N=150, batch=70, thrust_norm=True), 0.05, 1.0),
+    (lambda: pkg.random_ltv(N=23, n=6, m=3, batch=5, seed=3, thrust_norm=True), 0.4, 1.0),
+    (lambda: pkg.random_ltv(N=31, n=4, m=2, batch=66, seed=4, thrust_norm=True), 0.3, 1.5),
+    (lambda: pkg.random_ltv(N=12, n=12, m=6, batch=3, seed=5, thrust_norm=True), 0.5, 1.0),
+    (lambda: pkg.random_ltv(N=9, n=3, m=1, batch=4, seed=6, thrust_norm=True), 0.5, 1.2),   # m = 1: |u| <= ub
+]
+
+
+@pytest.mark.parametrize("flags", [0, 2], ids=["fused", "unfused"])
+@pytest.mark.parametrize("idx", range(len(SOC_CASES)))
+def test_thrust_magnitude_constraint(gpu, idx, flags):
+    """||u_k||_2 <= unorm_k replaces the control box (projection = radial scaling).
+    Iterates, residuals and the full solve against the oracle, fused (register-resident blocks) and
+    unfused (block-structured standalone kernels) paths."""
+    make, rho, alpha = SOC_CASES[idx]
+    p = make()
+    with pkg.Solver(p, pkg.Options(rho=rho, alpha=alpha, flags=flags)) as s:
+        done = 0
+        for upto in (1, 2, 9, 30):
+            s.run(upto - done, residual_every=3)
+            done = upto
+            w, z, y = s.get()
+            ref = oc.solve(p, rho=rho, alpha=alpha, max_iter=upto, check_interval=3, eps_abs=0, eps_rel=0, stop=False)
+            for a, b in ((w, ref["w"]), (z, ref["z"]), (y, ref["y"])):
+                assert np.abs(a - b).max() <= TOL * max(1.0, np.abs(b).max()), (upto,)
+        r, sd, *_ = s.residuals()
+        assert np.abs(r - ref["r"]).max() <= 1e-10 and np.abs(sd - ref["s"]).max() <= 1e-10
+    un = ar.expand_unorm(p.unorm, p.N)
+    nr = np.linalg.norm(z.reshape(p.batch, p.N, p.nb)[:, :, :p.m], axis=2)
+    assert (nr <= un[None] * (1 + 1e-14)).all()
+    kw = dict(rho=rho, alpha=alpha, eps_abs=1e-6, eps_rel=1e-6, max_iter=1500, check_interval=10)
+    ref = oc.solve(p, **kw)
+    with pkg.Solver(p, pkg.Options(flags=flags, **kw)) as s:
+        info = s.solve()
+        _, z, _ = s.get(False, True, False)
+    assert info.iters_run == ref["iters_run"] and info.n_converged == int(ref["status"].sum())
+    assert np.abs(z - ref["z"]).max() <= TOL * max(1.0, np.abs(ref["z"]).max())
+
+
 def test_update_instances(gpu):
     """New x0 on an existing handle = fresh setup with that x0."""
     p = pkg.cw_rendezvous(N=80, batch=10)

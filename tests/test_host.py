@@ -64,6 +64,8 @@ int main(void) {
     (lambda: pkg.cw_rendezvous(N=300, batch=2), 0.05),
     (lambda: pkg.double_integrator(N=50, batch=2), 1.0),
     (lambda: pkg.random_ltv(N=12, n=12, m=6, batch=2, seed=19), 0.6),
+    (lambda: pkg.random_ltv(N=14, n=6, m=3, batch=2, seed=23, thrust_norm=True), 0.4),
+    (lambda: pkg.cw_rendezvous(N=40, batch=2, thrust_norm=True), 0.05),
 ])
 def test_host_factor_matches_oracles(lib, make, rho):
     p = make()
@@ -79,6 +81,7 @@ def test_host_factor_matches_oracles(lib, make, rho):
     u = unpack(hf, p.n, p.m)
     np.testing.assert_array_equal(u["LO"].reshape(-1), lo)      # the box rides in the stage records
     np.testing.assert_array_equal(u["HI"].reshape(-1), hi)
+    np.testing.assert_array_equal(u["UB"], ar.expand_unorm(p.unorm, p.N))
     assert hf["seg_start"][0] == 0 and hf["seg_start"][-1] == p.N
     assert (np.diff(hf["seg_start"]) > 0).all()
 
@@ -144,6 +147,13 @@ def test_input_validation_through_the_abi(lib):
     keep["lo"][0] = -1.0
     cp.batch = 0
     assert lib.admm_setup(C.byref(h), C.byref(cp), None) == 1
+    # thrust-magnitude bound: positive, and the control box must be open where it is finite
+    cp2, keep2 = _abi.marshal_problem(pkg.cw_rendezvous(N=10, batch=2, thrust_norm=True))
+    keep2["unorm"][0] = -1.0
+    assert lib.admm_setup(C.byref(h), C.byref(cp2), None) == 1 and b"unorm" in lib.admm_last_error()
+    keep2["unorm"][0] = 0.2
+    keep2["lo"][1] = -0.5
+    assert lib.admm_setup(C.byref(h), C.byref(cp2), None) == 1 and b"unbounded" in lib.admm_last_error()
     # unsupported dimensions are reported before any device is touched
     rc, msg = _setup_rc(lib, pkg.random_ltv(N=5, n=11, m=5, batch=2))
     assert rc == 2 and "supported" in msg

@@ -16,7 +16,7 @@ import oracle_c as oc
 
 
 def _solve_np(p, **kw):
-    return ar.solve(p.A, p.B, p.Q, p.R, p.QN, p.x0, p.lo, p.hi, p.N, q=p.q, **kw)
+    return ar.solve(p.A, p.B, p.Q, p.R, p.QN, p.x0, p.lo, p.hi, p.N, q=p.q, unorm=p.unorm, **kw)
 
 
 def test_x_update_matches_dense_kkt():
@@ -201,3 +201,95 @@ print("ok", run.value)
                UBSAN_OPTIONS="halt_on_error=1", OMP_NUM_THREADS="2")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode == 0 and out.stdout.startswith("ok"), out.stderr[-2000:]
+
+
+# ---------------------------------------------------------------------------
+# Thrust-magnitude (second-order-cone) constraint, DESIGN.md §2.7
+# ---------------------------------------------------------------------------
+
+def test_soc_projection_is_the_euclidean_projection():
+    rng = np.random.default_rng(0)
+    N, n, m = 7, 3, 3
+    un = np.array([0.5, np.inf, 0.2, 1.0, np.inf, 0.7, 0.3])
+    lo = np.tile(np.r_[np.full(m, -np.inf), -np.ones(n)], N)
+    hi = np.tile(np.r_[np.full(m, np.inf), np.ones(n)], N)
+    v = rng.standard_normal((50, N * (n + m))) * 1.5
+    z = ar.project(v, lo, hi, un, m)
+    zb, vb = z.reshape(50, N, n + m), v.reshape(50, N, n + m)
+    nr = np.linalg.norm(zb[:, :, :m], axis=2)
+    assert (nr <= un[None] * (1 + 1e-15)).all()                       # feasible
+    assert np.allclose(ar.project(z, lo, hi, un, m), z, atol=1e-15)  # idempotent
+    # optimality of the projection: <v - z, c - z> <= 0 for feasible c (variational inequality)
+    c = ar.project(rng.standard_normal(v.shape), lo, hi, un, m)
+    assert ((v - z) * (c - z)).sum(1).max() <= 1e-12
+    # stages without a bound keep the box (here: open) on the control rows
+    np.testing.assert_array_equal(zb[:, 1, :m], vb[:, 1, :m])
+
+
+def test_soc_qp_vs_scipy_slsqp():
+    """T2 for the ball constraint: a tiny instance solved by SciPy's SLSQP on the condensed problem."""
+    from scipy.optimize import minimize
+    rng = np.random.default_rng(5)
+    N, n, m = 6, 2, 2
+    A = np.array([[1.0, 0.3], [0.0, 1.0]])
+    B = np.array([[0.05, 0.0], [0.3, 0.2]])
+    inf = np.inf
+    p = pkg.Problem(N=N, A=A, B=B, Q=np.eye(n), R=0.1 * np.eye(m), QN=5 * np.eye(n), x0=np.array([[3.0, -1.0], [-2.0, 2.0]]),
+                    lo=np.full(n + m, -inf), hi=np.full(n + m, inf), unorm=np.float64(0.8))
+    res = _solve_np(p, rho=1.0, eps_abs=1e-10, eps_rel=1e-10, max_iter=50000, check_interval=10)
+    assert res.status.all()
+    Qbar = np.kron(np.eye(N), p.Q); Qbar[-n:, -n:] = p.QN
+    Rbar = np.kron(np.eye(N), p.R)
+    n_active = 0
+    for b in range(p.batch):
+        Sx, Su = _condense(p, b)
+        H = Rbar + Su.T @ Qbar @ Su
+        f = Su.T @ Qbar @ Sx @ p.x0[b]
+        cons = [{"type": "ineq", "fun": (lambda u, k=k: 0.8 ** 2 - u[k * m:(k + 1) * m] @ u[k * m:(k + 1) * m]),
+                 "jac": (lambda u, k=k: np.r_[np.zeros(k * m), -2 * u[k * m:(k + 1) * m], np.zeros((N - k - 1) * m)])}
+                for k in range(N)]
+        sol = minimize(lambda u: 0.5 * u @ H @ u + f @ u, np.zeros(N * m), jac=lambda u: H @ u + f, constraints=cons,
+                       method="SLSQP", options={"ftol": 1e-12, "maxiter": 1000})
+        u_admm = res.z[b].reshape(N, n + m)[:, :m].reshape(-1)
+        obj = lambda u: 0.5 * u @ H @ u + f @ u
+        # SLSQP may stop on its line search right at the optimum; what matters is that it found the same point
+        assert sol.success or abs(obj(sol.x) - obj(u_admm)) < 1e-9, sol.message
+        assert np.abs(u_admm - sol.x).max() < 1e-4
+        assert obj(u_admm) <= obj(sol.x) + 1e-8            # ADMM's point is at least as good (and feasible)
+        n_active += int((np.abs(np.linalg.norm(u_admm.reshape(N, m), axis=1) - 0.8) < 1e-7).sum())
+    assert n_active >= 2
+
+
+def test_soc_kkt_certificate():
+    """T3 for the ball: lambda_u = rho y_u lies in the normal cone of the ball at z_u."""
+    p = pkg.cw_rendezvous(N=50, batch=3, u_max=0.3, thrust_norm=True)
+    rho = 0.3
+    res = _solve_np(p, rho=rho, eps_abs=1e-10, eps_rel=1e-10, max_iter=60000, check_interval=20)
+    assert res.status.all()
+    for b in range(p.batch):
+        P, q, G, bvec = ar.dense_qp(p.A, p.B, p.Q, p.R, p.QN, p.x0[b], p.N)
+        z, lam = res.z[b], rho * res.y[b]
+        assert np.abs(G @ z - bvec).max() < 1e-6
+        nu, *_ = np.linalg.lstsq(G.T, -(P @ z + q + lam), rcond=None)
+        assert np.abs(P @ z + q + lam + G.T @ nu).max() < 1e-6
+        zu = z.reshape(p.N, 9)[:, :3]; lu = lam.reshape(p.N, 9)[:, :3]; lx = lam.reshape(p.N, 9)[:, 3:]
+        nr = np.linalg.norm(zu, axis=1)
+        assert (nr <= 0.3 + 1e-12).all() and np.abs(lx).max() < 1e-9
+        inside = nr < 0.3 - 1e-9
+        assert np.abs(lu[inside]).max(initial=0.0) < 1e-7                 # no multiplier inside the ball
+        on = ~inside
+        assert on.sum() >= 3
+        kappa = (lu[on] * zu[on]).sum(1) / (0.3 ** 2)
+        assert (kappa >= -1e-9).all() and np.abs(lu[on] - kappa[:, None] * zu[on]).max() < 1e-7   # lambda = kappa z, kappa >= 0
+
+
+def test_soc_c_oracle_matches_numpy():
+    for p, rho in ((pkg.cw_rendezvous(N=60, batch=5, thrust_norm=True), 0.05),
+                   (pkg.random_ltv(N=23, n=6, m=3, batch=5, seed=3, thrust_norm=True), 0.4)):
+        kw = dict(rho=rho, alpha=1.3, max_iter=200, check_interval=10)
+        c = oc.solve(p, **kw)
+        a = _solve_np(p, **kw)
+        assert c["iters_run"] == a.iters_run
+        np.testing.assert_array_equal(c["iters"], a.iters)
+        for k in "wzy":
+            assert np.abs(getattr(a, k) - c[k]).max() < 1e-12
