@@ -39,6 +39,7 @@ int fail(int code, const std::string& msg) {
 struct admm_handle {
   int N = 0, n = 0, m = 0, nb = 0, batch = 0, pitch = 0, L = 0;
   int S = 0, zrows = 0, zchunks = 0;
+  int scan_split = 1;            // split-K factor of the MFMA scan (small batches)
   int device = 0;
   bool has_q = false;
   bool has_soc = false;          // some stage has a finite thrust-magnitude bound
@@ -90,6 +91,9 @@ admm::XLaunch xlaunch_of(const admm_handle* h) {
   l.recB = h->recB; l.recF = h->recF; l.recS = h->recS; l.seg_start = h->seg_start;
   l.dbuf = h->dbuf; l.tseg = h->tseg; l.eseg = h->eseg; l.tin = h->tin; l.xin = h->xin; l.part = h->part;
   l.x0 = h->x0;
+  const bool chain = (h->opt.flags & ADMM_FLAG_SCAN_CHAIN) != 0;     // the chain scan writes slab 0 only
+  l.nsplit = chain ? 1 : h->scan_split;
+  l.split_stride = (size_t)h->fac.scanM * h->pitch;
   return l;
 }
 
@@ -120,9 +124,10 @@ static_assert(admm::SCAN_KALIGN == 2 * admm::SCAN_U, "host range alignment must 
 
 int launch_xscan_mfma(admm_handle* h) {
   const int mtiles = h->fac.scanM / 16, ngroups = mtiles / admm::SCAN_MT;
-  dim3 grid(h->pitch / 64, ngroups), block(256);
+  dim3 grid(h->pitch / 64, ngroups, h->scan_split), block(256);
   hipLaunchKernelGGL((admm::xscan_mfma_kernel<admm::SCAN_MT>), grid, block, 0, h->stream, h->scanWp,
-                     h->scan_in, h->scan_out, h->scan_range, mtiles, ngroups, h->pitch);
+                     h->scan_in, h->scan_out, h->scan_range, mtiles, ngroups, h->pitch, h->scan_split,
+                     (size_t)h->fac.scanM * h->pitch);
   return ADMM_OK;
 }
 
@@ -513,9 +518,17 @@ int admm_setup(admm_handle** out, const admm_problem* p, const admm_options* o_i
   {  // scan operands: in = tseg | x0 | eseg | pad,  out = t_in | pad | x_in | pad  (admm_factor.hpp)
     const size_t Sn = (size_t)h->S * h->n;
     TRY_RELEASE(dalloc(&h->scan_in, (size_t)h->fac.scanK * P));
-    TRY_RELEASE(dalloc(&h->scan_out, (size_t)h->fac.scanM * P));
+    {  // split-K of the scan when the grid would be small: aim at >= 256 workgroups, <= 8 slices
+      const int wgs = (h->pitch / 64) * (h->fac.scanM / 16 / admm::SCAN_MT);
+      int sp = 1;
+      while (sp < 8 && wgs * sp < 256) sp *= 2;
+      const int ksteps = h->fac.scanK / 4;
+      while (sp > 1 && ksteps / sp < 2 * admm::SCAN_U) sp /= 2;     // at least one batch pair per slice
+      h->scan_split = sp;
+    }
+    TRY_RELEASE(dalloc(&h->scan_out, (size_t)h->scan_split * h->fac.scanM * P));
     HIP_TRY_RELEASE(hipMemsetAsync(h->scan_in, 0, sizeof(double) * (size_t)h->fac.scanK * P, h->stream));
-    HIP_TRY_RELEASE(hipMemsetAsync(h->scan_out, 0, sizeof(double) * (size_t)h->fac.scanM * P, h->stream));
+    HIP_TRY_RELEASE(hipMemsetAsync(h->scan_out, 0, sizeof(double) * (size_t)h->scan_split * h->fac.scanM * P, h->stream));
     h->tseg = h->scan_in;
     h->x0 = h->scan_in + Sn * P;
     h->eseg = h->scan_in + (Sn + h->n) * P;

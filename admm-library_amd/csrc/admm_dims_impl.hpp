@@ -37,13 +37,13 @@ void launch_dim(const XLaunch& l, XKernel k, bool a, bool b) {
     }
     case XKernel::XF:
       hipLaunchKernelGGL((xf_kernel<NX, NU>), grid, block, 0, l.stream, l.dbuf, l.tin, l.xin, l.recF,
-                         l.seg_start, l.w, l.pitch);
+                         l.seg_start, l.w, l.pitch, l.nsplit, l.split_stride);
       break;
     case XKernel::XFZ: {
       const bool relax = l.alpha != 1.0;
 #define XFZ1(RS, RX, VI, SC)                                                                                 \
   hipLaunchKernelGGL((xfz_kernel<NX, NU, RS, RX, VI, SC>), grid, block, 0, l.stream, l.dbuf, l.tin, l.xin,   \
-                     l.recF, l.seg_start, l.z, l.y, l.v, l.part, l.alpha, l.pitch)
+                     l.recF, l.seg_start, l.z, l.y, l.v, l.part, l.alpha, l.pitch, l.nsplit, l.split_stride)
 // the SOC form matters where z is rebuilt from v (VIN) or z+ is formed (RESID)
 #define XFZ(RS, RX, VI) do { if ((RS || VI) && l.has_soc) XFZ1(RS, RX, VI, true); else XFZ1(RS, RX, VI, false); } while (0)
 #define XFZ2(RS, RX) do { if (a) XFZ(RS, RX, true); else XFZ(RS, RX, false); } while (0)

@@ -19,6 +19,8 @@ struct XLaunch {
   const int* seg_start;
   double *dbuf, *tseg, *eseg, *tin, *xin, *part;
   const double* x0;
+  int nsplit;                   // split-K slabs of the scan output (t_in / x_in), 1 = none
+  size_t split_stride;          // elements between slabs
 };
 
 enum class XKernel { XB, XF, XFZ, XSCAN_CHAIN };

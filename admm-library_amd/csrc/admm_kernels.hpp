@@ -518,7 +518,7 @@ constexpr int SCAN_U = 8;   // k-steps per batch; host pads K and the ranges to 
 template <int MT>
 __global__ __launch_bounds__(256) void xscan_mfma_kernel(
     const double* __restrict__ Wp, const double* __restrict__ in, double* __restrict__ out,
-    const int* __restrict__ krange_, int mtiles, int ngroups, int pitch) {
+    const int* __restrict__ krange_, int mtiles, int ngroups, int pitch, int nsplit, size_t split_stride) {
   // Workgroup = 4 waves = 4 adjacent N-tiles (64 columns) of ONE M-group, so the A
   // fragments (the same for every N-tile) are fetched from L2 once per workgroup and
   // shared through a double-buffered LDS slab; each wave loads its own B fragments.
@@ -530,7 +530,17 @@ __global__ __launch_bounds__(256) void xscan_mfma_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int group = ngroups - 1 - (int)blockIdx.y;   // long k-ranges (x_in rows) are dispatched first
   cint_p krange = as_const(krange_);
-  const int kb = krange[2 * group], ke = krange[2 * group + 1];    // multiples of 2 U
+  int kb = krange[2 * group], ke = krange[2 * group + 1];          // multiples of 2 U
+  // Split-K (blockIdx.z): for small batches the grid has few workgroups and each would walk a
+  // long K range alone; the range is cut into nsplit slices whose partial results go to
+  // separate output slabs (the consumers add them in split order: deterministic).
+  if (nsplit > 1) {
+    const int per = (((ke - kb) / (2 * U) + nsplit - 1) / nsplit) * (2 * U);
+    const int sb = kb + (int)blockIdx.z * per;
+    ke = (sb + per < ke) ? sb + per : ke;
+    kb = sb;
+    out += (size_t)blockIdx.z * split_stride;
+  }
   const size_t P = (size_t)pitch;
   const int n0 = (blockIdx.x * 4 + wave) * 16;       // pitch is a multiple of 64
   const double* bptr = in + (size_t)(lane >> 4) * P + n0 + (lane & 15);
@@ -596,7 +606,7 @@ template <int NX, int NU>
 __global__ __launch_bounds__(XB_THREADS) void xf_kernel(
     const double* __restrict__ dbuf, const double* __restrict__ tin, const double* __restrict__ xin,
     const double* __restrict__ recF_, const int* __restrict__ seg_start_,
-    double* __restrict__ w, int pitch) {
+    double* __restrict__ w, int pitch, int nsplit, size_t split_stride) {
   constexpr int NB = NX + NU;
   constexpr RecFLayout LF = rec_f_layout(NX, NU);
   constexpr int RF = LF.SIZE;
@@ -612,8 +622,23 @@ __global__ __launch_bounds__(XB_THREADS) void xf_kernel(
     const size_t o = (size_t)s * NX * P + col;
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
-      t[i] = tin[o + i * P];
-      x[i] = xin[o + i * P];
+      // the scan may have been split over K (small batches, <= 8 slabs): partial sums, added in
+      // split order.  Unrolled so that every slab's loads are in flight together.
+      double tp[8], xp[8];
+#pragma unroll
+      for (int sp = 0; sp < 8; ++sp) {
+        const size_t so = (size_t)(sp < nsplit ? sp : 0) * split_stride + o + i * P;
+        tp[sp] = tin[so];
+        xp[sp] = xin[so];
+      }
+      double ta = tp[0], xa = xp[0];
+#pragma unroll
+      for (int sp = 1; sp < 8; ++sp) {
+        ta += (sp < nsplit) ? tp[sp] : 0.0;
+        xa += (sp < nsplit) ? xp[sp] : 0.0;
+      }
+      t[i] = ta;
+      x[i] = xa;
     }
   }
   double ld[NU];
@@ -683,7 +708,7 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_X_OCCUPANCY void xfz_kernel(
     const double* __restrict__ dbuf, const double* __restrict__ tin, const double* __restrict__ xin,
     const double* __restrict__ recF, const int* __restrict__ seg_start_,
     const double* __restrict__ zin, const double* __restrict__ yin, double* __restrict__ v,
-    double* __restrict__ part, double alpha, int pitch) {
+    double* __restrict__ part, double alpha, int pitch, int nsplit, size_t split_stride) {
   // VIN: the state is read from v (zin, yin unused); otherwise from zin, yin.  Either
   // way v+ is written to v.  (zin / yin never alias v.)
   constexpr int NB = NX + NU;
@@ -717,8 +742,23 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_X_OCCUPANCY void xfz_kernel(
     const size_t o = (size_t)s * NX * P + col;
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
-      t[i] = tin[o + i * P];
-      x[i] = xin[o + i * P];
+      // the scan may have been split over K (small batches, <= 8 slabs): partial sums, added in
+      // split order.  Unrolled so that every slab's loads are in flight together.
+      double tp[8], xp[8];
+#pragma unroll
+      for (int sp = 0; sp < 8; ++sp) {
+        const size_t so = (size_t)(sp < nsplit ? sp : 0) * split_stride + o + i * P;
+        tp[sp] = tin[so];
+        xp[sp] = xin[so];
+      }
+      double ta = tp[0], xa = xp[0];
+#pragma unroll
+      for (int sp = 1; sp < 8; ++sp) {
+        ta += (sp < nsplit) ? tp[sp] : 0.0;
+        xa += (sp < nsplit) ? xp[sp] : 0.0;
+      }
+      t[i] = ta;
+      x[i] = xa;
     }
   }
   // prefetch ring (see xb_kernel): l0 = v (VIN) or y; l1 = z (only !VIN && NEEDZ)
