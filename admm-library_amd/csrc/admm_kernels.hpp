@@ -968,14 +968,21 @@ __global__ __launch_bounds__(Z_THREADS) void zdual_kernel(
   cdouble_p lo = as_const(lo_);
   cdouble_p hi = as_const(hi_);
   double2 a_r = {0, 0}, a_s = {0, 0}, a_w = {0, 0}, a_z = {0, 0}, a_y = {0, 0};
-  constexpr int U = 4;
+#ifndef ADMM_Z_UNROLL
+#define ADMM_Z_UNROLL 4
+#endif
+  constexpr int U = ADMM_Z_UNROLL;
   int r = r_begin;
   for (; r + U <= r_end; r += U) {
     double2 wv[U], yv[U], zv[U];
 #pragma unroll
     for (int i = 0; i < U; ++i) {
       const size_t o = (size_t)(r + i) * P + col;
+#ifdef ADMM_Z_NT          // A/B: non-temporal hint on the once-read operand w
+      wv[i] = __builtin_nontemporal_load(reinterpret_cast<const double2*>(w + o));
+#else
       wv[i] = *reinterpret_cast<const double2*>(w + o);
+#endif
       yv[i] = *reinterpret_cast<const double2*>(y + o);
       if (RESID || RELAX) zv[i] = *reinterpret_cast<const double2*>(z + o);
     }

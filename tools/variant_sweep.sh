@@ -12,6 +12,6 @@ for spec in "$@"; do
   tail -n1 "gpurun_out/variants/${name}.json" | python -c "
 import sys, json
 d = json.loads(sys.stdin.read())
-print('$name', round(d['batch_iterations_per_s']), d['kernels_ms']['fused_resid'], 'plain', d['kernels_ms']['fused_plain']['xb_ms'], d['kernels_ms']['fused_plain']['xfz_ms'], 'ci10', round(d['check_interval_10']['batch_iterations_per_s']))"
+print('$name', round(d['batch_iterations_per_s']), d['kernels_ms']['fused_resid'], 'plain', d['kernels_ms']['fused_plain']['xb_ms'], d['kernels_ms']['fused_plain']['xfz_ms'], 'ci10', round(d['check_interval_10']['batch_iterations_per_s']), 'zdual_ms', d['kernels_ms']['unfused_resid']['zdual_ms'])"
   rm -rf "$lib" "$lib.obj"
 done
