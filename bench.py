@@ -88,11 +88,15 @@ def cpu_baseline(N, target_s):
     oracle_c.solve(p, rho=0.05, max_iter=2, check_interval=1, stop=False, nthreads=cores)   # spin up threads
     t0 = time.perf_counter()
     oracle_c.solve(p, rho=0.05, max_iter=10, check_interval=1, stop=False, nthreads=cores)
-    t_cal = (time.perf_counter() - t0) / 10
-    iters = int(max(10, min(100000, target_s / max(t_cal, 1e-6))))
-    t0 = time.perf_counter()
-    oracle_c.solve(p, rho=0.05, max_iter=iters, check_interval=1, stop=False, nthreads=cores)
-    dt = time.perf_counter() - t0
+    t_it = (time.perf_counter() - t0) / 10
+    for _ in range(3):                      # the calibration run is colder than the timed one: re-aim if short
+        iters = int(max(10, min(100000, target_s / max(t_it, 1e-6))))
+        t0 = time.perf_counter()
+        oracle_c.solve(p, rho=0.05, max_iter=iters, check_interval=1, stop=False, nthreads=cores)
+        dt = time.perf_counter() - t0
+        if dt >= 0.66 * target_s:
+            break
+        t_it = dt / iters
     return {"value": sample_batch * iters / dt, "unit": "QP-iterations/s", "cores": cores, "kind": "port",
             "sample": f"{iters} iterations of {sample_batch} QPs (N={N}, n=6, m=3), C/OpenMP oracle, "
                       f"residuals every iteration, {dt:.1f} s"}
