@@ -502,9 +502,9 @@ int admm_setup(admm_handle** out, const admm_problem* p, const admm_options* o_i
   {  // the x kernels address one segment of an array through a 32-bit buffer descriptor
     int longest = 0;
     for (int s = 0; s < h->S; ++s) longest = std::max(longest, h->fac.seg_start[s + 1] - h->fac.seg_start[s]);
-    if ((double)longest * h->nb * h->pitch * 8.0 >= 4.0e9) {
+    if ((double)longest * h->nb * h->pitch * 8.0 >= 2147483648.0) {
       release(h);
-      return fail(ADMM_ERR_UNSUPPORTED, "one segment of the state exceeds 4 GB: use more segments or a smaller batch per GPU");
+      return fail(ADMM_ERR_UNSUPPORTED, "one segment of the state exceeds 2 GiB: use more segments or a smaller batch per GPU");
     }
   }
 

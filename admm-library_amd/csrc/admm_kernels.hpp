@@ -95,9 +95,14 @@ __device__ __forceinline__ cint_p as_const(const int* p) { return (cint_p)(uintp
 // byte offset are wave-uniform (SGPRs), the lane part is ONE 32-bit byte offset shared by every
 // access of the kernel -- `buffer_load_dwordx2 v, v_off, s[rsrc], s_row offen`.  No per-access
 // 64-bit VALU address arithmetic (it was ~18 % of the VALU instructions of a stage) and no
-// per-row address VGPRs.  The descriptor spans one segment of the array (< 4 GiB, checked at
-// setup), so out-of-range accesses are dropped by the hardware instead of faulting.
+// per-row address VGPRs.  The descriptor spans one segment of the array (< 2 GiB, checked at
+// setup); accesses past it are dropped by the hardware instead of faulting.
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+// Lane offset of a lane that must not store.  A view spans < 2 GiB (checked at setup), so 2^31 is
+// out of range whether or not the hardware adds the scalar row offset before its range check
+// (and 2^31 + row offset cannot wrap): the store is discarded.
+constexpr unsigned ROWVIEW_OOB = 0x80000000u;
 
 struct RowView {
   __amdgpu_buffer_rsrc_t rsrc;
@@ -227,9 +232,9 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_X_OCCUPANCY void xb_kernel(
   constexpr int CH = stage_chunk(RB, PF);        // stages whose records are staged in LDS at once
   __shared__ __attribute__((aligned(16))) double rec[CH * RB];
 
-  // No early return (every wave must reach the barriers) and no store predicate: lanes past the
-  // pitch are clamped onto the last column, compute exactly what that column's lane computes and
-  // store the same values to the same addresses -- harmless, and the stage loop stays branch-free.
+  // No early return (every wave must reach the barriers) and no store branches: lanes past the
+  // pitch are clamped onto the last column for their LOADS (so they compute finite values) and
+  // their STORES are dropped (out-of-range buffer offset) -- the stage loop stays branch-free.
   const int col_raw = blockIdx.x * XB_THREADS + threadIdx.x;
   const int col = col_raw < pitch ? col_raw : pitch - 1;
 #ifdef ADMM_STORE_PRED      // A/B diagnostic: the older predicated-store form
@@ -237,6 +242,9 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_X_OCCUPANCY void xb_kernel(
 #else
   constexpr bool st = true;
 #endif
+  // Stores of clamped lanes go to an out-of-range buffer offset and are dropped by the hardware
+  // (see RowView): still branch-free, and no lane ever writes a column it does not own.
+  const unsigned lb_st = col_raw < pitch ? (unsigned)col * 8u : ROWVIEW_OOB;
   const int s = blockIdx.y;
   cint_p seg_start = as_const(seg_start_);
   const int k0 = seg_start[s], k1 = seg_start[s + 1];
@@ -331,7 +339,7 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_X_OCCUPANCY void xb_kernel(
         if (st) {
           const unsigned d0 = (unsigned)(k - k0) * NU * PB;
 #pragma unroll
-          for (int jj = 0; jj < NU; ++jj) vd.store(d[jj], lb, d0 + jj * PB);
+          for (int jj = 0; jj < NU; ++jj) vd.store(d[jj], lb_st, d0 + jj * PB);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -345,7 +353,7 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_X_OCCUPANCY void xb_kernel(
       }
     }
   }
-  {
+  if (col_raw < pitch) {
     const size_t o = (size_t)s * NX * P + col;
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
@@ -720,12 +728,15 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_X_OCCUPANCY void xfz_kernel(
   __shared__ __attribute__((aligned(16))) double rec[CH * RF];
 
   const int col_raw = blockIdx.x * XB_THREADS + threadIdx.x;
-  const int col = col_raw < pitch ? col_raw : pitch - 1;      // clamped lanes duplicate the last column (see xb_kernel)
+  const int col = col_raw < pitch ? col_raw : pitch - 1;      // clamped lanes: loads only (see xb_kernel)
 #ifdef ADMM_STORE_PRED
   const bool st = col_raw < pitch;
 #else
   constexpr bool st = true;
 #endif
+  // v is updated IN PLACE, so a clamped lane must never store: a duplicate of the last column
+  // running ahead would overwrite v rows its owner has not read yet.  Out-of-range offset = dropped.
+  const unsigned lb_st = col_raw < pitch ? (unsigned)col * 8u : ROWVIEW_OOB;
   const int s = blockIdx.y;
   cint_p seg_start = as_const(seg_start_);
   const int k0 = seg_start[s], k1 = seg_start[s + 1];
@@ -878,7 +889,7 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_X_OCCUPANCY void xfz_kernel(
           double wh = wv[r];
           if (RELAX) wh = fma(alpha, wv[r], (1.0 - alpha) * zo);
           const double vn = wh + yo;
-          if (st) vv.store(vn, lb, r0 + r * PB);
+          if (st) vv.store(vn, lb_st, r0 + r * PB);
           if (RESID) {
             const double zn = ball ? vn * cs_new : fmin(fmax(vn, l), h);
             const double yn = vn - zn;
@@ -895,7 +906,7 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_X_OCCUPANCY void xfz_kernel(
       }
     }
   }
-  if (RESID) {
+  if (RESID && col_raw < pitch) {
     const size_t o = (size_t)s * 5 * P + col;
     part[o + 0 * P] = a_r;
     part[o + 1 * P] = a_s;

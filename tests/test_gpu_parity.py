@@ -373,3 +373,19 @@ def test_plain_c_program_over_the_abi(gpu, tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "converged 5/5" in out.stdout
+
+
+@pytest.mark.parametrize("batch", [65, 130, 200])
+def test_clamped_lanes_never_store(gpu, batch):
+    """pitch not a multiple of the 256-column workgroup: the lanes past the pitch are clamped
+    onto the last column for loads and must not store (v is updated in place, so a duplicate of the
+    last column running ahead would corrupt it).  120 iterations of a long horizon, last columns
+    included, against the oracle."""
+    p = pkg.cw_rendezvous(N=300, batch=batch)
+    ref = oc.solve(p, rho=0.05, max_iter=120, stop=False)
+    with pkg.Solver(p, pkg.Options(rho=0.05, segments=4)) as s:      # long segments: many stages for a wave to run ahead
+        s.iterate(120)
+        w, z, y = s.get()
+    for a, b in ((w, ref["w"]), (z, ref["z"]), (y, ref["y"])):
+        assert np.abs(a - b).max() <= TOL * max(1.0, np.abs(b).max())
+    assert np.abs(z[-1] - ref["z"][-1]).max() <= TOL          # the column the clamped lanes alias
