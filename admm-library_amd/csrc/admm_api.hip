@@ -601,6 +601,7 @@ int admm_update_instances(admm_handle* h, const double* x0, const double* q) {
   if (!h) return fail(ADMM_ERR_INVALID, "NULL handle");
   HIP_TRY(hipSetDevice(h->device));
   int rc;
+  if ((x0 || q) && (rc = ensure_w(h))) return rc;   // w of the last x-update belongs to the old instance data
   if (x0) {
     if (!finite_all(x0, (size_t)h->n * h->batch)) return fail(ADMM_ERR_INVALID, "non-finite entry in x0");
     if ((rc = upload_transposed(h, x0, h->x0, h->n))) return rc;
@@ -631,6 +632,7 @@ static int set_rho_internal(admm_handle* h, double rho_new) {
   if (rc) return fail(rc, err);
   if (f.recB.size() != h->fac.recB.size() || f.scanWp.size() != h->fac.scanWp.size())
     return fail(ADMM_ERR_NUMERIC, "internal: record sizes changed on refactor");
+  if ((rc = ensure_w(h))) return rc;          // w of the last x-update must be rebuilt with the OLD records
   if ((rc = ensure_zy(h))) return rc;
   {
     const double c = h->opt.rho / rho_new;

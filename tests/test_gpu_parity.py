@@ -224,6 +224,13 @@ def test_set_rho_keeps_the_multiplier(gpu):
         s.iterate(11)
         w, z, y = s.get()
     assert np.abs(z_mid - a["z"]).max() <= TOL and np.abs(y_mid - a["y"] * (r1 / r2)).max() <= TOL
+    # w read AFTER the rho change is still the w of the last x-update (it is re-materialised from
+    # d / t_in / x_in, which belong to the old records)
+    with pkg.Solver(p, pkg.Options(rho=r1)) as s2:
+        s2.iterate(15)
+        s2.set_rho(r2)
+        w_after, _, _ = s2.get(True, False, False)
+    assert np.abs(w_after - a["w"]).max() <= TOL * max(1.0, np.abs(a["w"]).max())
     for got, ref in ((w, b["w"]), (z, b["z"]), (y, b["y"])):
         assert np.abs(got - ref).max() <= TOL * max(1.0, np.abs(ref).max())
 
