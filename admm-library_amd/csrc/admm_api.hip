@@ -447,17 +447,23 @@ int admm_setup(admm_handle** out, const admm_problem* p, const admm_options* o_i
   if (p->unorm)
     for (int k = 0; k < (p->stage_bounds ? p->N : 1); ++k) h->has_soc = h->has_soc || std::isfinite(p->unorm[k]);
 
-  // x-update segments: one (column-wave x segment) wave per SIMD (1024 SIMDs).  Measured on
-  // MI355X: the x kernels run as fast at 1 wave/SIMD as at 2, and the scan's
-  // work grows with S^2, so fewer, longer segments win; S = 16 for pitch 4096.
+  // x-update segments: ONE workgroup (256 columns x one segment) per CU -- the grid
+  // ceil(pitch / 256) x S should fill the 256 CUs once and not spill into a ragged second round
+  // (measured, DESIGN.md §4.6: pitch 4160 with S = 16 is 272 workgroups and runs 1.45x slower per
+  // QP than pitch 4096; S = 15 = 255 workgroups restores the rate).  The x kernels run as fast at
+  // one wave per SIMD as at two, and the scan's work grows with S^2, so fewer, longer segments win.
   {
     int S = o.segments;
     if (S == 0) {
-      const int wave_cols = h->pitch / 64;
-      S = (1024 + wave_cols - 1) / wave_cols;
+      const int col_blocks = (h->pitch + admm::XB_THREADS - 1) / admm::XB_THREADS;
+      S = 256 / col_blocks;
       const int max_by_len = h->N >= 16 ? h->N / 8 : 1;
       if (S > max_by_len) S = max_by_len;
       if (S > 64) S = 64;
+      // a segment of the state must stay below the 2 GiB a buffer descriptor can span (with margin)
+      const double total = (double)h->N * h->nb * h->pitch * 8.0;
+      const int min_by_span = (int)(total / 1.9e9) + 1;
+      if (S < min_by_span) S = min_by_span;
     }
     if (S > h->N) S = h->N;
     if (S < 1) S = 1;
