@@ -821,7 +821,11 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_X_OCCUPANCY void xfz_kernel(
 #pragma unroll
           for (int r = 0; r < NB; ++r) {
             if (VIN) {
+#ifdef ADMM_ABLATE_XFZ_LOAD    // timing-only diagnostic: no v loads in the stage loop
+              l0[j][r] = l0[j][r] * 0.5 + 0.125;
+#else
               l0[j][r] = vv.load(lb, r0 + r * PB);
+#endif
             } else {
               l0[j][r] = vy.load(lb, r0 + r * PB);
               if (NEEDZ) l1[j][r] = vz.load(lb, r0 + r * PB);
@@ -889,7 +893,11 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_X_OCCUPANCY void xfz_kernel(
           double wh = wv[r];
           if (RELAX) wh = fma(alpha, wv[r], (1.0 - alpha) * zo);
           const double vn = wh + yo;
+#ifdef ADMM_ABLATE_XFZ_STORE   // timing-only diagnostic: no v+ store (keep vn alive)
+          asm volatile("" ::"v"(vn));
+#else
           if (st) vv.store(vn, lb_st, r0 + r * PB);
+#endif
           if (RESID) {
             const double zn = ball ? vn * cs_new : fmin(fmax(vn, l), h);
             const double yn = vn - zn;
