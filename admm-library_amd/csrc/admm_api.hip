@@ -8,6 +8,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -120,7 +121,7 @@ int launch_x(admm_handle* h, admm::XKernel k, bool a, bool b) {
 // vform: read the state from h->v (z = clip(v), y = v - z rebuilt in registers)
 int launch_xb(admm_handle* h, bool vform) { return launch_x(h, admm::XKernel::XB, vform, false); }
 
-static_assert(admm::SCAN_KALIGN == 2 * admm::SCAN_U, "host range alignment must match the kernel's batch");
+static_assert(admm::SCAN_KALIGN == admm::SCAN_U, "host range alignment must match the kernel's batch");
 
 int launch_xscan_mfma(admm_handle* h) {
   const int mtiles = h->fac.scanM / 16, ngroups = mtiles / admm::SCAN_MT;
@@ -551,7 +552,11 @@ int admm_setup(admm_handle** out, const admm_problem* p, const admm_options* o_i
       int sp = 1;
       while (sp < 8 && wgs * sp < 256) sp *= 2;
       const int ksteps = h->fac.scanK / 4;
-      while (sp > 1 && ksteps / sp < 2 * admm::SCAN_U) sp /= 2;     // at least one batch pair per slice
+      while (sp > 1 && ksteps / sp < 2 * admm::SCAN_U) sp /= 2;     // at least two batches per slice
+      if (const char* e = std::getenv("ADMM_SCAN_SPLIT")) {           // tuning override (1, 2, 4, 8)
+        const int v = std::atoi(e);
+        if (v == 1 || v == 2 || v == 4 || v == 8) sp = v;
+      }
       h->scan_split = sp;
     }
     TRY_RELEASE(dalloc(&h->scan_out, (size_t)h->scan_split * h->fac.scanM * P));

@@ -59,8 +59,14 @@ struct Factor {
   std::vector<int32_t> scanRange;   // 2 * (scanM / 16 / SCAN_MT)
 };
 
-constexpr int SCAN_MT = 4;          // M-tiles (of 16 rows) per wave in xscan_mfma_kernel
-constexpr int SCAN_KALIGN = 16;     // k-step ranges and K/4 are padded to this (= 2 * SCAN_U of the kernel)
+#ifndef ADMM_SCAN_MT
+#define ADMM_SCAN_MT 4
+#endif
+#ifndef ADMM_SCAN_U
+#define ADMM_SCAN_U 8
+#endif
+constexpr int SCAN_MT = ADMM_SCAN_MT;      // M-tiles (of 16 rows) per wave in xscan_mfma_kernel
+constexpr int SCAN_KALIGN = ADMM_SCAN_U;   // k-step ranges and K/4 are padded to the kernel's batch (SCAN_U k-steps)
 
 inline int rec_b_size(int n, int m) { return rec_b_layout(n, m).SIZE; }
 inline int rec_f_size(int n, int m) { return rec_f_layout(n, m).SIZE; }

@@ -521,7 +521,10 @@ __global__ __launch_bounds__(64) void xscan_kernel(
 // ---------------------------------------------------------------------------
 typedef double mfma_d4 __attribute__((ext_vector_type(4)));
 
-constexpr int SCAN_U = 8;   // k-steps per batch; host pads K and the ranges to 2 * SCAN_U steps
+#ifndef ADMM_SCAN_U
+#define ADMM_SCAN_U 8
+#endif
+constexpr int SCAN_U = ADMM_SCAN_U;   // k-steps per batch; the host pads K and the ranges to multiples of it
 
 template <int MT>
 __global__ __launch_bounds__(256) void xscan_mfma_kernel(
@@ -538,12 +541,12 @@ __global__ __launch_bounds__(256) void xscan_mfma_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int group = ngroups - 1 - (int)blockIdx.y;   // long k-ranges (x_in rows) are dispatched first
   cint_p krange = as_const(krange_);
-  int kb = krange[2 * group], ke = krange[2 * group + 1];          // multiples of 2 U
+  int kb = krange[2 * group], ke = krange[2 * group + 1];          // multiples of U
   // Split-K (blockIdx.z): for small batches the grid has few workgroups and each would walk a
   // long K range alone; the range is cut into nsplit slices whose partial results go to
   // separate output slabs (the consumers add them in split order: deterministic).
   if (nsplit > 1) {
-    const int per = (((ke - kb) / (2 * U) + nsplit - 1) / nsplit) * (2 * U);
+    const int per = (((ke - kb) / U + nsplit - 1) / nsplit) * U;
     const int sb = kb + (int)blockIdx.z * per;
     ke = (sb + per < ke) ? sb + per : ke;
     kb = sb;
