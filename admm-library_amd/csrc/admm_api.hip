@@ -419,6 +419,28 @@ int admm_host_scan_matrix(const admm_problem* p, double rho, int32_t segments, d
   return ADMM_OK;
 }
 
+int admm_record_sizes_alt(int32_t n, int32_t m, int32_t* rfe, int32_t* rbe) {
+  if (n < 1 || m < 1) return fail(ADMM_ERR_INVALID, "n, m must be positive");
+  if (rfe) *rfe = admm::rec_fe_size(n, m);
+  if (rbe) *rbe = admm::rec_be_size(n, m);
+  return ADMM_OK;
+}
+
+int admm_host_factor_alt(const admm_problem* p, double rho, int32_t segments, double* recFE, double* recBE,
+                         double* WB, int32_t* ok) {
+  if (!p) return fail(ADMM_ERR_INVALID, "NULL problem");
+  admm::Factor f;
+  std::string err;
+  int rc = admm::factorise(*p, rho, segments, f, err);
+  if (rc) return fail(rc, err);
+  if (ok) *ok = f.alt_ok ? 1 : 0;
+  if (!f.alt_ok) return ADMM_OK;
+  if (recFE) std::memcpy(recFE, f.recFE.data(), sizeof(double) * f.recFE.size());
+  if (recBE) std::memcpy(recBE, f.recBE.data(), sizeof(double) * f.recBE.size());
+  if (WB) std::memcpy(WB, f.scanWB.data(), sizeof(double) * f.scanWB.size());
+  return ADMM_OK;
+}
+
 int admm_setup(admm_handle** out, const admm_problem* p, const admm_options* o_in) {
   if (!out || !p) return fail(ADMM_ERR_INVALID, "NULL argument");
   *out = nullptr;

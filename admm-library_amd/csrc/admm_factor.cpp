@@ -86,6 +86,213 @@ bool all_finite(const double* a, size_t cnt) {
   return true;
 }
 
+
+// W (row-major M x K) -> MFMA A-fragment order, plus each M-group's non-zero k-step range.
+void pack_scan(const std::vector<double>& Wm, int M, int K, std::vector<double>& Wp, std::vector<int32_t>& range) {
+  auto round_up = [](int v, int q) { return ((v + q - 1) / q) * q; };
+  auto W = [&](int r, int c) -> double { return Wm[(size_t)r * K + c]; };
+  const int mtiles = M / 16, ksteps = K / 4, groups = mtiles / SCAN_MT;
+  Wp.assign((size_t)ksteps * mtiles * 64, 0.0);
+  for (int ks = 0; ks < ksteps; ++ks)
+    for (int mt = 0; mt < mtiles; ++mt)
+      for (int lane = 0; lane < 64; ++lane)
+        Wp[((size_t)ks * mtiles + mt) * 64 + lane] = W(16 * mt + (lane & 15), 4 * ks + (lane >> 4));
+  range.assign((size_t)2 * groups, 0);
+  for (int g = 0; g < groups; ++g) {
+    int kb = ksteps, ke = 0;
+    for (int r = g * SCAN_MT * 16; r < (g + 1) * SCAN_MT * 16; ++r)
+      for (int c = 0; c < K; ++c)
+        if (W(r, c) != 0.0) {
+          if (c / 4 < kb) kb = c / 4;
+          if (c / 4 + 1 > ke) ke = c / 4 + 1;
+        }
+    if (ke < kb) { kb = 0; ke = 0; }
+    kb = (kb / SCAN_KALIGN) * SCAN_KALIGN;            // W is zero outside the true range, so
+    ke = round_up(ke, SCAN_KALIGN);                   // widening it to the batch size is harmless
+    range[2 * g] = kb;
+    range[2 * g + 1] = ke;
+  }
+}
+
+Mat add(const Mat& a, const Mat& b) {
+  Mat c(a);
+  for (size_t i = 0; i < c.size(); ++i) c[i] += b[i];
+  return c;
+}
+Mat sub(const Mat& a, const Mat& b) {
+  Mat c(a);
+  for (size_t i = 0; i < c.size(); ++i) c[i] -= b[i];
+  return c;
+}
+Mat neg(const Mat& a) {
+  Mat c(a);
+  for (auto& v : c) v = -v;
+  return c;
+}
+void put(double* dst, const Mat& a) {
+  for (size_t i = 0; i < a.size(); ++i) dst[i] = a[i];
+}
+void put_block(std::vector<double>& W, int K, int r0, int c0, const Mat& a, int n, bool accumulate) {
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) {
+      double& w = W[(size_t)(r0 + i) * K + c0 + j];
+      w = accumulate ? w + a[(size_t)i * n + j] : a[(size_t)i * n + j];
+    }
+}
+
+// Forward-elimination (information-filter) form of the x-update and its segment algebra
+// (DESIGN.md §4.8).  With Rr = R + rho I, Qr_k = Q (QN at k = N) + rho I and C_0 = 0:
+//     Pm      = A_k C_k A_k' + B_k Rr^{-1} B_k'
+//     G_{k+1} = Pm (Pm + Qr_{k+1}^{-1})^{-1},       C_{k+1} = Pm - G_{k+1} Pm
+// elimination (forward):   m_{k+1} = F_k m_k + Gam_k g^u_k + Pi_k g^x_{k+1},   m_0 = x_0
+// substitution (backward, costate form; lam = 0 after the last block):
+//     x_{k+1} = m_{k+1} + C_{k+1} lam,   nu = lam - Qr_{k+1} x_{k+1} - g^x_{k+1},
+//     u_k = Rr^{-1} (B_k' nu - g^u_k),   lam <- A_k' nu
+// Only inverses of positive definite matrices occur (C_k itself is singular for small k).
+// Leaves f.alt_ok false if a pivot fails or a transfer matrix overflows.
+void build_alternating(Factor& f, const std::vector<Mat>& A, const std::vector<Mat>& B, const Mat& Q,
+                       const Mat& R, const Mat& QN, double rho) {
+  const int N = f.N, n = f.n, m = f.m, S = f.S;
+  f.alt_ok = false;
+  f.RFE = rec_fe_size(n, m);
+  f.RBE = rec_be_size(n, m);
+  f.recFE.assign((size_t)N * f.RFE, 0.0);
+  f.recBE.assign((size_t)N * f.RBE, 0.0);
+  const RecFELayout lfe = rec_fe_layout(n, m);
+  const RecBELayout lbe = rec_be_layout(n, m);
+  const RecBLayout lb = rec_b_layout(n, m);
+  const RecFLayout lf = rec_f_layout(n, m);
+  const Mat I = eye(n);
+  Mat Rr = R;
+  for (int i = 0; i < m; ++i) Rr[(size_t)i * m + i] += rho;
+  symmetrise(Rr, m);
+  Mat Ri;
+  if (!spd_inverse(Rr, m, Ri)) return;
+  symmetrise(Ri, m);
+  Mat Qr = Q, QNr = QN;
+  for (int i = 0; i < n; ++i) { Qr[(size_t)i * n + i] += rho; QNr[(size_t)i * n + i] += rho; }
+  symmetrise(Qr, n);
+  symmetrise(QNr, n);
+  Mat Qi, QNi;
+  if (!spd_inverse(Qr, n, Qi) || !spd_inverse(QNr, n, QNi)) return;
+
+  std::vector<Mat> Fm(N), Gam(N), Pi(N), E(N), Cn(N), Qk(N);
+  Mat C((size_t)n * n, 0.0);
+  for (int k = 0; k < N; ++k) {
+    const Mat At = tr(A[k], n, n), Bt = tr(B[k], n, m);
+    const Mat BRi = mul(B[k], Ri, n, m, m);
+    Mat Pm = add(mul(mul(A[k], C, n, n, n), At, n, n, n), mul(BRi, Bt, n, m, n));
+    symmetrise(Pm, n);
+    const Mat& Qn = (k + 1 == N) ? QNr : Qr;
+    const Mat& Qin = (k + 1 == N) ? QNi : Qi;
+    Mat D = add(Pm, Qin);
+    symmetrise(D, n);
+    Mat Di;
+    if (!spd_inverse(D, n, Di)) return;
+    const Mat G = mul(Pm, Di, n, n, n);
+    const Mat ImG = sub(I, G);
+    C = sub(Pm, mul(G, Pm, n, n, n));
+    symmetrise(C, n);
+    Fm[k] = mul(ImG, A[k], n, n, n);
+    Gam[k] = neg(mul(ImG, BRi, n, n, m));
+    Pi[k] = neg(mul(G, Qin, n, n, n));
+    E[k] = mul(At, sub(I, mul(Qn, C, n, n, n)), n, n, n);
+    Cn[k] = C;
+    Qk[k] = Qn;
+    // stage-local blocks; the rollout / elimination blocks are copied from the plain records
+    double* rfe = &f.recFE[(size_t)k * f.RFE];
+    double* rbe = &f.recBE[(size_t)k * f.RBE];
+    const double* rf = &f.recF[(size_t)k * f.RF];
+    const double* rb = &f.recB[(size_t)k * f.RB];
+    for (int i = 0; i < even_up(m * n); ++i) { rfe[lfe.PSI + i] = rf[lf.PSI + i]; rfe[lfe.K + i] = rf[lf.K + i]; }
+    for (int i = 0; i < even_up(n * n); ++i) rfe[lfe.A + i] = rf[lf.A + i];
+    for (int i = 0; i < even_up(n * m); ++i) rfe[lfe.B + i] = rf[lf.B + i];
+    put(rfe + lfe.FM, Fm[k]);
+    put(rfe + lfe.GA, Gam[k]);
+    put(rfe + lfe.PI, Pi[k]);
+    put(rbe + lbe.CM, C);
+    put(rbe + lbe.QM, Qn);
+    put(rbe + lbe.RB, mul(Ri, Bt, m, m, n));
+    put(rbe + lbe.RI, Ri);
+    for (int i = 0; i < even_up(n * n); ++i) rbe[lbe.AT + i] = rb[lb.AT + i];
+    for (int i = 0; i < even_up(m * n); ++i) rbe[lbe.BT + i] = rb[lb.BT + i];
+    for (int i = 0; i < even_up(m * m); ++i) rbe[lbe.SI + i] = rb[lb.SI + i];
+    for (int i = 0; i < even_up(n * m); ++i) { rbe[lbe.KT + i] = rb[lb.KT + i]; rbe[lbe.OM + i] = rb[lb.OM + i]; }
+    for (int i = 0; i < even_up(n + m); ++i) {
+      rfe[lfe.LO + i] = rf[lf.LO + i]; rfe[lfe.HI + i] = rf[lf.HI + i];
+      rbe[lbe.LO + i] = rb[lb.LO + i]; rbe[lbe.HI + i] = rb[lb.HI + i];
+    }
+    rfe[lfe.UB] = rf[lf.UB];
+    rbe[lbe.UB] = rb[lb.UB];
+  }
+
+  // ---- segment algebra ----
+  //   Phf_k = F_k ... F_a,   Omb_k = (E_a ... E_{k-1}) A_k'
+  //   eps(s) = - sum_k Omb_k (Qr_{k+1} m0_{k+1} + g^x_{k+1}) = sum_k (YU_k g^u_k + YX_k g^x_{k+1})
+  //   lam_out(s) = eps(s) + Es(s) lam_in(s) + Xib(s) m_in(s),   m_out(s) = mseg(s) + Phs(s) m_in(s)
+  std::vector<Mat> Phs(S), Es(S), Xib(S);
+  for (int s = 0; s < S; ++s) {
+    const int a = f.seg_start[s], b = f.seg_start[s + 1];
+    std::vector<Mat> Phf(b - a), Omb(b - a);
+    Mat P = I, Ep = I;
+    for (int k = a; k < b; ++k) {
+      P = mul(Fm[k], P, n, n, n);
+      Phf[k - a] = P;
+      Omb[k - a] = mul(Ep, tr(A[k], n, n), n, n, n);
+      Ep = mul(Ep, E[k], n, n, n);
+      put(&f.recBE[(size_t)k * f.RBE + lbe.PHF], P);
+    }
+    Phs[s] = P;
+    Es[s] = Ep;
+    Mat Z((size_t)n * n, 0.0), Xi((size_t)n * n, 0.0);
+    for (int j = b - 1; j >= a; --j) {
+      const Mat OQ = mul(Omb[j - a], Qk[j], n, n, n);
+      Z = (j + 1 < b) ? add(OQ, mul(Z, Fm[j + 1], n, n, n)) : OQ;
+      put(&f.recFE[(size_t)j * f.RFE + lfe.YU], neg(mul(Z, Gam[j], n, n, m)));
+      put(&f.recFE[(size_t)j * f.RFE + lfe.YX], sub(neg(mul(Z, Pi[j], n, n, n)), Omb[j - a]));
+      Xi = sub(Xi, mul(OQ, Phf[j - a], n, n, n));
+    }
+    Xib[s] = Xi;
+  }
+  for (int k = 0; k < N; ++k) {                       // (the box blocks may hold +-inf: matrices only)
+    for (int i = 0; i < lfe.LO; ++i) if (!std::isfinite(f.recFE[(size_t)k * f.RFE + i])) return;
+    for (int i = 0; i < lbe.LO; ++i) if (!std::isfinite(f.recBE[(size_t)k * f.RBE + i])) return;
+  }
+
+  // ---- scan matrix, same shape and layout as scanW ----
+  const int Sn = S * n, Mt = f.scanMt, M = f.scanM, K = f.scanK;
+  f.scanWB.assign((size_t)M * K, 0.0);
+  const int c_m = 0, c_x0 = Sn, c_e = Sn + n, r_m = 0, r_l = Mt;
+  // m_in(s) = [Phs_{s-1} ... Phs_0] x0 + sum_{s' < s} [Phs_{s-1} ... Phs_{s'+1}] mseg(s')
+  std::vector<std::vector<Mat>> Mm(S, std::vector<Mat>(S));   // Mm[s][s'] (s' < s)
+  std::vector<Mat> Mx0(S);
+  for (int s = 0; s < S; ++s) {
+    Mat P = I;
+    for (int sp = s - 1; sp >= 0; --sp) {
+      Mm[s][sp] = P;
+      put_block(f.scanWB, K, r_m + s * n, c_m + sp * n, P, n, false);
+      P = mul(P, Phs[sp], n, n, n);
+    }
+    Mx0[s] = P;
+    put_block(f.scanWB, K, r_m + s * n, c_x0, P, n, false);
+  }
+  // lam_in(s) = sum_{s' > s} [Es_{s+1} ... Es_{s'-1}] (eps(s') + Xib_{s'} m_in(s'))
+  for (int s = 0; s < S; ++s) {
+    Mat P = I;
+    for (int sp = s + 1; sp < S; ++sp) {
+      put_block(f.scanWB, K, r_l + s * n, c_e + sp * n, P, n, false);
+      const Mat PX = mul(P, Xib[sp], n, n, n);
+      put_block(f.scanWB, K, r_l + s * n, c_x0, mul(PX, Mx0[sp], n, n, n), n, true);
+      for (int spp = 0; spp < sp; ++spp)
+        put_block(f.scanWB, K, r_l + s * n, c_m + spp * n, mul(PX, Mm[sp][spp], n, n, n), n, true);
+      P = mul(P, Es[sp], n, n, n);
+    }
+  }
+  for (double v : f.scanWB) if (!std::isfinite(v)) return;
+  pack_scan(f.scanWB, M, K, f.scanWpB, f.scanRangeB);
+  f.alt_ok = true;
+}
+
 }  // namespace
 
 int factorise(const admm_problem& p, double rho, int segments, Factor& f, std::string& err) {
@@ -263,29 +470,10 @@ int factorise(const admm_problem& p, double rho, int segments, Factor& f, std::s
     }
     for (double v : f.scanW)
       if (!std::isfinite(v)) { err = "scan matrix overflowed; use more segments"; return ADMM_ERR_NUMERIC; }
-    // pack in MFMA A-fragment order and find each M-group's non-zero k-step range
-    const int mtiles = M / 16, ksteps = K / 4, groups = mtiles / SCAN_MT;
-    f.scanWp.assign((size_t)ksteps * mtiles * 64, 0.0);
-    for (int ks = 0; ks < ksteps; ++ks)
-      for (int mt = 0; mt < mtiles; ++mt)
-        for (int lane = 0; lane < 64; ++lane)
-          f.scanWp[((size_t)ks * mtiles + mt) * 64 + lane] = W(16 * mt + (lane & 15), 4 * ks + (lane >> 4));
-    f.scanRange.assign((size_t)2 * groups, 0);
-    for (int g = 0; g < groups; ++g) {
-      int kb = ksteps, ke = 0;
-      for (int r = g * SCAN_MT * 16; r < (g + 1) * SCAN_MT * 16; ++r)
-        for (int c = 0; c < K; ++c)
-          if (W(r, c) != 0.0) {
-            if (c / 4 < kb) kb = c / 4;
-            if (c / 4 + 1 > ke) ke = c / 4 + 1;
-          }
-      if (ke < kb) { kb = 0; ke = 0; }
-      kb = (kb / SCAN_KALIGN) * SCAN_KALIGN;            // W is zero outside the true range, so
-      ke = round_up(ke, SCAN_KALIGN);                   // widening it to the batch size is harmless
-      f.scanRange[2 * g] = kb;
-      f.scanRange[2 * g + 1] = ke;
-    }
+    pack_scan(f.scanW, M, K, f.scanWp, f.scanRange);
   }
+
+  build_alternating(f, A, B, Q, R, QN, rho);
   return ADMM_OK;
 }
 

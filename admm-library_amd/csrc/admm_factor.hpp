@@ -57,6 +57,18 @@ struct Factor {
   int scanM = 0, scanMt = 0, scanK = 0;
   std::vector<double> scanW, scanWp;
   std::vector<int32_t> scanRange;   // 2 * (scanM / 16 / SCAN_MT)
+
+  // Alternating-direction iteration: records of the two fused kernels
+  // (layouts in admm_layout.hpp) and the scan matrix of the forward-elimination form, same
+  // shape and row/column layout as scanW:
+  //   in  rows: mseg(0..S-1) | x0 | epsseg(0..S-1)          out rows: m_in(0..S-1) | lam_in(0..S-1)
+  // alt_ok is false when that form could not be built (then only the plain iteration runs).
+  bool alt_ok = false;
+  int RFE = 0, RBE = 0;
+  std::vector<double> recFE;        // N * RFE
+  std::vector<double> recBE;        // N * RBE
+  std::vector<double> scanWB, scanWpB;
+  std::vector<int32_t> scanRangeB;
 };
 
 #ifndef ADMM_SCAN_MT
@@ -71,6 +83,8 @@ constexpr int SCAN_KALIGN = ADMM_SCAN_U;   // k-step ranges and K/4 are padded t
 inline int rec_b_size(int n, int m) { return rec_b_layout(n, m).SIZE; }
 inline int rec_f_size(int n, int m) { return rec_f_layout(n, m).SIZE; }
 inline int rec_s_size(int n) { return 3 * n * n; }
+inline int rec_fe_size(int n, int m) { return rec_fe_layout(n, m).SIZE; }
+inline int rec_be_size(int n, int m) { return rec_be_layout(n, m).SIZE; }
 
 // Validates nothing about the batch; only dynamics/weights.  Returns an
 // admm_status; err receives a message on failure.

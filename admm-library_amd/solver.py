@@ -69,6 +69,9 @@ _SIGNATURES = {
                                         c_int32_p, c_int32_p]),
     "admm_host_factor": (C.c_int, [C.POINTER(CProblem), C.c_double, C.c_int32, c_double_p, c_double_p,
                                    c_double_p, c_double_p, c_double_p, c_int32_p]),
+    "admm_record_sizes_alt": (C.c_int, [C.c_int32, C.c_int32, c_int32_p, c_int32_p]),
+    "admm_host_factor_alt": (C.c_int, [C.POINTER(CProblem), C.c_double, C.c_int32, c_double_p, c_double_p,
+                                       c_double_p, c_int32_p]),
 }
 
 
@@ -312,6 +315,15 @@ def host_factor(problem: Problem, rho: float, segments: int):
     _check(lib, lib.admm_host_scan_matrix(C.byref(cp), float(rho), S, None, C.byref(M), C.byref(Mt), C.byref(Kd)))
     W = np.empty((M.value, Kd.value))
     _check(lib, lib.admm_host_scan_matrix(C.byref(cp), float(rho), S, dptr(W), None, None, None))
+    out = {"K": K, "Sinv": Sinv, "recB": recB, "recF": recF, "recS": recS, "seg_start": seg,
+           "scanW": W, "scanMt": Mt.value, "alt_ok": False}
+    # records of the alternating-direction iteration
+    rfe, rbe, ok = C.c_int32(), C.c_int32(), C.c_int32()
+    _check(lib, lib.admm_record_sizes_alt(n, m, C.byref(rfe), C.byref(rbe)))
+    recFE = np.empty((N, rfe.value)); recBE = np.empty((N, rbe.value)); WB = np.empty_like(W)
+    _check(lib, lib.admm_host_factor_alt(C.byref(cp), float(rho), S, dptr(recFE), dptr(recBE), dptr(WB),
+                                         C.byref(ok)))
+    if ok.value:
+        out.update(alt_ok=True, recFE=recFE, recBE=recBE, scanWB=WB)
     del keep
-    return {"K": K, "Sinv": Sinv, "recB": recB, "recF": recF, "recS": recS, "seg_start": seg,
-            "scanW": W, "scanMt": Mt.value}
+    return out

@@ -215,6 +215,16 @@ int admm_host_factor(const admm_problem* p, double rho, int32_t segments, double
 int admm_host_scan_matrix(const admm_problem* p, double rho, int32_t segments, double* W, int32_t* M,
                           int32_t* Mt, int32_t* K);
 
+/* Alternating-direction iteration: per-stage records of the two fused kernels
+ * (rfe / rbe doubles per stage; layouts in csrc/admm_layout.hpp) and the dense scan matrix WB of
+ * the forward-elimination form (same M x K shape and row / column layout as W above:
+ *   [m_in(0..S-1) | pad to Mt | lam_in(0..S-1) | pad] = WB [mseg(0..S-1) | x0 | epsseg(0..S-1) | pad]).
+ * *ok = 0 if that form could not be built for this problem (outputs are then untouched).
+ * Any output pointer may be NULL. */
+int admm_record_sizes_alt(int32_t n, int32_t m, int32_t* rfe, int32_t* rbe);
+int admm_host_factor_alt(const admm_problem* p, double rho, int32_t segments, double* recFE, double* recBE,
+                         double* WB, int32_t* ok);
+
 const char* admm_last_error(void);
 int admm_abi_version(void);
 /* Number of HIP devices visible (0 if none / no driver). */

@@ -120,3 +120,76 @@ def x_update_segmented(rec, n, m, g, x0, scan="chain", return_parts=False):
     if return_parts:
         return w.reshape(batch, N * nb), dict(tin=tin, xin=xin, chain=chain if scan == "gemm" else None)
     return w.reshape(batch, N * nb)
+
+
+# ---------------------------------------------------------------------------
+# Alternating-direction iteration: the forward-elimination /
+# backward-substitution form of the x-update, from the host records recFE /
+# recBE and the scan matrix scanWB.  Mirrors the elimination half of
+# xfze_kernel, xscan_mfma_kernel and the substitution half of xbze_kernel.
+# ---------------------------------------------------------------------------
+def _blocks(a, spec):
+    N = a.shape[0]
+    out, o = {}, 0
+    for name, rows, cols in spec:
+        out[name] = a[:, o:o + rows * cols].reshape(N, rows, cols)
+        assert not a[:, o + rows * cols:o + _even(rows * cols)].any()
+        o += _even(rows * cols)
+    return out, o
+
+
+def unpack_alt(rec, n, m):
+    nb = n + m
+    fe, o = _blocks(rec["recFE"], (("PSI", m, n), ("K", m, n), ("A", n, n), ("B", n, m), ("FM", n, n), ("GA", n, m),
+                                   ("PI", n, n), ("YU", n, m), ("YX", n, n)))
+    assert o + 2 * _even(nb) + 2 == rec["recFE"].shape[1]
+    be, o = _blocks(rec["recBE"], (("PHF", n, n), ("CM", n, n), ("QM", n, n), ("RB", m, n), ("RI", m, m), ("AT", n, n),
+                                   ("BT", m, n), ("SI", m, m), ("KT", n, m), ("OM", n, m)))
+    assert o + 2 * _even(nb) + 2 == rec["recBE"].shape[1]
+    u = unpack(rec, n, m)
+    for k in ("PSI", "K", "A", "B"):
+        assert np.array_equal(fe[k], u[k])
+    for k in ("AT", "BT", "SI", "KT", "OM"):
+        assert np.array_equal(be[k], u[k])
+    fe.update(be)
+    return fe
+
+
+def x_update_alt(rec, n, m, g, x0):
+    """The x-update by forward elimination (segment-local), one dense scan product and backward
+    substitution.  g: (batch, L), x0: (batch, n).  Returns w (batch, L)."""
+    a = unpack_alt(rec, n, m)
+    seg = rec["seg_start"]
+    S = len(seg) - 1
+    N = rec["recFE"].shape[0]
+    nb = n + m
+    batch = g.shape[0]
+    gb = g.reshape(batch, N, nb)
+    mst = np.zeros((N, batch, n)); mseg = np.zeros((S, batch, n)); eseg = np.zeros((S, batch, n))
+    for s in range(S):                                   # elimination half of xfze_kernel
+        mm = np.zeros((batch, n)); ee = np.zeros((batch, n))
+        for k in range(seg[s], seg[s + 1]):
+            gu, gx = gb[:, k, :m], gb[:, k, m:]
+            ee = ee + gu @ a["YU"][k].T + gx @ a["YX"][k].T
+            mm = mm @ a["FM"][k].T + gu @ a["GA"][k].T + gx @ a["PI"][k].T
+            mst[k] = mm
+        mseg[s], eseg[s] = mm, ee
+    Wm, Mt = rec["scanWB"], rec["scanMt"]                # the scan (same kernel, other matrix)
+    cin = np.zeros((Wm.shape[1], batch))
+    cin[:S * n] = mseg.transpose(0, 2, 1).reshape(S * n, batch)
+    cin[S * n:S * n + n] = np.asarray(x0, np.float64).T
+    cin[S * n + n:2 * S * n + n] = eseg.transpose(0, 2, 1).reshape(S * n, batch)
+    out = Wm @ cin
+    min_ = out[:S * n].reshape(S, n, batch).transpose(0, 2, 1)
+    lin = out[Mt:Mt + S * n].reshape(S, n, batch).transpose(0, 2, 1)
+    w = np.zeros((batch, N, nb))
+    for s in range(S):                                   # substitution half of xbze_kernel
+        lam = lin[s].copy()
+        for k in range(seg[s + 1] - 1, seg[s] - 1, -1):
+            x = mst[k] + min_[s] @ a["PHF"][k].T + lam @ a["CM"][k].T
+            nu = lam - x @ a["QM"][k].T - gb[:, k, m:]
+            u = nu @ a["RB"][k].T - gb[:, k, :m] @ a["RI"][k].T
+            lam = nu @ a["AT"][k].T
+            w[:, k, :m] = u
+            w[:, k, m:] = x
+    return w.reshape(batch, N * nb)

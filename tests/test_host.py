@@ -16,7 +16,7 @@ import admm_ref as ar
 import oracle_c as oc
 from admm_library_amd import _abi
 from admm_library_amd.solver import host_factor
-from _segmented import x_update_segmented
+from _segmented import x_update_alt, x_update_segmented
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -111,6 +111,30 @@ def test_segment_algebra_reproduces_sequential_sweep(lib, make, rho, segs):
     assert np.abs(parts["tin"] - tin_c).max() <= 1e-12 * max(1.0, np.abs(tin_c).max())
     assert np.abs(parts["xin"] - xin_c).max() <= 1e-12 * max(1.0, np.abs(xin_c).max())
     assert np.abs(w_ref - w_gemm).max() <= 1e-12 * max(1.0, np.abs(w_ref).max())
+
+
+@pytest.mark.parametrize("make,rho,segs", [
+    (lambda: pkg.random_ltv(N=40, n=4, m=2, batch=5, seed=1), 0.3, 5),
+    (lambda: pkg.random_ltv(N=37, n=6, m=3, batch=3, seed=2), 0.1, 7),
+    (lambda: pkg.random_ltv(N=9, n=2, m=2, batch=2, seed=3), 0.4, 9),      # one stage per segment
+    (lambda: pkg.cw_rendezvous(N=1000, batch=3), 0.05, 16),
+    (lambda: pkg.cw_rendezvous(N=1000, batch=2), 0.8, 1),                  # no segmentation
+    (lambda: pkg.cw_rendezvous(N=1000, batch=2), 0.05, 64),
+    (lambda: pkg.double_integrator(N=50, batch=3), 1.0, 6),
+    (lambda: pkg.random_ltv(N=24, n=3, m=1, batch=3, seed=4), 0.2, 4),     # m < n: singular C_k for k < n
+])
+def test_alternating_form_reproduces_sequential_sweep(lib, make, rho, segs):
+    """the forward-elimination / backward-substitution form of the x-update
+    (odd iterations of the alternating scheme), emulated in NumPy from the host records
+    recFE / recBE and the scan matrix WB, equals the oracle's backward Riccati sweep."""
+    p = make()
+    g = np.random.default_rng(8).standard_normal((p.batch, p.L))
+    f = ar.factor(p.A, p.B, p.Q, p.R, p.QN, rho, p.N)
+    w_ref = ar.x_update(f, g, p.x0)
+    rec = host_factor(p, rho, segs)
+    assert rec["alt_ok"]
+    w_alt = x_update_alt(rec, p.n, p.m, g, p.x0)
+    assert np.abs(w_ref - w_alt).max() <= 1e-11 * max(1.0, np.abs(w_ref).max())
 
 
 def _setup_rc(lib, p, opt=None):
