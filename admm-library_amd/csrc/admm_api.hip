@@ -60,6 +60,17 @@ struct admm_handle {
   double *recB = nullptr, *recF = nullptr, *recS = nullptr;
   double *scan_in = nullptr, *scan_out = nullptr, *scanWp = nullptr;   // tseg|x0|eseg and t_in|x_in live inside these
   int* scan_range = nullptr;
+  // alternating-direction iteration
+  double *recFE = nullptr, *recBE = nullptr, *mvec = nullptr, *scanWpB = nullptr;
+  int* scan_rangeB = nullptr;
+  bool alt = false;              // the alternating kernels exist for this problem and are enabled
+  // what the last kernel left behind for the next x-update:
+  //   ALT_NONE  nothing (the next iteration starts with xb_kernel)
+  //   ALT_FWD   xfze ran: mvec | mseg | epsseg  -> next: scan (WB) + xbze
+  //   ALT_BWD   xbze ran: dbuf | tseg | eseg    -> next: scan (W)  + xfze   (w of that iteration cannot be
+  //             re-materialised, so no API call ever returns in this state)
+  enum { ALT_NONE = 0, ALT_FWD = 1, ALT_BWD = 2 };
+  int alt_state = ALT_NONE;
   int *seg_start = nullptr, *status = nullptr, *iters = nullptr, *nconv = nullptr;
   double* stage = nullptr;      // QP-major staging buffer, L * batch
   int* h_nconv = nullptr;       // pinned
@@ -70,9 +81,9 @@ struct admm_handle {
   bool v_valid = false;         // h->v holds the current state
   bool zy_valid = true;         // h->z, h->y hold the current state
   // captured iterations, replayed by admm_run / admm_solve:
-  //   [0] x-update + plain z step;  [1] x-update + residual z step + finalise (it = 0)
-  hipGraph_t graph[2] = {nullptr, nullptr};
-  hipGraphExec_t graph_exec[2] = {nullptr, nullptr};
+  //   [2 t + r]: iteration form t (IT_PLAIN .. IT_BWD below), r = 1 with residuals + finalise (it = 0)
+  hipGraph_t graph[8] = {};
+  hipGraphExec_t graph_exec[8] = {};
 };
 
 namespace {
@@ -90,6 +101,7 @@ admm::XLaunch xlaunch_of(const admm_handle* h) {
   l.rho = h->opt.rho; l.alpha = h->opt.alpha;
   l.z = h->z; l.y = h->y; l.q = h->q; l.v = h->v; l.w = h->w;
   l.recB = h->recB; l.recF = h->recF; l.recS = h->recS; l.seg_start = h->seg_start;
+  l.recFE = h->recFE; l.recBE = h->recBE; l.mvec = h->mvec;
   l.dbuf = h->dbuf; l.tseg = h->tseg; l.eseg = h->eseg; l.tin = h->tin; l.xin = h->xin; l.part = h->part;
   l.x0 = h->x0;
   const bool chain = (h->opt.flags & ADMM_FLAG_SCAN_CHAIN) != 0;     // the chain scan writes slab 0 only
@@ -123,11 +135,13 @@ int launch_xb(admm_handle* h, bool vform) { return launch_x(h, admm::XKernel::XB
 
 static_assert(admm::SCAN_KALIGN == admm::SCAN_U, "host range alignment must match the kernel's batch");
 
-int launch_xscan_mfma(admm_handle* h) {
+// forward_form: the scan of the forward-elimination form (matrix WB)
+int launch_xscan_mfma(admm_handle* h, bool forward_form = false) {
   const int mtiles = h->fac.scanM / 16, ngroups = mtiles / admm::SCAN_MT;
   dim3 grid(h->pitch / 64, ngroups, h->scan_split), block(256);
-  hipLaunchKernelGGL((admm::xscan_mfma_kernel<admm::SCAN_MT>), grid, block, 0, h->stream, h->scanWp,
-                     h->scan_in, h->scan_out, h->scan_range, mtiles, ngroups, h->pitch, h->scan_split,
+  hipLaunchKernelGGL((admm::xscan_mfma_kernel<admm::SCAN_MT>), grid, block, 0, h->stream,
+                     forward_form ? h->scanWpB : h->scanWp, h->scan_in, h->scan_out,
+                     forward_form ? h->scan_rangeB : h->scan_range, mtiles, ngroups, h->pitch, h->scan_split,
                      (size_t)h->fac.scanM * h->pitch);
   return ADMM_OK;
 }
@@ -189,6 +203,37 @@ int launch_finalize(admm_handle* h, int it, int nchunks) {
 
 bool fused(const admm_handle* h) { return !(h->opt.flags & ADMM_FLAG_UNFUSED); }
 
+// Iteration forms.  IT_PLAIN is always available; the others need h->alt and
+// the state in v-form.
+enum IterForm {
+  IT_PLAIN = 0,     // xb + scan + xfz                    leaves ALT_NONE
+  IT_FWD_START = 1, // xb + scan + xfze                   leaves ALT_FWD
+  IT_FWD = 2,       // scan + xfze        (needs ALT_BWD) leaves ALT_FWD
+  IT_BWD = 3        // scan (WB) + xbze   (needs ALT_FWD) leaves ALT_BWD
+};
+
+// The form of the next iteration when `remaining` iterations (this one included) are still to be
+// enqueued before control returns to the caller.  A call must never return after IT_BWD (w of that
+// iteration cannot be rebuilt), so a backward iteration is started only if an even number remains.
+IterForm next_form(const admm_handle* h, int remaining) {
+  if (!h->alt || !h->v_valid) return IT_PLAIN;
+  if (h->alt_state == admm_handle::ALT_BWD) return IT_FWD;
+  if (h->alt_state == admm_handle::ALT_FWD && remaining % 2 == 0) return IT_BWD;
+  return remaining >= 2 ? IT_FWD_START : IT_PLAIN;
+}
+
+int enqueue_form(admm_handle* h, IterForm f, bool resid) {
+  int rc;
+  if (f == IT_FWD_START && (rc = launch_xb(h, true))) return rc;
+  if ((rc = launch_xscan_mfma(h, f == IT_BWD))) return rc;
+  return launch_x(h, f == IT_BWD ? admm::XKernel::XBZE : admm::XKernel::XFZE, false, resid);
+}
+
+void after_form(admm_handle* h, IterForm f) {
+  h->v_valid = true; h->zy_valid = false; h->w_stale = true;
+  h->alt_state = f == IT_PLAIN ? admm_handle::ALT_NONE : (f == IT_BWD ? admm_handle::ALT_BWD : admm_handle::ALT_FWD);
+}
+
 // One full iteration on the stream: x-update + z/dual (+ residual partials).
 // Fused path: state in = h->v if use_v else h->z / h->y; state out = h->v.
 // Unfused path: state in and out = h->z / h->y (caller has made them valid).
@@ -209,6 +254,7 @@ int enqueue_iteration(admm_handle* h, bool resid, bool use_v) {
 // bookkeeping after `count` enqueued iterations
 void after_iterations(admm_handle* h, int count) {
   if (count <= 0) return;
+  h->alt_state = admm_handle::ALT_NONE;
   if (fused(h)) { h->v_valid = true; h->zy_valid = false; h->w_stale = true; }
   else          { h->zy_valid = true; h->v_valid = false; h->w_stale = false; }
 }
@@ -226,6 +272,7 @@ int ensure_w(admm_handle* h) {
 
 int step_x(admm_handle* h) {
   int rc;
+  h->alt_state = admm_handle::ALT_NONE;     // xb and the scan overwrite what a fused elimination left
   if ((rc = launch_xb(h, h->v_valid))) return rc;
   if ((rc = launch_xscan(h))) return rc;
   if ((rc = launch_xf(h))) return rc;
@@ -305,7 +352,7 @@ int validate_problem(const admm_problem* p) {
 }
 
 void destroy_graph(admm_handle* h) {
-  for (int v = 0; v < 2; ++v) {
+  for (int v = 0; v < 8; ++v) {
     if (h->graph_exec[v]) { (void)hipGraphExecDestroy(h->graph_exec[v]); h->graph_exec[v] = nullptr; }
     if (h->graph[v]) { (void)hipGraphDestroy(h->graph[v]); h->graph[v] = nullptr; }
   }
@@ -316,10 +363,11 @@ void release(admm_handle* h) {
   (void)hipSetDevice(h->device);
   destroy_graph(h);
   double** bufs[] = {&h->w, &h->z, &h->y, &h->v, &h->q, &h->dbuf, &h->scan_in, &h->scan_out, &h->scanWp,
-                     &h->part, &h->resid, &h->lo, &h->hi, &h->ub, &h->recB, &h->recF, &h->recS, &h->stage};
+                     &h->part, &h->resid, &h->lo, &h->hi, &h->ub, &h->recB, &h->recF, &h->recS, &h->stage,
+                     &h->recFE, &h->recBE, &h->mvec, &h->scanWpB};
   for (auto b : bufs)
     if (*b) { (void)hipFree(*b); *b = nullptr; }
-  int** ibufs[] = {&h->seg_start, &h->status, &h->iters, &h->nconv, &h->scan_range};
+  int** ibufs[] = {&h->seg_start, &h->status, &h->iters, &h->nconv, &h->scan_range, &h->scan_rangeB};
   for (auto b : ibufs)
     if (*b) { (void)hipFree(*b); *b = nullptr; }
   if (h->h_nconv) { (void)hipHostFree(h->h_nconv); h->h_nconv = nullptr; }
@@ -336,10 +384,12 @@ int dalloc(T** p, size_t count) {
 
 int capture_iterations(admm_handle* h) {
   destroy_graph(h);
-  for (int v = 0; v < 2; ++v) {
+  for (int v = 0; v < (h->alt ? 8 : 2); ++v) {
     HIP_TRY(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-    int rc = enqueue_iteration(h, v == 1, /*use_v=*/true);   // steady state of the fused path
-    if (!rc && v == 1) rc = launch_finalize(h, 0, chunks_of_iteration(h));
+    const bool res = (v & 1) != 0;
+    int rc = v < 2 ? enqueue_iteration(h, res, /*use_v=*/true)   // steady state of the fused path
+                   : enqueue_form(h, (IterForm)(v >> 1), res);
+    if (!rc && res) rc = launch_finalize(h, 0, chunks_of_iteration(h));
     hipGraph_t g = nullptr;
     hipError_t e = hipStreamEndCapture(h->stream, &g);
     if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
@@ -592,6 +642,22 @@ int admm_setup(admm_handle** out, const admm_problem* p, const admm_options* o_i
     TRY_RELEASE(dalloc(&h->scanWp, h->fac.scanWp.size()));
     TRY_RELEASE(dalloc(&h->scan_range, h->fac.scanRange.size()));
   }
+  // alternating-direction iteration: compiled for this (n, m), buildable for this problem, not disabled
+  h->alt = h->fac.alt_ok && !h->has_q && !h->has_soc && fused(h) &&
+           !(h->opt.flags & (ADMM_FLAG_SCAN_CHAIN | ADMM_FLAG_NO_ALTERNATE)) &&
+           dispatch_x(xlaunch_of(h), admm::XKernel::XFZE, false, false, /*query_only=*/true);
+  if (h->alt) {
+    TRY_RELEASE(dalloc(&h->recFE, h->fac.recFE.size()));
+    TRY_RELEASE(dalloc(&h->recBE, h->fac.recBE.size()));
+    TRY_RELEASE(dalloc(&h->scanWpB, h->fac.scanWpB.size()));
+    TRY_RELEASE(dalloc(&h->scan_rangeB, h->fac.scanRangeB.size()));
+    TRY_RELEASE(dalloc(&h->mvec, (size_t)h->N * h->n * P));
+    HIP_TRY_RELEASE(hipMemsetAsync(h->mvec, 0, sizeof(double) * (size_t)h->N * h->n * P, h->stream));
+    HIP_TRY_RELEASE(hipMemcpy(h->recFE, h->fac.recFE.data(), sizeof(double) * h->fac.recFE.size(), hipMemcpyHostToDevice));
+    HIP_TRY_RELEASE(hipMemcpy(h->recBE, h->fac.recBE.data(), sizeof(double) * h->fac.recBE.size(), hipMemcpyHostToDevice));
+    HIP_TRY_RELEASE(hipMemcpy(h->scanWpB, h->fac.scanWpB.data(), sizeof(double) * h->fac.scanWpB.size(), hipMemcpyHostToDevice));
+    HIP_TRY_RELEASE(hipMemcpy(h->scan_rangeB, h->fac.scanRangeB.data(), sizeof(int32_t) * h->fac.scanRangeB.size(), hipMemcpyHostToDevice));
+  }
   const size_t part_chunks = (size_t)(h->zchunks > h->S ? h->zchunks : h->S);
   TRY_RELEASE(dalloc(&h->part, part_chunks * 5 * P));
   TRY_RELEASE(dalloc(&h->resid, 5 * P));
@@ -653,6 +719,7 @@ int admm_update_instances(admm_handle* h, const double* x0, const double* q) {
   HIP_TRY(hipSetDevice(h->device));
   int rc;
   if ((x0 || q) && (rc = ensure_w(h))) return rc;   // w of the last x-update belongs to the old instance data
+  if (x0 || q) h->alt_state = admm_handle::ALT_NONE;
   if (x0) {
     if (!finite_all(x0, (size_t)h->n * h->batch)) return fail(ADMM_ERR_INVALID, "non-finite entry in x0");
     if ((rc = upload_transposed(h, x0, h->x0, h->n))) return rc;
@@ -700,6 +767,14 @@ static int set_rho_internal(admm_handle* h, double rho_new) {
   HIP_TRY(hipMemcpy(h->recS, h->fac.recS.data(), sizeof(double) * h->fac.recS.size(), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(h->scanWp, h->fac.scanWp.data(), sizeof(double) * h->fac.scanWp.size(), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(h->scan_range, h->fac.scanRange.data(), sizeof(int32_t) * h->fac.scanRange.size(), hipMemcpyHostToDevice));
+  h->alt_state = admm_handle::ALT_NONE;
+  if (h->alt && !h->fac.alt_ok) h->alt = false;            // the forward-elimination form did not survive the new rho
+  if (h->alt) {
+    HIP_TRY(hipMemcpy(h->recFE, h->fac.recFE.data(), sizeof(double) * h->fac.recFE.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->recBE, h->fac.recBE.data(), sizeof(double) * h->fac.recBE.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->scanWpB, h->fac.scanWpB.data(), sizeof(double) * h->fac.scanWpB.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->scan_rangeB, h->fac.scanRangeB.data(), sizeof(int32_t) * h->fac.scanRangeB.size(), hipMemcpyHostToDevice));
+  }
   h->opt.rho = rho_new;
   destroy_graph(h);                                        // rho is a captured kernel argument
   return ADMM_OK;
@@ -725,6 +800,7 @@ int admm_set_state(admm_handle* h, const double* w, const double* z, const doubl
     if (y && (rc = upload_transposed(h, y, h->y, h->L))) return rc;
     h->zy_valid = true;
     h->v_valid = false;                         // an arbitrary (z, y) pair need not be of the form (clip(v), v - clip(v))
+    h->alt_state = admm_handle::ALT_NONE;
   }
   return ADMM_OK;
 }
@@ -748,6 +824,7 @@ int admm_step_z(admm_handle* h, int32_t residuals) {
   if (!rc) rc = launch_z(h, residuals != 0);
   if (rc) return rc;
   h->v_valid = false;
+  h->alt_state = admm_handle::ALT_NONE;
   if (residuals) {
     launch_finalize(h, 0, h->zchunks);
     h->resid_valid = true;
@@ -760,11 +837,30 @@ int admm_step_z(admm_handle* h, int32_t residuals) {
 // Enqueue iteration number `it` (1-based within the caller's loop).  The graphs hold the
 // steady-state kernel forms; an iteration whose input state is not in that form (first
 // fused iteration after setup / set_state / an unfused step) is launched directly.
-static int enqueue_one(admm_handle* h, bool resid, bool use_graph) {
+// `remaining` = iterations (this one included) the caller still enqueues before it returns:
+// it selects the iteration form (next_form).  it_number > 0: a checked iteration of admm_solve
+// (residuals + finalise with that iteration number, launched directly).
+static int enqueue_one(admm_handle* h, bool resid, bool use_graph, int remaining, int it_number = 0) {
   int rc;
   const bool steady = fused(h) ? h->v_valid : h->zy_valid;
   if (!fused(h) && !h->zy_valid && (rc = ensure_zy(h))) return rc;
-  if (use_graph && steady) {
+  const IterForm form = next_form(h, remaining);
+  if (form != IT_PLAIN) {
+    if (use_graph && it_number == 0) {
+      HIP_TRY(hipGraphLaunch(h->graph_exec[2 * (int)form + (resid ? 1 : 0)], h->stream));
+    } else {
+      rc = enqueue_form(h, form, resid);
+      if (!rc && resid) rc = launch_finalize(h, it_number, chunks_of_iteration(h));
+      if (rc) return rc;
+    }
+    after_form(h, form);
+    if (resid) h->resid_valid = true;
+    return ADMM_OK;
+  }
+  if (it_number > 0) {
+    if ((rc = enqueue_iteration(h, true, fused(h) && h->v_valid))) return rc;
+    if ((rc = launch_finalize(h, it_number, chunks_of_iteration(h)))) return rc;
+  } else if (use_graph && steady) {
     HIP_TRY(hipGraphLaunch(h->graph_exec[resid ? 1 : 0], h->stream));
   } else {
     rc = enqueue_iteration(h, resid, fused(h) && h->v_valid);
@@ -787,7 +883,7 @@ int admm_run(admm_handle* h, int32_t iters, int32_t residual_every) {
   }
   for (int it = 1; it <= iters; ++it) {
     const bool resid = residual_every > 0 && (it % residual_every == 0);
-    int rc = enqueue_one(h, resid, use_graph);
+    int rc = enqueue_one(h, resid, use_graph, iters - it + 1);
     if (rc) return rc;
   }
   HIP_TRY(hipGetLastError());
@@ -837,15 +933,13 @@ int admm_solve_step(admm_handle* h, int32_t* iters_done, int32_t* n_converged, d
     const int it = ++h->solve_it;
     const bool check = (it % ci == 0) || it == h->opt.max_iter;
     if (!check) {
-      if ((rc = enqueue_one(h, false, use_graph))) return rc;
+      const int next_check = std::min(((it / ci) + 1) * ci, h->opt.max_iter);
+      if ((rc = enqueue_one(h, false, use_graph, next_check - it + 1))) return rc;
       continue;
     }
     // checked iteration: launched directly so that the finalise kernel gets the iteration number
-    if (!fused(h) && (rc = ensure_zy(h))) return rc;
-    if ((rc = enqueue_iteration(h, true, fused(h) && h->v_valid))) return rc;
-    after_iterations(h, 1);
     HIP_TRY(hipMemsetAsync(h->nconv, 0, sizeof(int), h->stream));
-    launch_finalize(h, it, chunks_of_iteration(h));
+    if ((rc = enqueue_one(h, true, use_graph, 1, it))) return rc;
     HIP_TRY(hipMemcpyAsync(h->h_nconv, h->nconv, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->solve_nconv = *h->h_nconv;
@@ -970,11 +1064,40 @@ int admm_profile(admm_handle* h, int32_t iters, int32_t residuals, int32_t fused
   if (iters < 1 || iters > 4096) return fail(ADMM_ERR_INVALID, "iters must lie in [1, 4096]");
   HIP_TRY(hipSetDevice(h->device));
   constexpr int NE = 6;     // events per iteration
+  if (fused_path == 2 && !h->alt) return fail(ADMM_ERR_UNSUPPORTED, "the alternating-direction kernels are not enabled for this handle");
   std::vector<hipEvent_t> ev((size_t)iters * NE);
   for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
   int rc = ADMM_OK;
   const bool res = residuals != 0;
-  for (int it = 0; it < iters && !rc; ++it) {
+  h->alt_state = admm_handle::ALT_NONE;       // the plain kernels are profiled; they overwrite the scan operands
+  if (fused_path == 2) {
+    // `iters` PAIRS of alternating iterations (forward form, backward form); ms[] = scan, xfze,
+    // (finalise +) scan, xbze, finalise, whole pair.  2 iters + 1 (+1) iterations are applied.
+    if (!h->v_valid) {
+      rc = enqueue_iteration(h, false, false);
+      if (!rc) after_iterations(h, 1);
+    }
+    if (!rc) rc = launch_xb(h, true);
+    for (int it = 0; it < iters && !rc; ++it) {
+      hipEvent_t* e = &ev[(size_t)it * NE];
+      HIP_TRY(hipEventRecord(e[0], h->stream));
+      rc = launch_xscan_mfma(h, false);
+      HIP_TRY(hipEventRecord(e[1], h->stream));
+      if (!rc) rc = launch_x(h, admm::XKernel::XFZE, false, res);
+      HIP_TRY(hipEventRecord(e[2], h->stream));
+      if (!rc && res) rc = launch_finalize(h, 0, h->S);
+      if (!rc) rc = launch_xscan_mfma(h, true);
+      HIP_TRY(hipEventRecord(e[3], h->stream));
+      if (!rc) rc = launch_x(h, admm::XKernel::XBZE, false, res);
+      HIP_TRY(hipEventRecord(e[4], h->stream));
+      if (!rc && res) rc = launch_finalize(h, 0, h->S);
+      HIP_TRY(hipEventRecord(e[5], h->stream));
+    }
+    if (!rc) rc = enqueue_form(h, IT_FWD, res);           // never stop after the backward form
+    if (!rc && res) rc = launch_finalize(h, 0, h->S);
+    if (!rc) after_form(h, IT_FWD);
+  }
+  for (int it = 0; it < iters && !rc && fused_path != 2; ++it) {
     hipEvent_t* e = &ev[(size_t)it * NE];
     const bool use_v = fused_path && h->v_valid;
     if (!fused_path && (rc = ensure_zy(h))) break;

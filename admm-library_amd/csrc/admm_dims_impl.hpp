@@ -4,6 +4,7 @@
 //   ADMM_GROUP_DIMS(X)   X(n, m) X(n, m) ...
 #include "admm_dispatch.hpp"
 #include "admm_kernels.hpp"
+#include "admm_kernels_alt.hpp"
 
 namespace admm {
 
@@ -58,6 +59,28 @@ void launch_dim(const XLaunch& l, XKernel k, bool a, bool b) {
       hipLaunchKernelGGL((xscan_kernel<NX>), dim3(l.pitch / 64), dim3(64), 0, l.stream, l.tseg, l.eseg, l.x0,
                          l.recS, l.tin, l.xin, l.S, l.pitch);
       break;
+    case XKernel::XFZE:
+    case XKernel::XBZE:
+      if constexpr (alt_dims(NX, NU)) {
+        const bool relax = l.alpha != 1.0;
+        // the scan's input / output slots are shared by both directions: (tseg, eseg) = (mseg, epsseg),
+        // (tin, xin) = (m_in, lam_in)
+#define ALT1(RS, RX)                                                                                         \
+  do {                                                                                                       \
+    if (k == XKernel::XFZE)                                                                                  \
+      hipLaunchKernelGGL((xfze_kernel<NX, NU, RS, RX>), grid, block, 0, l.stream, l.dbuf, l.tin, l.xin,      \
+                         l.recFE, l.seg_start, l.v, l.mvec, l.tseg, l.eseg, l.part, l.alpha, l.rho, l.pitch, \
+                         l.nsplit, l.split_stride);                                                          \
+    else                                                                                                     \
+      hipLaunchKernelGGL((xbze_kernel<NX, NU, RS, RX>), grid, block, 0, l.stream, l.mvec, l.tin, l.xin,      \
+                         l.recBE, l.seg_start, l.v, l.dbuf, l.tseg, l.eseg, l.part, l.alpha, l.rho, l.pitch, \
+                         l.nsplit, l.split_stride);                                                          \
+  } while (0)
+        if (b) { if (relax) ALT1(true, true); else ALT1(true, false); }
+        else   { if (relax) ALT1(false, true); else ALT1(false, false); }
+#undef ALT1
+      }
+      break;
   }
 }
 
@@ -66,6 +89,7 @@ void launch_dim(const XLaunch& l, XKernel k, bool a, bool b) {
 bool ADMM_GROUP_FN(const XLaunch& l, XKernel k, bool a, bool b, bool query_only) {
 #define X(NX, NU)                               \
   if (l.n == NX && l.m == NU) {                 \
+    if ((k == XKernel::XFZE || k == XKernel::XBZE) && !alt_dims(NX, NU)) return false; \
     if (!query_only) launch_dim<NX, NU>(l, k, a, b); \
     return true;                                \
   }

@@ -16,6 +16,8 @@ struct XLaunch {
   const double *z, *y, *q;      // state in (z, y) form and the linear term
   double *v, *w;                // state in v-form; materialised w
   const double *recB, *recF, *recS;
+  const double *recFE, *recBE;  // records of the alternating-direction kernels (admm_kernels_alt.hpp)
+  double* mvec;                 // their per-stage filter means (n rows per stage)
   const int* seg_start;
   double *dbuf, *tseg, *eseg, *tin, *xin, *part;
   const double* x0;
@@ -23,10 +25,11 @@ struct XLaunch {
   size_t split_stride;          // elements between slabs
 };
 
-enum class XKernel { XB, XF, XFZ, XSCAN_CHAIN };
+enum class XKernel { XB, XF, XFZ, XSCAN_CHAIN, XFZE, XBZE };
 
 // Each returns true if (n, m) is compiled in that group (and, unless query_only, the kernel
-// was enqueued on l.stream).  a = VFORM (XB) / VIN (XFZ); b = RESID (XFZ).
+// was enqueued on l.stream).  a = VFORM (XB) / VIN (XFZ); b = RESID (XFZ, XFZE, XBZE).
+// XFZE / XBZE exist only for the pairs alt_dims() accepts: false otherwise.
 bool launch_group0(const XLaunch& l, XKernel k, bool a, bool b, bool query_only);
 bool launch_group1(const XLaunch& l, XKernel k, bool a, bool b, bool query_only);
 bool launch_group2(const XLaunch& l, XKernel k, bool a, bool b, bool query_only);

@@ -145,10 +145,9 @@ __device__ __forceinline__ void lds_block(const double* p, double (&o)[LEN]) {
 // blocks of up to 2 * LDS_GROUP_PAIRS doubles (all of n = 6, m = 3) are unaffected.
 constexpr int LDS_GROUP_PAIRS = 24;
 
-template <int ROWS, int COLS, bool NEG>
+template <int ROWS, int COLS, bool NEG, int G = LDS_GROUP_PAIRS>
 __device__ __forceinline__ void lds_matvec_acc(const double* blk, const double (&x)[COLS], double (&acc)[ROWS]) {
   constexpr int PAIRS = even_up(ROWS * COLS) / 2;
-  constexpr int G = LDS_GROUP_PAIRS;
 #ifndef ADMM_ABLATE_LDS
   const double2* q = reinterpret_cast<const double2*>(blk);
 #else

@@ -1,0 +1,429 @@
+// admm_kernels_alt.hpp -- the two fused kernels of the alternating-direction iteration
+// (DESIGN.md §4.8).  No reference counterpart exists (README.md:1-2 only).
+//
+// The plain iteration sweeps the horizon twice per x-update in opposite directions
+// (xb_kernel backward, xfz_kernel forward), and the next iteration's backward sweep has to
+// re-read the state v the forward sweep has just written.  Here consecutive iterations solve
+// the same KKT system in opposite elimination orders:
+//     even iteration:  backward elimination (Riccati)        + forward substitution
+//     odd iteration:   forward elimination (information form) + backward substitution
+// so every substitution sweep runs in the direction of the NEXT iteration's elimination sweep
+// and the two are one kernel: the fresh v+ of a stage is eliminated while still in registers.
+//     xfze_kernel  (forward):   rollout (as xfz_kernel) | z-update | forward elimination of v+
+//     xbze_kernel  (backward):  costate substitution    | z-update | backward elimination of v+
+// One kernel + one scan per iteration.  Algorithmic HBM bytes per stacked element (n = 6, m = 3):
+//     xfze: d read 2.67 + v read 8 + v+ written 8 + m written 5.33 = 24
+//     xbze: m read 5.33 + v read 8 + v+ written 8 + d written 2.67 = 24
+// against 29.33 for xb + xfz.  Same layout, staging and addressing as admm_kernels.hpp.
+#pragma once
+
+#include "admm_kernels.hpp"
+
+namespace admm {
+
+// Operand prefetch depth (stages) of the forward / backward fused kernel.
+#ifndef ADMM_ALT_PF_F
+#define ADMM_ALT_PF_F 2
+#endif
+#ifndef ADMM_ALT_PF_B
+#define ADMM_ALT_PF_B 1
+#endif
+// Register budget of the fused kernels: asking for two waves per SIMD caps a wave at 256 registers
+// (arch + accumulator), which keeps the whole working set in arch VGPRs.  Left at (1, 2) the
+// scheduler spends up to 512, parks the operand prefetch ring in accumulator registers and then
+// serialises every prefetch load behind an `s_waitcnt vmcnt(0)` + v_accvgpr_write (measured: 3x slower).
+#ifndef ADMM_ALT_MIN_WAVES
+#define ADMM_ALT_MIN_WAVES 2
+#endif
+#define ADMM_ALT_OCCUPANCY __attribute__((amdgpu_waves_per_eu(ADMM_ALT_MIN_WAVES, 2)))
+
+// 16-byte operand pairs read from LDS ahead of their FMAs in the fused kernels' mat-vecs (see
+// lds_matvec_acc): smaller than the plain kernels' 24, again for registers.
+#ifndef ADMM_ALT_G_F
+#define ADMM_ALT_G_F 12
+#endif
+#ifndef ADMM_ALT_G_B
+#define ADMM_ALT_G_B 12
+#endif
+
+// the alternating kernels are compiled for the block sizes that stay in registers
+constexpr bool alt_dims(int nx, int nu) { return nx + nu <= 9; }
+
+// Sum of the (<= 8) split-K slabs of one scan output row (see xf_kernel).
+__device__ __forceinline__ double scan_row(const double* base, size_t o, int nsplit, size_t split_stride) {
+  double p[8];
+#pragma unroll
+  for (int sp = 0; sp < 8; ++sp) p[sp] = base[(size_t)(sp < nsplit ? sp : 0) * split_stride + o];
+  double a = p[0];
+#pragma unroll
+  for (int sp = 1; sp < 8; ++sp) a += (sp < nsplit) ? p[sp] : 0.0;
+  return a;
+}
+
+// ---------------------------------------------------------------------------
+// Forward fused kernel.  One lane = one QP, blockIdx.y = segment, stages k = a .. b-1:
+//     d  = d0_k + Psi_k t_in;  u = -K_k x - d;  x = A_k x + B_k u         (w block k = (u, x))
+//     (z, y) = (clip(v), v - clip(v));  wh = alpha w + (1 - alpha) z;  v+ = wh + y   -> v (in place)
+//     z+ = clip(v+), y+ = v+ - z+;  RESID: the five per-QP partial sums           -> part
+//     g  = -rho (z+ - y+)                                 (linear term of the NEXT x-update)
+//     eps += YU_k g^u + YX_k g^x
+//     mu  = FM_k mu + GA_k g^u + PI_k g^x                 (mu = 0 on entry)        -> mvec block k
+// and on exit mu -> mseg[s], eps -> epsseg[s].
+// ---------------------------------------------------------------------------
+template <int NX, int NU, bool RESID, bool RELAX>
+__global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY void xfze_kernel(
+    const double* __restrict__ dbuf, const double* __restrict__ tin, const double* __restrict__ xin,
+    const double* __restrict__ recFE, const int* __restrict__ seg_start_, double* __restrict__ v,
+    double* __restrict__ mvec, double* __restrict__ mseg, double* __restrict__ epsseg,
+    double* __restrict__ part, double alpha, double rho, int pitch, int nsplit, size_t split_stride) {
+  constexpr int NB = NX + NU;
+  constexpr RecFELayout LF = rec_fe_layout(NX, NU);
+  constexpr int RF = LF.SIZE;
+  constexpr int PF = ADMM_ALT_PF_F;
+  constexpr int ALT_G = ADMM_ALT_G_F;
+  constexpr int CH = stage_chunk(RF, PF);
+  __shared__ __attribute__((aligned(16))) double rec[CH * RF];
+
+  const int col_raw = blockIdx.x * XB_THREADS + threadIdx.x;
+  const int col = col_raw < pitch ? col_raw : pitch - 1;      // clamped lanes: loads only (see xb_kernel)
+  const unsigned lb_st = col_raw < pitch ? (unsigned)col * 8u : ROWVIEW_OOB;
+  const int s = blockIdx.y;
+  cint_p seg_start = as_const(seg_start_);
+  const int k0 = seg_start[s], k1 = seg_start[s + 1];
+  const size_t P = (size_t)pitch;
+  const unsigned lb = (unsigned)col * 8u;
+  const unsigned PB = (unsigned)pitch * 8u;
+  const RowView vv(v, (size_t)k0 * NB * P, (size_t)(k1 - k0) * NB * P * 8);
+  const RowView vd(dbuf, (size_t)k0 * NU * P, (size_t)(k1 - k0) * NU * P * 8);
+  const RowView vm(mvec, (size_t)k0 * NX * P, (size_t)(k1 - k0) * NX * P * 8);
+  double t[NX], x[NX], mu[NX], eps[NX];
+  {
+    const size_t o = (size_t)s * NX * P + col;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      t[i] = scan_row(tin, o + i * P, nsplit, split_stride);
+      x[i] = scan_row(xin, o + i * P, nsplit, split_stride);
+      mu[i] = 0.0;
+      eps[i] = 0.0;
+    }
+  }
+  double ld[PF][NU], l0[PF][NB];
+#pragma unroll
+  for (int j = 0; j < PF; ++j) {
+    const int kj = (k0 + j < k1) ? k0 + j : k1 - 1;
+    const unsigned d0 = (unsigned)(kj - k0) * NU * PB;
+#pragma unroll
+    for (int jj = 0; jj < NU; ++jj) ld[j][jj] = vd.load(lb, d0 + jj * PB);
+    const unsigned r0 = (unsigned)(kj - k0) * NB * PB;
+#pragma unroll
+    for (int r = 0; r < NB; ++r) l0[j][r] = vv.load(lb, r0 + r * PB);
+  }
+  double a_r = 0, a_s = 0, a_w = 0, a_z = 0, a_y = 0;
+  for (int kc = k0; kc < k1; kc += CH) {
+    const int khi = (kc + CH - 1 < k1 - 1) ? kc + CH - 1 : k1 - 1;
+    __syncthreads();
+    stage_records<XB_THREADS>(rec, recFE + (size_t)kc * RF, (khi - kc + 1) * RF, threadIdx.x);
+    __syncthreads();
+    for (int kb = kc; kb <= khi; kb += PF) {
+#pragma unroll
+      for (int j = 0; j < PF; ++j) {
+        const int k = kb + j;
+        if (k > khi) break;
+        const double* rf = rec + (k - kc) * RF;
+        double d[NU], c0[NB];
+#pragma unroll
+        for (int jj = 0; jj < NU; ++jj) d[jj] = ld[j][jj];
+#pragma unroll
+        for (int r = 0; r < NB; ++r) c0[r] = l0[j][r];
+        {  // refill this slot with stage k + PF (clamped; see xfz_kernel)
+          const int kn = (k + PF < k1) ? k + PF : k1 - 1;
+          const unsigned d0 = (unsigned)(kn - k0) * NU * PB;
+#pragma unroll
+          for (int jj = 0; jj < NU; ++jj) ld[j][jj] = vd.load(lb, d0 + jj * PB);
+          const unsigned r0 = (unsigned)(kn - k0) * NB * PB;
+#pragma unroll
+          for (int r = 0; r < NB; ++r) l0[j][r] = vv.load(lb, r0 + r * PB);
+        }
+        // ---- substitution: rollout of stage k ----
+        double wv[NB];
+        {
+          double uacc[NU], xn[NX];
+#pragma unroll
+          for (int jj = 0; jj < NU; ++jj) uacc[jj] = d[jj];
+          lds_matvec_acc<NU, NX, false, ALT_G>(rf + LF.PSI, t, uacc);
+          lds_matvec_acc<NU, NX, false, ALT_G>(rf + LF.K, x, uacc);
+          double uu[NU];
+#pragma unroll
+          for (int jj = 0; jj < NU; ++jj) { wv[jj] = -uacc[jj]; uu[jj] = wv[jj]; }
+#pragma unroll
+          for (int i = 0; i < NX; ++i) xn[i] = 0.0;
+          lds_matvec_acc<NX, NX, false, ALT_G>(rf + LF.A, x, xn);
+          lds_matvec_acc<NX, NU, false, ALT_G>(rf + LF.B, uu, xn);
+#pragma unroll
+          for (int i = 0; i < NX; ++i) { wv[NU + i] = xn[i]; x[i] = xn[i]; }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- z-update, dual ascent, residual partials; g = linear term of the next x-update ----
+        double mLO[even_up(NB)], mHI[even_up(NB)], g[NB];
+        lds_block(rf + LF.LO, mLO);
+        lds_block(rf + LF.HI, mHI);
+        const unsigned r0 = (unsigned)(k - k0) * NB * PB;
+#pragma unroll
+        for (int r = 0; r < NB; ++r) {
+          const double zo = fmin(fmax(c0[r], mLO[r]), mHI[r]);
+          const double yo = c0[r] - zo;
+          double wh = wv[r];
+          if (RELAX) wh = fma(alpha, wv[r], (1.0 - alpha) * zo);
+          const double vn = wh + yo;
+          vv.store(vn, lb_st, r0 + r * PB);
+          const double zn = fmin(fmax(vn, mLO[r]), mHI[r]);
+          const double yn = vn - zn;
+          g[r] = -rho * (zn - yn);
+          if (RESID) {
+            const double dr = wv[r] - zn, ds = zn - zo;
+            a_r = fma(dr, dr, a_r);
+            a_s = fma(ds, ds, a_s);
+            a_w = fma(wv[r], wv[r], a_w);
+            a_z = fma(zn, zn, a_z);
+            a_y = fma(yn, yn, a_y);
+          }
+          if (r % 3 == 2) __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- forward elimination of stage k for the next x-update ----
+        {
+          double gu[NU], gx[NX], mn[NX];
+#pragma unroll
+          for (int jj = 0; jj < NU; ++jj) gu[jj] = g[jj];
+#pragma unroll
+          for (int i = 0; i < NX; ++i) { gx[i] = g[NU + i]; mn[i] = 0.0; }
+          lds_matvec_acc<NX, NU, false, ALT_G>(rf + LF.YU, gu, eps);
+          lds_matvec_acc<NX, NX, false, ALT_G>(rf + LF.YX, gx, eps);
+          __builtin_amdgcn_sched_barrier(0);
+          lds_matvec_acc<NX, NX, false, ALT_G>(rf + LF.FM, mu, mn);
+          lds_matvec_acc<NX, NU, false, ALT_G>(rf + LF.GA, gu, mn);
+          lds_matvec_acc<NX, NX, false, ALT_G>(rf + LF.PI, gx, mn);
+          const unsigned m0 = (unsigned)(k - k0) * NX * PB;
+#pragma unroll
+          for (int i = 0; i < NX; ++i) {
+            mu[i] = mn[i];
+            vm.store(mn[i], lb_st, m0 + i * PB);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  if (col_raw < pitch) {
+    const size_t o = (size_t)s * NX * P + col;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      mseg[o + i * P] = mu[i];
+      epsseg[o + i * P] = eps[i];
+    }
+    if (RESID) {
+      const size_t op = (size_t)s * 5 * P + col;
+      part[op + 0 * P] = a_r;
+      part[op + 1 * P] = a_s;
+      part[op + 2 * P] = a_w;
+      part[op + 3 * P] = a_z;
+      part[op + 4 * P] = a_y;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Backward fused kernel.  One lane = one QP, blockIdx.y = segment, stages k = b-1 .. a, with
+// lam = lam_in(s), m_in = m_in(s) from the scan and t = e = 0 on entry:
+//     (z, y) = (clip(v), v - clip(v));  gold = -rho (z - y)            (the CURRENT x-update's linear term)
+//     x  = m0_k + PHF_k m_in + CM_k lam                                 (x_{k+1})
+//     nu = lam - QM_k x - gold^x;   u = RB_k nu - RI_k gold^u;   lam = AT_k nu      (w block k = (u, x))
+//     wh = alpha w + (1 - alpha) z;  v+ = wh + y   -> v (in place);  z+, y+, RESID partials as above
+//     g  = -rho (z+ - y+)
+//     p = g^x + t;  h = BT_k p + g^u;  d0_k = SI_k h -> dbuf;  t = AT_k p - KT_k h;  e += OM_k d0_k
+// and on exit t -> tseg[s], e -> eseg[s]: exactly what xb_kernel leaves for the plain scan.
+// ---------------------------------------------------------------------------
+template <int NX, int NU, bool RESID, bool RELAX>
+__global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY void xbze_kernel(
+    const double* __restrict__ mvec, const double* __restrict__ min_, const double* __restrict__ lin,
+    const double* __restrict__ recBE, const int* __restrict__ seg_start_, double* __restrict__ v,
+    double* __restrict__ dbuf, double* __restrict__ tseg, double* __restrict__ eseg,
+    double* __restrict__ part, double alpha, double rho, int pitch, int nsplit, size_t split_stride) {
+  constexpr int NB = NX + NU;
+  constexpr RecBELayout LB = rec_be_layout(NX, NU);
+  constexpr int RB = LB.SIZE;
+  constexpr int PF = ADMM_ALT_PF_B;
+  constexpr int ALT_G = ADMM_ALT_G_B;
+  constexpr int CH = stage_chunk(RB, PF);
+  __shared__ __attribute__((aligned(16))) double rec[CH * RB];
+
+  const int col_raw = blockIdx.x * XB_THREADS + threadIdx.x;
+  const int col = col_raw < pitch ? col_raw : pitch - 1;
+  const unsigned lb_st = col_raw < pitch ? (unsigned)col * 8u : ROWVIEW_OOB;
+  const int s = blockIdx.y;
+  cint_p seg_start = as_const(seg_start_);
+  const int k0 = seg_start[s], k1 = seg_start[s + 1];
+  const size_t P = (size_t)pitch;
+  const unsigned lb = (unsigned)col * 8u;
+  const unsigned PB = (unsigned)pitch * 8u;
+  const RowView vv(v, (size_t)k0 * NB * P, (size_t)(k1 - k0) * NB * P * 8);
+  const RowView vd(dbuf, (size_t)k0 * NU * P, (size_t)(k1 - k0) * NU * P * 8);
+  const RowView vm(mvec, (size_t)k0 * NX * P, (size_t)(k1 - k0) * NX * P * 8);
+  double t[NX], e[NX], lam[NX], mi[NX];
+  {
+    const size_t o = (size_t)s * NX * P + col;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      mi[i] = scan_row(min_, o + i * P, nsplit, split_stride);
+      lam[i] = scan_row(lin, o + i * P, nsplit, split_stride);
+      t[i] = 0.0;
+      e[i] = 0.0;
+    }
+  }
+  double lm[PF][NX], l0[PF][NB];
+#pragma unroll
+  for (int j = 0; j < PF; ++j) {
+    const int kj = (k1 - 1 - j > k0) ? k1 - 1 - j : k0;
+    const unsigned m0 = (unsigned)(kj - k0) * NX * PB;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) lm[j][i] = vm.load(lb, m0 + i * PB);
+    const unsigned r0 = (unsigned)(kj - k0) * NB * PB;
+#pragma unroll
+    for (int r = 0; r < NB; ++r) l0[j][r] = vv.load(lb, r0 + r * PB);
+  }
+  double a_r = 0, a_s = 0, a_w = 0, a_z = 0, a_y = 0;
+  for (int kc = k1 - 1; kc >= k0; kc -= CH) {
+    const int klo = (kc - CH + 1 > k0) ? kc - CH + 1 : k0;
+    __syncthreads();
+    stage_records<XB_THREADS>(rec, recBE + (size_t)klo * RB, (kc - klo + 1) * RB, threadIdx.x);
+    __syncthreads();
+    for (int kb = kc; kb >= klo; kb -= PF) {
+#pragma unroll
+      for (int j = 0; j < PF; ++j) {
+        const int k = kb - j;
+        if (k < klo) break;
+        const double* rb = rec + (k - klo) * RB;
+        double c0[NB], xk[NX];
+#pragma unroll
+        for (int r = 0; r < NB; ++r) c0[r] = l0[j][r];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xk[i] = lm[j][i];
+        {  // refill this slot with stage k - PF (clamped: the re-read rows near the segment start
+           // are overwritten by this lane only later, in program order, and the values are unused)
+          const int kn = (k - PF > k0) ? k - PF : k0;
+          const unsigned m0 = (unsigned)(kn - k0) * NX * PB;
+#pragma unroll
+          for (int i = 0; i < NX; ++i) lm[j][i] = vm.load(lb, m0 + i * PB);
+          const unsigned r0 = (unsigned)(kn - k0) * NB * PB;
+#pragma unroll
+          for (int r = 0; r < NB; ++r) l0[j][r] = vv.load(lb, r0 + r * PB);
+        }
+        // ---- substitution: costate step of stage k ----
+        // (the old state z = clip(v), y = v - z is rebuilt twice -- here for the linear term of the
+        //  CURRENT x-update, below for the z-update -- rather than kept live across the mat-vecs:
+        //  registers are the scarce resource of this kernel)
+        double wv[NB];
+        {
+          double nu[NX], gou[NU], uu[NU];
+          {
+            double mLO[even_up(NB)], mHI[even_up(NB)];
+            lds_block(rb + LB.LO, mLO);
+            lds_block(rb + LB.HI, mHI);
+#pragma unroll
+            for (int r = 0; r < NB; ++r) {
+              const double zo = fmin(fmax(c0[r], mLO[r]), mHI[r]);
+              const double yo = c0[r] - zo;
+              if (r < NU) gou[r] = -rho * (zo - yo);
+              else nu[r - NU] = lam[r - NU] + rho * (zo - yo);    // lam - gold^x
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          lds_matvec_acc<NX, NX, false, ALT_G>(rb + LB.PHF, mi, xk);     // m_{k+1} = m0 + PHF m_in
+          lds_matvec_acc<NX, NX, false, ALT_G>(rb + LB.CM, lam, xk);     // x_{k+1} = m_{k+1} + C lam
+          __builtin_amdgcn_sched_barrier(0);
+          lds_matvec_acc<NX, NX, true, ALT_G>(rb + LB.QM, xk, nu);       // nu = lam - gold^x - Qr x
+#pragma unroll
+          for (int jj = 0; jj < NU; ++jj) uu[jj] = 0.0;
+          lds_matvec_acc<NU, NX, false, ALT_G>(rb + LB.RB, nu, uu);      // u = Rr^-1 B' nu
+          lds_matvec_acc<NU, NU, true, ALT_G>(rb + LB.RI, gou, uu);      //     - Rr^-1 gold^u
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < NX; ++i) lam[i] = 0.0;
+          lds_matvec_acc<NX, NX, false, ALT_G>(rb + LB.AT, nu, lam);     // lam = A' nu
+#pragma unroll
+          for (int jj = 0; jj < NU; ++jj) wv[jj] = uu[jj];
+#pragma unroll
+          for (int i = 0; i < NX; ++i) wv[NU + i] = xk[i];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("" ::: "memory");     // the box is re-read from LDS below, not carried in registers
+        // ---- z-update, dual ascent, residual partials ----
+        double g[NB];
+        const unsigned r0 = (unsigned)(k - k0) * NB * PB;
+#pragma unroll
+        for (int r3 = 0; r3 < NB; r3 += 3) {
+#pragma unroll
+          for (int r = r3; r < r3 + 3 && r < NB; ++r) {
+            const double lo = rb[LB.LO + r], hi = rb[LB.HI + r];
+            const double zo = fmin(fmax(c0[r], lo), hi);
+            const double yo = c0[r] - zo;
+            double wh = wv[r];
+            if (RELAX) wh = fma(alpha, wv[r], (1.0 - alpha) * zo);
+            const double vn = wh + yo;
+            vv.store(vn, lb_st, r0 + r * PB);
+            const double zn = fmin(fmax(vn, lo), hi);
+            const double yn = vn - zn;
+            g[r] = -rho * (zn - yn);
+            if (RESID) {
+              const double dr = wv[r] - zn, ds = zn - zo;
+              a_r = fma(dr, dr, a_r);
+              a_s = fma(ds, ds, a_s);
+              a_w = fma(wv[r], wv[r], a_w);
+              a_z = fma(zn, zn, a_z);
+              a_y = fma(yn, yn, a_y);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- backward elimination of stage k for the next x-update (as xb_kernel) ----
+        {
+          double p[NX], h[NU], d[NU];
+#pragma unroll
+          for (int i = 0; i < NX; ++i) p[i] = g[NU + i] + t[i];
+#pragma unroll
+          for (int jj = 0; jj < NU; ++jj) { h[jj] = g[jj]; d[jj] = 0.0; }
+          lds_matvec_acc<NU, NX, false, ALT_G>(rb + LB.BT, p, h);
+          lds_matvec_acc<NU, NU, false, ALT_G>(rb + LB.SI, h, d);
+          const unsigned d0 = (unsigned)(k - k0) * NU * PB;
+#pragma unroll
+          for (int jj = 0; jj < NU; ++jj) vd.store(d[jj], lb_st, d0 + jj * PB);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < NX; ++i) t[i] = 0.0;
+          lds_matvec_acc<NX, NX, false, ALT_G>(rb + LB.AT, p, t);
+          lds_matvec_acc<NX, NU, true, ALT_G>(rb + LB.KT, h, t);
+          lds_matvec_acc<NX, NU, false, ALT_G>(rb + LB.OM, d, e);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  if (col_raw < pitch) {
+    const size_t o = (size_t)s * NX * P + col;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      tseg[o + i * P] = t[i];
+      eseg[o + i * P] = e[i];
+    }
+    if (RESID) {
+      const size_t op = (size_t)s * 5 * P + col;
+      part[op + 0 * P] = a_r;
+      part[op + 1 * P] = a_s;
+      part[op + 2 * P] = a_w;
+      part[op + 3 * P] = a_z;
+      part[op + 4 * P] = a_y;
+    }
+  }
+}
+
+}  // namespace admm

@@ -264,9 +264,15 @@ class Solver:
         _check(self._lib, self._lib.admm_get(self._h, *[dptr(o) for o in outs]))
         return tuple(outs)
 
-    def profile(self, iters: int, residuals: bool = True, fused: bool = True):
+    def profile(self, iters: int, residuals: bool = True, fused: bool = True, alternating: bool = False):
+        """Per-kernel HIP-event timings (ms).  alternating: `iters` PAIRS of the alternating-direction
+        iteration (forward form, backward form) instead of the plain kernels."""
         ms = np.zeros(6)
-        _check(self._lib, self._lib.admm_profile(self._h, int(iters), int(bool(residuals)), int(bool(fused)), dptr(ms)))
+        mode = 2 if alternating else int(bool(fused))
+        _check(self._lib, self._lib.admm_profile(self._h, int(iters), int(bool(residuals)), mode, dptr(ms)))
+        if alternating:
+            return {"xscan_ms": ms[0], "xfze_ms": ms[1], "finalize_xscan_ms": ms[2], "xbze_ms": ms[3],
+                    "finalize_ms": ms[4], "pair_ms": ms[5]}
         if fused:
             return {"xb_ms": ms[0], "xscan_ms": ms[1], "xfz_ms": ms[2], "finalize_ms": ms[4], "iter_ms": ms[5]}
         return {"xb_ms": ms[0], "xscan_ms": ms[1], "xf_ms": ms[2], "zdual_ms": ms[3], "finalize_ms": ms[4],

@@ -100,6 +100,11 @@ typedef struct admm_options {
 #define ADMM_FLAG_UNFUSED 2    /* iterate with separate forward-rollout and z/dual kernels (w stored
                                   every iteration) instead of the fused xfz kernel */
 
+#define ADMM_FLAG_NO_ALTERNATE 8 /* always eliminate backward / substitute forward (xb + xfz kernels); by
+                                  default, where compiled (n + m <= 9, no q, no thrust-magnitude bound),
+                                  consecutive iterations alternate the elimination direction so that each
+                                  substitution sweep is fused with the next elimination sweep */
+
 typedef struct admm_info {
   int32_t iters_run;      /* batch iterations executed by the last admm_solve */
   int32_t n_converged;    /* QPs that met the stopping rule */
