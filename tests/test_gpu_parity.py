@@ -112,12 +112,13 @@ def test_zdual_kernel(gpu, alpha, resid):
             assert np.abs(got - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
 
 
-@pytest.mark.parametrize("flags", [0, 2], ids=["fused", "unfused"])
+@pytest.mark.parametrize("flags", [0, 8, 2], ids=["default", "fused_plain", "unfused"])
 @pytest.mark.parametrize("idx", [0, 1, 3, 5, 7, 9, 15, 16, 17, 18, 20])
 def test_iterate_parity(gpu, idx, flags):
-    """T4: iterates of the full loop vs the C oracle after 1, 2, 10, 40 iterations,
-    on the default fused path (xb, xscan, xfz) and on the ADMM_FLAG_UNFUSED path
-    (xb, xscan, xf, zdual).  w is re-materialised by admm_get on the fused path."""
+    """T4: iterates of the full loop vs the C oracle after 1, 2, 10, 40 iterations, on the
+    default path (the alternating-direction kernels where compiled, tests/test_gpu_alternating.py,
+    else xb, xscan, xfz), on the plain fused path (ADMM_FLAG_NO_ALTERNATE) and on the
+    ADMM_FLAG_UNFUSED path (xb, xscan, xf, zdual).  w is re-materialised by admm_get on the fused paths."""
     make, rho, segs = CASES[idx]
     p = make()
     with pkg.Solver(p, pkg.Options(rho=rho, segments=segs, flags=flags)) as s:
