@@ -10,19 +10,24 @@ before the timed region.  For N > 1 GPUs the global batch is 4096 * N QPs,
 sharded contiguously (weak scaling, no data-path collective: QPs are
 independent).
 
-A "step" = one batch-iteration over the rank's shard on the default (fused)
-path: x-update backward sweep (xb), segment scan (xscan), then the forward
-rollout fused with z-update / dual ascent / residual partials (xfz), then the
-residual finalise kernel -- i.e. every iteration evaluates the residuals on the
-device (check_interval = 1), which is the most expensive honest form of the
-iteration.  `value` = QP-iterations/s summed over all ranks.
+A "step" = one batch-iteration over the rank's shard on the default path, the
+alternating-direction iteration: segment scan (xscan), then ONE
+fused kernel -- the x-update's substitution sweep, z-update / dual ascent /
+residual partials, and the next x-update's elimination sweep (xfze forward on
+even iterations, xbze backward on odd ones) -- then the residual finalise
+kernel, i.e. every iteration evaluates the residuals on the device
+(check_interval = 1), the most expensive honest form of the iteration.
+`value` = QP-iterations/s summed over all ranks.  (`plain_path` re-times the
+same steps with ADMM_FLAG_NO_ALTERNATE: xb + xscan + xfz + finalise.)
 
 Extra objects on the JSON line:
-  roofline     -- the dominant kernel, xfz<RESID, VIN>: 8 m/(n+m) + 16 = 18.67 B per
-                  stacked element (d and v read; v+ written; fp64 -- the state is
-                  kept in v-form) x L x pitch per launch, divided
-                  by its average launch duration measured with HIP events on the
-                  library's own stream (admm_profile).
+  roofline     -- the dominant kernels, the pair xfze<RESID> / xbze<RESID>: each
+                  moves 8 m/(n+m) + 16 + 8 n/(n+m) = 24 B per stacked element
+                  (d, v read and v+, m written, resp. m, v read and v+, d written;
+                  fp64, state in v-form, DESIGN.md §4.5) x L x pitch per launch;
+                  achieved = the pair's bytes / the pair's average launch
+                  durations, measured with HIP events on the library's own stream
+                  (admm_profile).  `per_kernel` holds each kernel's own figures.
   roofline_zdual_standalone -- the standalone fused z/dual/residual kernel of
                   the ADMM_FLAG_UNFUSED path (40 B per element),
                   measured the same way in the same run.
@@ -169,7 +174,12 @@ def main():
 
     # per-kernel timing on the library's stream (HIP events)
     npf = min(a.steps, 100)
-    prof = solver.profile(npf, residuals=True, fused=True)           # the timed path
+    try:
+        prof_alt = solver.profile(max(1, npf // 2), residuals=True, alternating=True)     # the timed path
+        prof_alt_plain = solver.profile(max(1, npf // 2), residuals=False, alternating=True)
+    except pkg.AdmmError:                          # no alternating kernels for this shape: the plain kernels are timed
+        prof_alt = prof_alt_plain = None
+    prof = solver.profile(npf, residuals=True, fused=True)           # plain fused path (the timed path without alternation)
     prof_plain = solver.profile(npf, residuals=False, fused=True)
     prof_unf = solver.profile(npf, residuals=True, fused=False)      # standalone z/dual kernel
     L = full.L
@@ -177,17 +187,45 @@ def main():
     n_, m_ = full.n, full.m
     b_xfz = 8.0 * m_ / (n_ + m_) + 16.0          # d read + v read + v+ written
     xfz_ms = prof["xfz_ms"]
-    achieved = b_xfz * elems / (xfz_ms * 1e-3) / 1e9
-    roofline = {"kernel": f"xfz_kernel<{n_},{m_},RESID=true,RELAX=false,VIN=true> (forward rollout fused with z-update + dual "
-                          "ascent + residual partials, state in v-form)",
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "bytes_per_launch": b_xfz * elems, "bytes_per_element": b_xfz, "avg_launch_ms": xfz_ms}
-    if (a.batch, a.horizon, a.workload) == (4096, 1000, "cw_rendezvous"):   # the stored PMC run is of this workload only
-        tr, src = pmc_traffic("xfz_kernel<6, 3, true, false, true>")
-        roofline["traffic"] = tr
-        if src:
-            roofline["traffic_source"] = src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE x2)"
+    pmc_ok = (a.batch, a.horizon, a.workload) == (4096, 1000, "cw_rendezvous")   # the stored PMC runs are of this workload only
+    pmc_note = " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE x2)"
+
+    def kernel_roofline(name, desc, bytes_per_elem, ms, pmc_name):
+        ach = bytes_per_elem * elems / (ms * 1e-3) / 1e9
+        r = {"kernel": f"{name} ({desc})", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "frac": ach / HBM_PEAK_GBS, "traffic": None, "bytes_per_launch": bytes_per_elem * elems,
+             "bytes_per_element": bytes_per_elem, "avg_launch_ms": ms}
+        if pmc_ok:
+            tr, src = pmc_traffic(pmc_name)
+            r["traffic"] = tr
+            if src:
+                r["traffic_source"] = src + pmc_note
+        return r
+
+    roofline_xfz = kernel_roofline(f"xfz_kernel<{n_},{m_},RESID=true,RELAX=false,VIN=true>",
+                                   "plain path: forward rollout fused with z-update + dual ascent + residual partials, "
+                                   "state in v-form", b_xfz, xfz_ms, "xfz_kernel<6, 3, true, false, true")
+    if prof_alt is not None:
+        b_alt = 16.0 + 8.0 * m_ / (n_ + m_) + 8.0 * n_ / (n_ + m_)     # v, v+ and the d / m rows
+        rf = kernel_roofline(f"xfze_kernel<{n_},{m_},RESID=true,RELAX=false>",
+                             "forward rollout + z-update + dual ascent + residual partials + forward elimination of v+",
+                             b_alt, prof_alt["xfze_ms"], "xfze_kernel<6, 3, true, false>")
+        rb = kernel_roofline(f"xbze_kernel<{n_},{m_},RESID=true,RELAX=false>",
+                             "backward costate substitution + z-update + dual ascent + residual partials + backward "
+                             "elimination of v+", b_alt, prof_alt["xbze_ms"], "xbze_kernel<6, 3, true, false>")
+        pair_ms = prof_alt["xfze_ms"] + prof_alt["xbze_ms"]
+        ach = 2 * b_alt * elems / (pair_ms * 1e-3) / 1e9
+        roofline = {"kernel": f"xfze_kernel / xbze_kernel <{n_},{m_},RESID=true,RELAX=false> (the alternating pair: one of them "
+                              "per iteration; substitution sweep + z-update + dual ascent + residual partials + next "
+                              "elimination sweep, state in v-form)",
+                    "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                    "traffic": (None if rf["traffic"] is None or rb["traffic"] is None else 0.5 * (rf["traffic"] + rb["traffic"])),
+                    "bytes_per_launch": b_alt * elems, "bytes_per_element": b_alt, "avg_launch_ms": 0.5 * pair_ms,
+                    "per_kernel": {"xfze": rf, "xbze": rb}}
+        if "traffic_source" in rf:
+            roofline["traffic_source"] = rf["traffic_source"] + "; mean of the two kernels"
+    else:
+        roofline = roofline_xfz
     zs_ms = prof_unf["zdual_ms"]
     zs = BYTES_PER_ELEM_ZDUAL * elems / (zs_ms * 1e-3) / 1e9
     standalone = {"kernel": "zdual_kernel<RESID=true> (standalone fused z-update + dual + residual, ADMM_FLAG_UNFUSED path)",
@@ -196,7 +234,22 @@ def main():
                   "avg_launch_ms": zs_ms}
     b_xb = 8.0 + 8.0 * m_ / (n_ + m_)             # v read + d written
     xb_gbs = b_xb * elems / (prof["xb_ms"] * 1e-3) / 1e9
-    b_iter = b_xb + b_xfz                          # algorithmic HBM bytes per element per fused iteration
+    # algorithmic HBM bytes per element per iteration of the timed path
+    b_iter = (16.0 + 8.0 * m_ / (n_ + m_) + 8.0 * n_ / (n_ + m_)) if prof_alt is not None else b_xb + b_xfz
+
+    # the same steps on the plain fused path (xb + xscan + xfz + finalise), for the A/B in DESIGN.md §4.8
+    plain_path = None
+    if prof_alt is not None:
+        from admm_library_amd import _abi
+        with pkg.Solver(full, pkg.Options(rho=0.05, check_interval=1, segments=a.segments, zrows=a.zrows, device=dev_index,
+                                          flags=_abi.FLAG_NO_ALTERNATE)) as sp:
+            sp.run(a.warmup, residual_every=1)
+            barrier()
+            t0 = time.perf_counter()
+            sp.run(a.steps, residual_every=1, sync=True)
+            dtp = time.perf_counter() - t0
+        plain_path = {"batch_iterations_per_s": a.steps / dtp, "ms_per_step": dtp / a.steps * 1e3,
+                      "iteration_bytes_per_element": b_xb + b_xfz, "roofline_xfz": roofline_xfz}
 
     # mixed mode a solver would normally run: residuals every 10th iteration
     solver.run(10, residual_every=10)
@@ -261,7 +314,10 @@ def main():
                        **geo},
             "roofline": roofline,
             "roofline_zdual_standalone": standalone,
-            "kernels_ms": {"fused_resid": {k: round(v, 5) for k, v in prof.items()},
+            "plain_path": plain_path,
+            "kernels_ms": {"alternating_resid": None if prof_alt is None else {k: round(v, 5) for k, v in prof_alt.items()},
+                           "alternating_plain": None if prof_alt_plain is None else {k: round(v, 5) for k, v in prof_alt_plain.items()},
+                           "fused_resid": {k: round(v, 5) for k, v in prof.items()},
                            "fused_plain": {k: round(v, 5) for k, v in prof_plain.items()},
                            "unfused_resid": {k: round(v, 5) for k, v in prof_unf.items()},
                            "xb_GBs": xb_gbs, "xb_bytes_per_element": b_xb,
