@@ -24,6 +24,7 @@ FLAG_NO_GRAPH = 1
 FLAG_UNFUSED = 2
 FLAG_SCAN_CHAIN = 4
 FLAG_NO_ALTERNATE = 8
+FLAG_GRAPH = 16
 
 c_double_p = C.POINTER(C.c_double)
 c_int32_p = C.POINTER(C.c_int32)

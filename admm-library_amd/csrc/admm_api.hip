@@ -76,14 +76,19 @@ struct admm_handle {
   int* h_nconv = nullptr;       // pinned
   int iters_run = 0;
   bool resid_valid = false;
+  // A residual-evaluating alternating iteration leaves its finalise to the NEXT scan launch (finalise
+  // role of xscan_mfma_kernel); flush_finalize() runs it standalone when no scan follows.
+  bool fin_pending = false;
   bool w_stale = false;         // fused iterations do not store w; admm_get re-materialises it
   // State form: the fused path keeps v = z + y only; z, y are rebuilt on demand.
   bool v_valid = false;         // h->v holds the current state
   bool zy_valid = true;         // h->z, h->y hold the current state
   // captured iterations, replayed by admm_run / admm_solve:
-  //   [2 t + r]: iteration form t (IT_PLAIN .. IT_BWD below), r = 1 with residuals + finalise (it = 0)
-  hipGraph_t graph[8] = {};
-  hipGraphExec_t graph_exec[8] = {};
+  //   [r]: plain iteration, r = 1 with residuals + finalise (it = 0);
+  //   [4 t + 2 r + p] (t = IT_FWD_START .. IT_BWD): alternating forms, p = 1 if the scan launch also
+  //   finalises the previous iteration's residuals
+  hipGraph_t graph[16] = {};
+  hipGraphExec_t graph_exec[16] = {};
 };
 
 namespace {
@@ -135,14 +140,24 @@ int launch_xb(admm_handle* h, bool vform) { return launch_x(h, admm::XKernel::XB
 
 static_assert(admm::SCAN_KALIGN == admm::SCAN_U, "host range alignment must match the kernel's batch");
 
-// forward_form: the scan of the forward-elimination form (matrix WB)
-int launch_xscan_mfma(admm_handle* h, bool forward_form = false) {
+admm::FinArgs fin_args(const admm_handle* h, int it, int nchunks) {
+  admm::FinArgs fa{};
+  fa.part = h->part; fa.resid = h->resid; fa.status = h->status; fa.iters = h->iters; fa.nconv = h->nconv;
+  fa.rho = h->opt.rho; fa.eps_abs = h->opt.eps_abs; fa.eps_rel = h->opt.eps_rel; fa.sqrtL = std::sqrt((double)h->L);
+  fa.nchunks = nchunks; fa.batch = h->batch; fa.it = it;
+  return fa;
+}
+
+// forward_form: the scan of the forward-elimination form (matrix WB).
+// with_finalize: one extra row of workgroups finalises the previous iteration's residual partials
+// (S chunks, it = 0: no stopping rule -- checked iterations of admm_solve finalise standalone).
+int launch_xscan_mfma(admm_handle* h, bool forward_form = false, bool with_finalize = false) {
   const int mtiles = h->fac.scanM / 16, ngroups = mtiles / admm::SCAN_MT;
-  dim3 grid(h->pitch / 64, ngroups, h->scan_split), block(256);
+  dim3 grid(h->pitch / 64, ngroups + (with_finalize ? 1 : 0), h->scan_split), block(256);
   hipLaunchKernelGGL((admm::xscan_mfma_kernel<admm::SCAN_MT>), grid, block, 0, h->stream,
                      forward_form ? h->scanWpB : h->scanWp, h->scan_in, h->scan_out,
                      forward_form ? h->scan_rangeB : h->scan_range, mtiles, ngroups, h->pitch, h->scan_split,
-                     (size_t)h->fac.scanM * h->pitch);
+                     (size_t)h->fac.scanM * h->pitch, fin_args(h, 0, h->S));
   return ADMM_OK;
 }
 
@@ -195,10 +210,15 @@ int launch_z(admm_handle* h, bool resid) {
 // nchunks = zchunks after the standalone z kernel, S after the fused xfz kernel
 int launch_finalize(admm_handle* h, int it, int nchunks) {
   dim3 grid(h->pitch / admm::FIN_COLS), block(admm::FIN_COLS * admm::FIN_GROUPS);
-  hipLaunchKernelGGL(admm::resid_finalize_kernel, grid, block, 0, h->stream, h->part, h->resid,
-                     h->status, h->iters, h->nconv, h->opt.rho, h->opt.eps_abs, h->opt.eps_rel,
-                     std::sqrt((double)h->L), nchunks, h->batch, h->pitch, it);
+  hipLaunchKernelGGL(admm::resid_finalize_kernel, grid, block, 0, h->stream, fin_args(h, it, nchunks), h->pitch);
   return ADMM_OK;
+}
+
+// the deferred finalise of the last alternating iteration, when no scan launch will carry it
+int flush_finalize(admm_handle* h, int it = 0) {
+  if (!h->fin_pending) return ADMM_OK;
+  h->fin_pending = false;
+  return launch_finalize(h, it, h->S);
 }
 
 bool fused(const admm_handle* h) { return !(h->opt.flags & ADMM_FLAG_UNFUSED); }
@@ -222,10 +242,11 @@ IterForm next_form(const admm_handle* h, int remaining) {
   return remaining >= 2 ? IT_FWD_START : IT_PLAIN;
 }
 
-int enqueue_form(admm_handle* h, IterForm f, bool resid) {
+// fin_prev: the previous iteration evaluated residuals and left their finalise to this scan launch
+int enqueue_form(admm_handle* h, IterForm f, bool resid, bool fin_prev) {
   int rc;
   if (f == IT_FWD_START && (rc = launch_xb(h, true))) return rc;
-  if ((rc = launch_xscan_mfma(h, f == IT_BWD))) return rc;
+  if ((rc = launch_xscan_mfma(h, f == IT_BWD, fin_prev))) return rc;
   return launch_x(h, f == IT_BWD ? admm::XKernel::XBZE : admm::XKernel::XFZE, false, resid);
 }
 
@@ -352,7 +373,7 @@ int validate_problem(const admm_problem* p) {
 }
 
 void destroy_graph(admm_handle* h) {
-  for (int v = 0; v < 8; ++v) {
+  for (int v = 0; v < 16; ++v) {
     if (h->graph_exec[v]) { (void)hipGraphExecDestroy(h->graph_exec[v]); h->graph_exec[v] = nullptr; }
     if (h->graph[v]) { (void)hipGraphDestroy(h->graph[v]); h->graph[v] = nullptr; }
   }
@@ -384,12 +405,13 @@ int dalloc(T** p, size_t count) {
 
 int capture_iterations(admm_handle* h) {
   destroy_graph(h);
-  for (int v = 0; v < (h->alt ? 8 : 2); ++v) {
+  for (int v = 0; v < (h->alt ? 16 : 2); ++v) {
+    if (v == 2 || v == 3) continue;                              // (unused slots: form 0 is the plain iteration)
     HIP_TRY(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-    const bool res = (v & 1) != 0;
+    const bool res = v < 2 ? (v & 1) != 0 : (v & 2) != 0;
     int rc = v < 2 ? enqueue_iteration(h, res, /*use_v=*/true)   // steady state of the fused path
-                   : enqueue_form(h, (IterForm)(v >> 1), res);
-    if (!rc && res) rc = launch_finalize(h, 0, chunks_of_iteration(h));
+                   : enqueue_form(h, (IterForm)(v >> 2), res, (v & 1) != 0);
+    if (!rc && res && v < 2) rc = launch_finalize(h, 0, chunks_of_iteration(h));
     hipGraph_t g = nullptr;
     hipError_t e = hipStreamEndCapture(h->stream, &g);
     if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
@@ -846,17 +868,19 @@ static int enqueue_one(admm_handle* h, bool resid, bool use_graph, int remaining
   if (!fused(h) && !h->zy_valid && (rc = ensure_zy(h))) return rc;
   const IterForm form = next_form(h, remaining);
   if (form != IT_PLAIN) {
-    if (use_graph && it_number == 0) {
-      HIP_TRY(hipGraphLaunch(h->graph_exec[2 * (int)form + (resid ? 1 : 0)], h->stream));
-    } else {
-      rc = enqueue_form(h, form, resid);
-      if (!rc && resid) rc = launch_finalize(h, it_number, chunks_of_iteration(h));
-      if (rc) return rc;
+    const bool fin_prev = h->fin_pending;
+    if (use_graph) {
+      HIP_TRY(hipGraphLaunch(h->graph_exec[4 * (int)form + (resid ? 2 : 0) + (fin_prev ? 1 : 0)], h->stream));
+    } else if ((rc = enqueue_form(h, form, resid, fin_prev))) {
+      return rc;
     }
     after_form(h, form);
+    h->fin_pending = resid;                 // carried by the next scan launch, or flushed by the caller
     if (resid) h->resid_valid = true;
+    if (it_number > 0) return flush_finalize(h, it_number);
     return ADMM_OK;
   }
+  if ((rc = flush_finalize(h))) return rc;
   if (it_number > 0) {
     if ((rc = enqueue_iteration(h, true, fused(h) && h->v_valid))) return rc;
     if ((rc = launch_finalize(h, it_number, chunks_of_iteration(h)))) return rc;
@@ -876,7 +900,7 @@ int admm_run(admm_handle* h, int32_t iters, int32_t residual_every) {
   if (!h) return fail(ADMM_ERR_INVALID, "NULL handle");
   if (iters < 0 || residual_every < 0) return fail(ADMM_ERR_INVALID, "iters / residual_every must be >= 0");
   HIP_TRY(hipSetDevice(h->device));
-  const bool use_graph = !(h->opt.flags & ADMM_FLAG_NO_GRAPH);
+  const bool use_graph = (h->opt.flags & ADMM_FLAG_GRAPH) != 0;
   if (use_graph && !h->graph_exec[0]) {
     int rc = capture_iterations(h);
     if (rc) return rc;
@@ -886,6 +910,8 @@ int admm_run(admm_handle* h, int32_t iters, int32_t residual_every) {
     int rc = enqueue_one(h, resid, use_graph, iters - it + 1);
     if (rc) return rc;
   }
+  int rcf = flush_finalize(h);
+  if (rcf) return rcf;
   HIP_TRY(hipGetLastError());
   return ADMM_OK;
 }
@@ -912,7 +938,7 @@ int admm_solve_begin(admm_handle* h, const double* z0, const double* y0) {
     HIP_TRY(hipMemcpyAsync(h->iters, init.data(), sizeof(int) * P, hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
   }
-  const bool use_graph = !(h->opt.flags & ADMM_FLAG_NO_GRAPH);
+  const bool use_graph = (h->opt.flags & ADMM_FLAG_GRAPH) != 0;
   if (use_graph && !h->graph_exec[0] && (rc = capture_iterations(h))) return rc;
   h->rho_updates = 0;
   h->solve_it = 0;
@@ -924,7 +950,7 @@ int admm_solve_step(admm_handle* h, int32_t* iters_done, int32_t* n_converged, d
   if (!h) return fail(ADMM_ERR_INVALID, "NULL handle");
   if (h->solve_it >= h->opt.max_iter) return fail(ADMM_ERR_INVALID, "admm_solve_step: max_iter already reached");
   HIP_TRY(hipSetDevice(h->device));
-  const bool use_graph = !(h->opt.flags & ADMM_FLAG_NO_GRAPH);
+  const bool use_graph = (h->opt.flags & ADMM_FLAG_GRAPH) != 0;
   if (use_graph && !h->graph_exec[0]) { int rc0 = capture_iterations(h); if (rc0) return rc0; }
   const int ci = h->opt.check_interval;
   const size_t P = h->pitch;
@@ -1072,7 +1098,8 @@ int admm_profile(admm_handle* h, int32_t iters, int32_t residuals, int32_t fused
   h->alt_state = admm_handle::ALT_NONE;       // the plain kernels are profiled; they overwrite the scan operands
   if (fused_path == 2) {
     // `iters` PAIRS of alternating iterations (forward form, backward form); ms[] = scan, xfze,
-    // (finalise +) scan, xbze, finalise, whole pair.  2 iters + 1 (+1) iterations are applied.
+    // scan, xbze, 0, whole pair (with residuals each scan launch also finalises the iteration before
+    // it).  2 iters + 1 (+1) iterations are applied.
     if (!h->v_valid) {
       rc = enqueue_iteration(h, false, false);
       if (!rc) after_iterations(h, 1);
@@ -1081,19 +1108,17 @@ int admm_profile(admm_handle* h, int32_t iters, int32_t residuals, int32_t fused
     for (int it = 0; it < iters && !rc; ++it) {
       hipEvent_t* e = &ev[(size_t)it * NE];
       HIP_TRY(hipEventRecord(e[0], h->stream));
-      rc = launch_xscan_mfma(h, false);
+      rc = launch_xscan_mfma(h, false, res && it > 0);
       HIP_TRY(hipEventRecord(e[1], h->stream));
       if (!rc) rc = launch_x(h, admm::XKernel::XFZE, false, res);
       HIP_TRY(hipEventRecord(e[2], h->stream));
-      if (!rc && res) rc = launch_finalize(h, 0, h->S);
-      if (!rc) rc = launch_xscan_mfma(h, true);
+      if (!rc) rc = launch_xscan_mfma(h, true, res);
       HIP_TRY(hipEventRecord(e[3], h->stream));
       if (!rc) rc = launch_x(h, admm::XKernel::XBZE, false, res);
       HIP_TRY(hipEventRecord(e[4], h->stream));
-      if (!rc && res) rc = launch_finalize(h, 0, h->S);
       HIP_TRY(hipEventRecord(e[5], h->stream));
     }
-    if (!rc) rc = enqueue_form(h, IT_FWD, res);           // never stop after the backward form
+    if (!rc) rc = enqueue_form(h, IT_FWD, res, res);      // never stop after the backward form
     if (!rc && res) rc = launch_finalize(h, 0, h->S);
     if (!rc) after_form(h, IT_FWD);
   }

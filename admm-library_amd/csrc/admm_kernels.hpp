@@ -500,6 +500,76 @@ __global__ __launch_bounds__(64) void xscan_kernel(
 }
 
 // ---------------------------------------------------------------------------
+// Residual finalise + stopping rule (device body shared by resid_finalize_kernel and by the
+// finalise role of xscan_mfma_kernel).  A workgroup = 64 QPs x GROUPS chunk groups: each lane sums
+// its group's chunk partials, the groups are combined through LDS in a fixed order (bitwise
+// reproducible), then one wave takes square roots, applies
+//   r <= sqrt(L) eps_abs + eps_rel max(|w|, |z|),  s <= sqrt(L) eps_abs + eps_rel rho |y|
+// records the first iteration at which the QP met it, and counts converged QPs of the real batch
+// (wave-shuffle reduction, one atomic per wave).
+// ---------------------------------------------------------------------------
+constexpr int FIN_COLS = 64;     // columns (QPs) per finalise workgroup: one wave wide
+constexpr int FIN_GROUPS = 16;   // chunk groups per workgroup of resid_finalize_kernel (one wave each)
+
+struct FinArgs {
+  const double* part;
+  double* resid;
+  int *status, *iters, *nconv;
+  double rho, eps_abs, eps_rel, sqrtL;
+  int nchunks, batch, it;
+};
+
+template <int GROUPS>
+__device__ __forceinline__ void finalize_body(double (*red)[5][FIN_COLS], const FinArgs& fa, int block, int pitch) {
+  const int lane = threadIdx.x & (FIN_COLS - 1), g = threadIdx.x / FIN_COLS;
+  const int col = block * FIN_COLS + lane;      // pitch is a multiple of 64
+  const size_t P = (size_t)pitch;
+  double a[5] = {0, 0, 0, 0, 0};
+  for (int c = g; c < fa.nchunks; c += GROUPS) {
+    const size_t o = (size_t)c * 5 * P + col;
+#pragma unroll
+    for (int v = 0; v < 5; ++v) a[v] += fa.part[o + v * P];
+  }
+#pragma unroll
+  for (int v = 0; v < 5; ++v) red[g][v][lane] = a[v];
+  __syncthreads();
+  if (g != 0) return;
+  // fixed combination order (group 0, 1, ...): bitwise reproducible run to run
+#pragma unroll
+  for (int v = 0; v < 5; ++v) {
+    double t = red[0][v][lane];
+    for (int gg = 1; gg < GROUPS; ++gg) t += red[gg][v][lane];
+    a[v] = t;
+  }
+  const double r = sqrt(a[0]), s = fa.rho * sqrt(a[1]);
+  const double nw = sqrt(a[2]), nz = sqrt(a[3]), ny = fa.rho * sqrt(a[4]);
+  fa.resid[0 * P + col] = r;
+  fa.resid[1 * P + col] = s;
+  fa.resid[2 * P + col] = nw;
+  fa.resid[3 * P + col] = nz;
+  fa.resid[4 * P + col] = ny;
+  if (fa.it > 0) {
+    int ok_now = 0;
+    if (col < fa.batch) {
+      const double e_pri = fa.sqrtL * fa.eps_abs + fa.eps_rel * fmax(nw, nz);
+      const double e_dua = fa.sqrtL * fa.eps_abs + fa.eps_rel * ny;
+      int st = fa.status[col];
+      if (!st && r <= e_pri && s <= e_dua) {
+        st = 1;
+        fa.status[col] = 1;
+        fa.iters[col] = fa.it;
+      }
+      ok_now = st;
+    }
+    // wave64 shuffle reduction of the converged count, then one atomic per wave
+    int v = ok_now;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if (lane == 0 && v) atomicAdd(fa.nconv, v);
+  }
+}
+
+// ---------------------------------------------------------------------------
 // Segment scan as a dense fp64 GEMM on the matrix cores (the default scan).
 // Both chains of xscan_kernel are linear with batch-shared matrices, so their
 // composition is one constant matrix W (built on the host, admm_factor.cpp):
@@ -525,16 +595,25 @@ typedef double mfma_d4 __attribute__((ext_vector_type(4)));
 #endif
 constexpr int SCAN_U = ADMM_SCAN_U;   // k-steps per batch; the host pads K and the ranges to multiples of it
 
+// Finalise role: launched with gridDim.y = ngroups + 1, the extra row of workgroups (64 QPs each,
+// 4 chunk groups) finalises the residual partials of the iteration that has just finished (fa) while
+// the others run the scan -- the two are independent and both too small to fill the chip, so the
+// 6 us resid_finalize_kernel launch disappears from every checked iteration but the last of a call.
 template <int MT>
 __global__ __launch_bounds__(256) void xscan_mfma_kernel(
     const double* __restrict__ Wp, const double* __restrict__ in, double* __restrict__ out,
-    const int* __restrict__ krange_, int mtiles, int ngroups, int pitch, int nsplit, size_t split_stride) {
+    const int* __restrict__ krange_, int mtiles, int ngroups, int pitch, int nsplit, size_t split_stride, FinArgs fa) {
   // Workgroup = 4 waves = 4 adjacent N-tiles (64 columns) of ONE M-group, so the A
   // fragments (the same for every N-tile) are fetched from L2 once per workgroup and
   // shared through a double-buffered LDS slab; each wave loads its own B fragments.
   constexpr int U = SCAN_U;
   constexpr int SLAB = U * MT * 64;                  // doubles of A per batch (16 KiB at MT = 4)
   __shared__ __attribute__((aligned(16))) double abuf[2][SLAB];
+  static_assert(2 * SLAB >= 4 * 5 * FIN_COLS, "finalise role reuses the A slab");
+  if ((int)blockIdx.y >= ngroups) {                  // finalise role (workgroup-uniform)
+    if (blockIdx.z == 0) finalize_body<4>(reinterpret_cast<double(*)[5][FIN_COLS]>(&abuf[0][0]), fa, blockIdx.x, pitch);
+    return;
+  }
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1221,68 +1300,10 @@ static __global__ __launch_bounds__(Z_THREADS) void v_to_zy_soc_kernel(
   }
 }
 
-// ---------------------------------------------------------------------------
-// Residual finalise + stopping rule.  A workgroup = 64 QPs x 16 chunk groups:
-// each lane sums its group's chunk partials, the groups are combined through
-// LDS in a fixed order (bitwise reproducible), then one wave takes square roots, applies
-//   r <= sqrt(L) eps_abs + eps_rel max(|w|, |z|),  s <= sqrt(L) eps_abs + eps_rel rho |y|
-// records the first iteration at which the QP met it, and counts converged QPs
-// of the real batch (wave-shuffle reduction, one atomic per wave).
-// ---------------------------------------------------------------------------
-constexpr int FIN_COLS = 64;     // columns (QPs) per finalise workgroup: one wave wide
-constexpr int FIN_GROUPS = 16;   // chunk groups per workgroup (one wave each)
-
-static __global__ __launch_bounds__(FIN_COLS * FIN_GROUPS) void resid_finalize_kernel(
-    const double* __restrict__ part, double* __restrict__ resid, int* __restrict__ status,
-    int* __restrict__ iters, int* __restrict__ nconv, double rho, double eps_abs, double eps_rel,
-    double sqrtL, int nchunks, int batch, int pitch, int it) {
+// Standalone residual finalise (see finalize_body above).
+static __global__ __launch_bounds__(FIN_COLS * FIN_GROUPS) void resid_finalize_kernel(FinArgs fa, int pitch) {
   __shared__ double red[FIN_GROUPS][5][FIN_COLS];
-  const int lane = threadIdx.x & (FIN_COLS - 1), g = threadIdx.x / FIN_COLS;
-  const int col = blockIdx.x * FIN_COLS + lane;      // pitch is a multiple of 64
-  const size_t P = (size_t)pitch;
-  double a[5] = {0, 0, 0, 0, 0};
-  for (int c = g; c < nchunks; c += FIN_GROUPS) {
-    const size_t o = (size_t)c * 5 * P + col;
-#pragma unroll
-    for (int v = 0; v < 5; ++v) a[v] += part[o + v * P];
-  }
-#pragma unroll
-  for (int v = 0; v < 5; ++v) red[g][v][lane] = a[v];
-  __syncthreads();
-  if (g != 0) return;
-  // fixed combination order (group 0, 1, ...): bitwise reproducible run to run
-#pragma unroll
-  for (int v = 0; v < 5; ++v) {
-    double t = red[0][v][lane];
-    for (int gg = 1; gg < FIN_GROUPS; ++gg) t += red[gg][v][lane];
-    a[v] = t;
-  }
-  const double r = sqrt(a[0]), s = rho * sqrt(a[1]);
-  const double nw = sqrt(a[2]), nz = sqrt(a[3]), ny = rho * sqrt(a[4]);
-  resid[0 * P + col] = r;
-  resid[1 * P + col] = s;
-  resid[2 * P + col] = nw;
-  resid[3 * P + col] = nz;
-  resid[4 * P + col] = ny;
-  if (it > 0) {
-    int ok_now = 0;
-    if (col < batch) {
-      const double e_pri = sqrtL * eps_abs + eps_rel * fmax(nw, nz);
-      const double e_dua = sqrtL * eps_abs + eps_rel * ny;
-      int st = status[col];
-      if (!st && r <= e_pri && s <= e_dua) {
-        st = 1;
-        status[col] = 1;
-        iters[col] = it;
-      }
-      ok_now = st;
-    }
-    // wave64 shuffle reduction of the converged count, then one atomic per wave
-    int v = ok_now;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    if (lane == 0 && v) atomicAdd(nconv, v);
-  }
+  finalize_body<FIN_GROUPS>(red, fa, blockIdx.x, pitch);
 }
 
 // ---------------------------------------------------------------------------

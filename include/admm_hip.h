@@ -94,7 +94,11 @@ typedef struct admm_options {
 } admm_options;
 
 #define ADMM_FLAG_NONE 0
-#define ADMM_FLAG_NO_GRAPH 1   /* launch kernels directly instead of replaying a hipGraph */
+#define ADMM_FLAG_NO_GRAPH 1   /* accepted, no effect: direct launches are the default (see ADMM_FLAG_GRAPH) */
+#define ADMM_FLAG_GRAPH 16     /* replay captured hipGraphs (one per iteration form) instead of launching
+                                  the 2-4 kernels of an iteration directly.  Off by default: on ROCm 7.2 /
+                                  MI355X a graph launch per iteration costs ~5 us MORE than the direct
+                                  launches it replaces, at every problem size measured */
 #define ADMM_FLAG_SCAN_CHAIN 4 /* segment scan as the sequential per-QP chain (xscan_kernel) instead of
                                   the fp64-MFMA GEMM form (xscan_mfma_kernel) */
 #define ADMM_FLAG_UNFUSED 2    /* iterate with separate forward-rollout and z/dual kernels (w stored

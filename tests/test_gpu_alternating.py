@@ -38,12 +38,12 @@ def _close(a, b):
 @pytest.mark.parametrize("idx", range(len(ALT_CASES)))
 def test_alternating_iterates_match_oracle(gpu, idx):
     """Every iteration count 1..9 and 16 (both parities, from a fresh handle each time, so the
-    schedule start / end rules of next_form are all exercised), graph replay and direct launch."""
+    schedule start / end rules of next_form are all exercised), direct launches and graph replay."""
     make, rho, segs = ALT_CASES[idx]
     p = make()
     for K in (1, 2, 3, 4, 5, 6, 7, 8, 9, 16):
         ref = oc.solve(p, rho=rho, max_iter=K, stop=False)
-        for flags in (0, _abi.FLAG_NO_GRAPH):
+        for flags in (0, _abi.FLAG_GRAPH):
             with pkg.Solver(p, pkg.Options(rho=rho, segments=segs, flags=flags)) as s:
                 s.iterate(K)
                 w, z, y = s.get()

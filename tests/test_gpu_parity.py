@@ -149,7 +149,7 @@ def test_fused_relaxed_with_residuals(gpu):
 def test_graph_and_direct_launch_agree(gpu):
     p = pkg.cw_rendezvous(N=100, batch=66)
     outs = []
-    for flags in (0, 1):
+    for flags in (0, 16):          # direct launches (default) / ADMM_FLAG_GRAPH
         with pkg.Solver(p, pkg.Options(rho=0.05, flags=flags)) as s:
             s.iterate(17)
             outs.append(s.get())

@@ -10,7 +10,7 @@ import oracle_c
 p = pkg.cw_rendezvous(N=200, batch=70)
 for K in (1, 2, 3, 4, 5, 8, 11):
     ref = oracle_c.solve(p, rho=0.05, max_iter=K, check_interval=10, stop=False)
-    for flags in (0, _abi.FLAG_NO_GRAPH, _abi.FLAG_NO_ALTERNATE):
+    for flags in (0, _abi.FLAG_GRAPH, _abi.FLAG_NO_ALTERNATE):
         with pkg.Solver(p, pkg.Options(rho=0.05, segments=4, flags=flags)) as s:
             s.iterate(K)
             w, z, y = s.get()
