@@ -192,10 +192,13 @@ int admm_get_info(admm_handle* h, int32_t* iters, int32_t* status, double* r, do
 
 /* Timing hook for bench.py: runs `iters` iterations with HIP events recorded
  * on the handle's stream around each kernel launch and returns average
- * durations in ms.  fused_path != 0 (the default iteration path):
+ * durations in ms.  fused_path == 1 (the plain fused path, ADMM_FLAG_NO_ALTERNATE):
  *   ms = {xb, xscan, xfz, 0, finalise, whole iteration}
  * fused_path == 0 (ADMM_FLAG_UNFUSED path):
  *   ms = {xb, xscan, xf, zdual, finalise, whole iteration}
+ * fused_path == 2 (the default alternating-direction path; ADMM_ERR_UNSUPPORTED if the
+ * handle does not run it): `iters` PAIRS of iterations,
+ *   ms = {xscan, xfze, xscan (+ finalise role), xbze, 0, whole pair}
  * xb = x-update backward sweep, xscan = segment scan, xf = forward rollout,
  * zdual = standalone fused z/dual/residual kernel, xfz = forward rollout fused
  * with z/dual/residual.  `residuals` selects the residual-evaluating kernel
