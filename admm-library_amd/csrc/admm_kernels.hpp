@@ -109,11 +109,14 @@ struct RowView {
   __device__ __forceinline__ RowView(const double* base, size_t first_elem, size_t span_bytes)
       : rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(base + first_elem), 0,
                                                (int)(unsigned)span_bytes, 0x00020000)) {}
+  // AUX = cache policy bits of the buffer instruction (gfx940+: 1 = sc0, 2 = nt, 16 = sc1)
+  template <int AUX = 0>
   __device__ __forceinline__ double load(unsigned lane_bytes, unsigned row_bytes) const {
-    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsrc, lane_bytes, row_bytes, 0));
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsrc, lane_bytes, row_bytes, AUX));
   }
+  template <int AUX = 0>
   __device__ __forceinline__ void store(double v, unsigned lane_bytes, unsigned row_bytes) const {
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rsrc, lane_bytes, row_bytes, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rsrc, lane_bytes, row_bytes, AUX);
   }
 };
 

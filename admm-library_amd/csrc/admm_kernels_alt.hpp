@@ -21,6 +21,14 @@
 
 namespace admm {
 
+// Cache policy of the fused kernels' state loads / stores (RowView AUX bits; A/B in DESIGN.md §4.8).
+#ifndef ADMM_ALT_LOAD_AUX
+#define ADMM_ALT_LOAD_AUX 0
+#endif
+#ifndef ADMM_ALT_STORE_AUX
+#define ADMM_ALT_STORE_AUX 0
+#endif
+
 // Operand prefetch depth (stages) of the forward / backward fused kernel.
 #ifndef ADMM_ALT_PF_F
 #define ADMM_ALT_PF_F 2
@@ -113,10 +121,10 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY void xfze_kernel(
     const int kj = (k0 + j < k1) ? k0 + j : k1 - 1;
     const unsigned d0 = (unsigned)(kj - k0) * NU * PB;
 #pragma unroll
-    for (int jj = 0; jj < NU; ++jj) ld[j][jj] = vd.load(lb, d0 + jj * PB);
+    for (int jj = 0; jj < NU; ++jj) ld[j][jj] = vd.load<ADMM_ALT_LOAD_AUX>(lb, d0 + jj * PB);
     const unsigned r0 = (unsigned)(kj - k0) * NB * PB;
 #pragma unroll
-    for (int r = 0; r < NB; ++r) l0[j][r] = vv.load(lb, r0 + r * PB);
+    for (int r = 0; r < NB; ++r) l0[j][r] = vv.load<ADMM_ALT_LOAD_AUX>(lb, r0 + r * PB);
   }
   double a_r = 0, a_s = 0, a_w = 0, a_z = 0, a_y = 0;
   for (int kc = k0; kc < k1; kc += CH) {
@@ -139,10 +147,10 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY void xfze_kernel(
           const int kn = (k + PF < k1) ? k + PF : k1 - 1;
           const unsigned d0 = (unsigned)(kn - k0) * NU * PB;
 #pragma unroll
-          for (int jj = 0; jj < NU; ++jj) ld[j][jj] = vd.load(lb, d0 + jj * PB);
+          for (int jj = 0; jj < NU; ++jj) ld[j][jj] = vd.load<ADMM_ALT_LOAD_AUX>(lb, d0 + jj * PB);
           const unsigned r0 = (unsigned)(kn - k0) * NB * PB;
 #pragma unroll
-          for (int r = 0; r < NB; ++r) l0[j][r] = vv.load(lb, r0 + r * PB);
+          for (int r = 0; r < NB; ++r) l0[j][r] = vv.load<ADMM_ALT_LOAD_AUX>(lb, r0 + r * PB);
         }
         // ---- substitution: rollout of stage k ----
         double wv[NB];
@@ -175,7 +183,7 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY void xfze_kernel(
           double wh = wv[r];
           if (RELAX) wh = fma(alpha, wv[r], (1.0 - alpha) * zo);
           const double vn = wh + yo;
-          vv.store(vn, lb_st, r0 + r * PB);
+          vv.store<ADMM_ALT_STORE_AUX>(vn, lb_st, r0 + r * PB);
           const double zn = fmin(fmax(vn, mLO[r]), mHI[r]);
           const double yn = vn - zn;
           g[r] = -rho * (zn - yn);
@@ -207,7 +215,7 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY void xfze_kernel(
 #pragma unroll
           for (int i = 0; i < NX; ++i) {
             mu[i] = mn[i];
-            vm.store(mn[i], lb_st, m0 + i * PB);
+            vm.store<ADMM_ALT_STORE_AUX>(mn[i], lb_st, m0 + i * PB);
           }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -269,6 +277,11 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY void xbze_kernel(
   const RowView vv(v, (size_t)k0 * NB * P, (size_t)(k1 - k0) * NB * P * 8);
   const RowView vd(dbuf, (size_t)k0 * NU * P, (size_t)(k1 - k0) * NU * P * 8);
   const RowView vm(mvec, (size_t)k0 * NX * P, (size_t)(k1 - k0) * NX * P * 8);
+#ifdef ADMM_ABLATE_REVERSE   // timing-only diagnostic: the backward sweep walks ASCENDING addresses (wrong results)
+#define SIDX(kk) (k1 - 1 - (kk))
+#else
+#define SIDX(kk) ((kk) - k0)
+#endif
   double t[NX], e[NX], lam[NX], mi[NX];
   {
     const size_t o = (size_t)s * NX * P + col;
@@ -284,12 +297,12 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY void xbze_kernel(
 #pragma unroll
   for (int j = 0; j < PF; ++j) {
     const int kj = (k1 - 1 - j > k0) ? k1 - 1 - j : k0;
-    const unsigned m0 = (unsigned)(kj - k0) * NX * PB;
+    const unsigned m0 = (unsigned)SIDX(kj) * NX * PB;
 #pragma unroll
-    for (int i = 0; i < NX; ++i) lm[j][i] = vm.load(lb, m0 + i * PB);
-    const unsigned r0 = (unsigned)(kj - k0) * NB * PB;
+    for (int i = 0; i < NX; ++i) lm[j][i] = vm.load<ADMM_ALT_LOAD_AUX>(lb, m0 + i * PB);
+    const unsigned r0 = (unsigned)SIDX(kj) * NB * PB;
 #pragma unroll
-    for (int r = 0; r < NB; ++r) l0[j][r] = vv.load(lb, r0 + r * PB);
+    for (int r = 0; r < NB; ++r) l0[j][r] = vv.load<ADMM_ALT_LOAD_AUX>(lb, r0 + r * PB);
   }
   double a_r = 0, a_s = 0, a_w = 0, a_z = 0, a_y = 0;
   for (int kc = k1 - 1; kc >= k0; kc -= CH) {
@@ -311,12 +324,12 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY void xbze_kernel(
         {  // refill this slot with stage k - PF (clamped: the re-read rows near the segment start
            // are overwritten by this lane only later, in program order, and the values are unused)
           const int kn = (k - PF > k0) ? k - PF : k0;
-          const unsigned m0 = (unsigned)(kn - k0) * NX * PB;
+          const unsigned m0 = (unsigned)SIDX(kn) * NX * PB;
 #pragma unroll
-          for (int i = 0; i < NX; ++i) lm[j][i] = vm.load(lb, m0 + i * PB);
-          const unsigned r0 = (unsigned)(kn - k0) * NB * PB;
+          for (int i = 0; i < NX; ++i) lm[j][i] = vm.load<ADMM_ALT_LOAD_AUX>(lb, m0 + i * PB);
+          const unsigned r0 = (unsigned)SIDX(kn) * NB * PB;
 #pragma unroll
-          for (int r = 0; r < NB; ++r) l0[j][r] = vv.load(lb, r0 + r * PB);
+          for (int r = 0; r < NB; ++r) l0[j][r] = vv.load<ADMM_ALT_LOAD_AUX>(lb, r0 + r * PB);
         }
         // ---- substitution: costate step of stage k ----
         // (the old state z = clip(v), y = v - z is rebuilt twice -- here for the linear term of the
@@ -359,7 +372,7 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY void xbze_kernel(
         asm volatile("" ::: "memory");     // the box is re-read from LDS below, not carried in registers
         // ---- z-update, dual ascent, residual partials ----
         double g[NB];
-        const unsigned r0 = (unsigned)(k - k0) * NB * PB;
+        const unsigned r0 = (unsigned)SIDX(k) * NB * PB;
 #pragma unroll
         for (int r3 = 0; r3 < NB; r3 += 3) {
 #pragma unroll
@@ -370,7 +383,7 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY void xbze_kernel(
             double wh = wv[r];
             if (RELAX) wh = fma(alpha, wv[r], (1.0 - alpha) * zo);
             const double vn = wh + yo;
-            vv.store(vn, lb_st, r0 + r * PB);
+            vv.store<ADMM_ALT_STORE_AUX>(vn, lb_st, r0 + r * PB);
             const double zn = fmin(fmax(vn, lo), hi);
             const double yn = vn - zn;
             g[r] = -rho * (zn - yn);
@@ -394,9 +407,9 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY void xbze_kernel(
           for (int jj = 0; jj < NU; ++jj) { h[jj] = g[jj]; d[jj] = 0.0; }
           lds_matvec_acc<NU, NX, false, ALT_G>(rb + LB.BT, p, h);
           lds_matvec_acc<NU, NU, false, ALT_G>(rb + LB.SI, h, d);
-          const unsigned d0 = (unsigned)(k - k0) * NU * PB;
+          const unsigned d0 = (unsigned)SIDX(k) * NU * PB;
 #pragma unroll
-          for (int jj = 0; jj < NU; ++jj) vd.store(d[jj], lb_st, d0 + jj * PB);
+          for (int jj = 0; jj < NU; ++jj) vd.store<ADMM_ALT_STORE_AUX>(d[jj], lb_st, d0 + jj * PB);
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int i = 0; i < NX; ++i) t[i] = 0.0;
