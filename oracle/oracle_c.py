@@ -51,6 +51,10 @@ def solve(p: pkg.Problem, rho=0.1, alpha=1.0, eps_abs=1e-6, eps_rel=1e-6, max_it
           adapt_interval=0, adapt_max=16, adapt_mu=10.0, adapt_tau=2.0):
     """Returns dict(w, z, y, iters_run, iters, status, r, s, rho, rho_updates)."""
     lib = load()
+    if nthreads == 0:
+        # never more threads than QPs: idle OpenMP threads spin at every barrier, and on a box whose CPU
+        # share is smaller than its core count that turns a batch-1 solve of seconds into minutes
+        nthreads = max(1, min(max_threads(), p.batch))
     cp, keep = _abi.marshal_problem(p)
     co = _abi.make_options(rho=rho, alpha=alpha, eps_abs=eps_abs, eps_rel=eps_rel, max_iter=max_iter,
                            check_interval=check_interval, adapt_interval=adapt_interval, adapt_max=adapt_max,

@@ -1,0 +1,69 @@
+"""Successive-convexification outer loop (admm-library_amd/scvx.py) on the CPU:
+model / linearisation checks and the loop itself with the CPU oracle as its QP solver.
+No reference counterpart exists (PARITY UNPINNED); the checks are solver-independent properties."""
+import numpy as np
+
+import admm_library_amd as pkg
+from admm_library_amd import scvx as sc
+import oracle_c
+
+import _scvx_case as case
+
+
+def test_linearisation_at_the_origin_is_clohessy_wiltshire():
+    for dt in (case.DT, 0.01, 0.3):
+        A, B = sc.linearise(np.zeros((1, 6)), np.zeros((1, 3)), dt)
+        Ac, Bc = pkg.cw_matrices(dt)
+        assert np.abs(A[0] - Ac).max() <= 1e-6 and np.abs(B[0] - Bc).max() <= 1e-6   # RK4 truncation at dt = 0.3: 5e-7
+
+
+def test_linearisation_predicts_the_nonlinear_step():
+    rng = np.random.default_rng(3)
+    x = rng.uniform(-50, 50, (5, 6)); x[:, 3:] *= 0.1
+    u = rng.uniform(-1, 1, (5, 3))
+    A, B = sc.linearise(x, u, case.DT)
+    dx = 1e-3 * rng.standard_normal((5, 6)); du = 1e-3 * rng.standard_normal((5, 3))
+    lin = sc.rk4_step(x, u, case.DT) + np.einsum("kij,kj->ki", A, dx) + np.einsum("kij,kj->ki", B, du)
+    assert np.abs(sc.rk4_step(x + dx, u + du, case.DT) - lin).max() <= 1e-7
+
+
+def test_correction_qp_is_the_hot_path_problem():
+    N, dt = 12, case.DT
+    ub = np.full((N, 3), 0.5); ub[3] = 2.9
+    xb = sc.rollout(case.X0, ub, dt)
+    p = sc.correction_qp(xb, ub, case.X0, dt, case.Q, case.R, case.QN, -3.0, 3.0, tr_u=1.0, tr_x=7.0)
+    p.validate()
+    assert p.batch == 1 and p.time_varying and p.A.shape == (N, 6, 6) and p.lo.shape == (N, 9)
+    np.testing.assert_allclose(p.hi[3, :3], 0.1)            # control box minus the reference, inside the trust region
+    np.testing.assert_allclose(p.lo[3, :3], -1.0)
+    np.testing.assert_allclose(p.hi[0, :3], 1.0)
+    assert np.all(p.lo[:, 3:] == -7.0) and np.all(p.hi[:, 3:] == 7.0) and np.all(p.x0 == 0)
+    q = p.q.reshape(N, 9)
+    np.testing.assert_allclose(q[:, :3], ub @ case.R)
+    np.testing.assert_allclose(q[-1, 3:], case.QN @ xb[-1])
+    np.testing.assert_allclose(q[0, 3:], case.Q @ xb[0])
+    # the QP's objective at d = 0 differs from the trajectory cost by a constant only: its gradient is q
+    d = np.zeros((N, 9)); d[2, 1] = 1e-3
+    c0 = sc.trajectory_cost(xb, ub, case.Q, case.R, case.QN)
+    c1 = sc.trajectory_cost(xb + d[:, 3:], ub + d[:, :3], case.Q, case.R, case.QN)
+    assert abs((c1 - c0) - (q[2, 1] * 1e-3 + 0.5 * case.R[1, 1] * 1e-6)) <= 1e-9      # c0 ~ 5e5: cancellation
+
+
+def test_scvx_converges_with_the_oracle_as_qp_solver():
+    res = sc.scvx(case.X0, case.N, case.DT, case.Q, case.R, case.QN, -case.U_MAX, case.U_MAX,
+                  qp_solver=case.oracle_qp_solver(**case.QP), **case.SCVX)
+    assert res.converged and 2 <= res.accepted <= 10
+    costs = [h["cost_candidate"] for h in res.history if h["accepted"]]
+    assert all(b < a for a, b in zip([res.history[0]["cost"]] + costs, costs))      # monotone decrease
+    assert all(h["ratio"] > 0.9 for h in res.history if h["accepted"])            # the model predicts the plant
+    assert np.abs(res.u).max() <= case.U_MAX + 1e-12
+    np.testing.assert_allclose(res.x, sc.rollout(case.X0, res.u, case.DT), atol=1e-12)  # nonlinear dynamics hold exactly
+    assert abs(res.cost - sc.trajectory_cost(res.x, res.u, case.Q, case.R, case.QN)) <= 1e-9
+    # against designing with the Clohessy-Wiltshire model alone and flying the nonlinear plant
+    Ac, Bc = pkg.cw_matrices(case.DT)
+    p = pkg.Problem(N=case.N, A=Ac, B=Bc, Q=case.Q, R=case.R, QN=case.QN, x0=case.X0[None],
+                    lo=np.array([-case.U_MAX] * 3 + [-np.inf] * 6), hi=np.array([case.U_MAX] * 3 + [np.inf] * 6))
+    ucw = oracle_c.solve(p, **case.QP)["z"].reshape(case.N, 9)[:, :3]
+    xcw = sc.rollout(case.X0, ucw, case.DT)
+    assert sc.trajectory_cost(xcw, ucw, case.Q, case.R, case.QN) > 5 * res.cost
+    assert np.linalg.norm(xcw[-1, :3]) > 20 * np.linalg.norm(res.x[-1, :2])      # CW-only misses along-track by tens of km
