@@ -66,7 +66,7 @@ struct admm_handle {
   bool alt = false;              // the alternating kernels exist for this problem and are enabled
   // what the last kernel left behind for the next x-update:
   //   ALT_NONE  nothing (the next iteration starts with xb_kernel)
-  //   ALT_FWD   xfze ran: mvec | mseg | epsseg  -> next: scan (WB) + xbze
+  //   ALT_FWD   xfze ran: db rows | mseg | ebseg -> next: scan (WB) + xbze
   //   ALT_BWD   xbze ran: dbuf | tseg | eseg    -> next: scan (W)  + xfze   (w of that iteration cannot be
   //             re-materialised, so no API call ever returns in this state)
   enum { ALT_NONE = 0, ALT_FWD = 1, ALT_BWD = 2 };
@@ -673,8 +673,8 @@ int admm_setup(admm_handle** out, const admm_problem* p, const admm_options* o_i
     TRY_RELEASE(dalloc(&h->recBE, h->fac.recBE.size()));
     TRY_RELEASE(dalloc(&h->scanWpB, h->fac.scanWpB.size()));
     TRY_RELEASE(dalloc(&h->scan_rangeB, h->fac.scanRangeB.size()));
-    TRY_RELEASE(dalloc(&h->mvec, (size_t)h->N * h->n * P));
-    HIP_TRY_RELEASE(hipMemsetAsync(h->mvec, 0, sizeof(double) * (size_t)h->N * h->n * P, h->stream));
+    TRY_RELEASE(dalloc(&h->mvec, (size_t)h->N * h->m * P));     // db rows of the forward elimination
+    HIP_TRY_RELEASE(hipMemsetAsync(h->mvec, 0, sizeof(double) * (size_t)h->N * h->m * P, h->stream));
     HIP_TRY_RELEASE(hipMemcpy(h->recFE, h->fac.recFE.data(), sizeof(double) * h->fac.recFE.size(), hipMemcpyHostToDevice));
     HIP_TRY_RELEASE(hipMemcpy(h->recBE, h->fac.recBE.data(), sizeof(double) * h->fac.recBE.size(), hipMemcpyHostToDevice));
     HIP_TRY_RELEASE(hipMemcpy(h->scanWpB, h->fac.scanWpB.data(), sizeof(double) * h->fac.scanWpB.size(), hipMemcpyHostToDevice));

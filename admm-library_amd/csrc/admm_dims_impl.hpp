@@ -64,7 +64,7 @@ void launch_dim(const XLaunch& l, XKernel k, bool a, bool b) {
       if constexpr (alt_dims(NX, NU)) {
         const bool relax = l.alpha != 1.0;
         // the scan's input / output slots are shared by both directions: (tseg, eseg) = (mseg, epsseg),
-        // (tin, xin) = (m_in, lam_in)
+        // (tin, xin) = (m_in, x_end)
 #define ALT1(RS, RX)                                                                                         \
   do {                                                                                                       \
     if (k == XKernel::XFZE)                                                                                  \

@@ -17,7 +17,7 @@ struct XLaunch {
   double *v, *w;                // state in v-form; materialised w
   const double *recB, *recF, *recS;
   const double *recFE, *recBE;  // records of the alternating-direction kernels (admm_kernels_alt.hpp)
-  double* mvec;                 // their per-stage filter means (n rows per stage)
+  double* mvec;                 // the forward elimination's feed-forward rows db (m rows per stage)
   const int* seg_start;
   double *dbuf, *tseg, *eseg, *tin, *xin, *part;
   const double* x0;

@@ -2,7 +2,9 @@
 // once per admm_setup (and again only if rho changes).
 #include "admm_factor.hpp"
 
+#include <algorithm>
 #include <cmath>
+#include <cstdint>
 
 namespace admm {
 namespace {
@@ -140,16 +142,101 @@ void put_block(std::vector<double>& W, int K, int r0, int c0, const Mat& a, int 
     }
 }
 
-// Forward-elimination (information-filter) form of the x-update and its segment algebra
-// (DESIGN.md §4.8).  With Rr = R + rho I, Qr_k = Q (QN at k = N) + rho I and C_0 = 0:
-//     Pm      = A_k C_k A_k' + B_k Rr^{-1} B_k'
+// general n x n inverse (Gauss-Jordan, partial pivoting); false if a pivot is tiny relative to the matrix
+bool general_inverse(const Mat& a, int n, Mat& inv) {
+  Mat w(a);
+  inv = eye(n);
+  double scale = 0.0;
+  for (double v : a) scale = std::max(scale, std::fabs(v));
+  if (!(scale > 0.0) || !std::isfinite(scale)) return false;
+  for (int c = 0; c < n; ++c) {
+    int piv = c;
+    for (int r = c + 1; r < n; ++r)
+      if (std::fabs(w[(size_t)r * n + c]) > std::fabs(w[(size_t)piv * n + c])) piv = r;
+    const double pv = w[(size_t)piv * n + c];
+    if (!(std::fabs(pv) > 1e-10 * scale)) return false;
+    if (piv != c)
+      for (int j = 0; j < n; ++j) {
+        std::swap(w[(size_t)piv * n + j], w[(size_t)c * n + j]);
+        std::swap(inv[(size_t)piv * n + j], inv[(size_t)c * n + j]);
+      }
+    for (int j = 0; j < n; ++j) { w[(size_t)c * n + j] /= pv; inv[(size_t)c * n + j] /= pv; }
+    for (int r = 0; r < n; ++r) {
+      if (r == c) continue;
+      const double fct = w[(size_t)r * n + c];
+      if (fct == 0.0) continue;
+      for (int j = 0; j < n; ++j) {
+        w[(size_t)r * n + j] -= fct * w[(size_t)c * n + j];
+        inv[(size_t)r * n + j] -= fct * inv[(size_t)c * n + j];
+      }
+    }
+  }
+  return true;
+}
+
+// Moore-Penrose inverse of a symmetric positive semidefinite matrix (cyclic Jacobi eigen-decomposition;
+// eigenvalues below tol * largest count as zero).
+Mat pinv_psd(const Mat& a_in, int n, double tol) {
+  Mat a(a_in), v = eye(n);
+  symmetrise(a, n);
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    double off = 0.0, diag = 0.0;
+    for (int i = 0; i < n; ++i)
+      for (int j = 0; j < n; ++j) (i == j ? diag : off) += a[(size_t)i * n + j] * a[(size_t)i * n + j];
+    if (off <= 1e-32 * diag || off == 0.0) break;
+    for (int p = 0; p < n; ++p)
+      for (int q = p + 1; q < n; ++q) {
+        const double apq = a[(size_t)p * n + q];
+        if (apq == 0.0) continue;
+        const double theta = (a[(size_t)q * n + q] - a[(size_t)p * n + p]) / (2.0 * apq);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+        const double c = 1.0 / std::sqrt(t * t + 1.0), sn = t * c;
+        for (int k = 0; k < n; ++k) {      // columns p, q of a
+          const double akp = a[(size_t)k * n + p], akq = a[(size_t)k * n + q];
+          a[(size_t)k * n + p] = c * akp - sn * akq;
+          a[(size_t)k * n + q] = sn * akp + c * akq;
+        }
+        for (int k = 0; k < n; ++k) {      // rows p, q of a
+          const double apk = a[(size_t)p * n + k], aqk = a[(size_t)q * n + k];
+          a[(size_t)p * n + k] = c * apk - sn * aqk;
+          a[(size_t)q * n + k] = sn * apk + c * aqk;
+        }
+        for (int k = 0; k < n; ++k) {      // eigenvectors
+          const double vkp = v[(size_t)k * n + p], vkq = v[(size_t)k * n + q];
+          v[(size_t)k * n + p] = c * vkp - sn * vkq;
+          v[(size_t)k * n + q] = sn * vkp + c * vkq;
+        }
+      }
+  }
+  double wmax = 0.0;
+  for (int i = 0; i < n; ++i) wmax = std::max(wmax, a[(size_t)i * n + i]);
+  Mat out((size_t)n * n, 0.0);
+  for (int e = 0; e < n; ++e) {
+    const double w = a[(size_t)e * n + e];
+    if (!(w > tol * wmax) || !(w > 0.0)) continue;
+    for (int i = 0; i < n; ++i)
+      for (int j = 0; j < n; ++j) out[(size_t)i * n + j] += v[(size_t)i * n + e] * v[(size_t)j * n + e] / w;
+  }
+  return out;
+}
+
+// Forward-elimination form of the x-update -- the time-reversed mirror of the Riccati form -- and its
+// segment algebra.  With Rr = R + rho I, Qr_k = Q (QN at k = N) + rho I and the
+// filter covariance C_0 = 0 (x_0 is known):
+//     Pm      = A_k C_k A_k' + B_k Rr^{-1} B_k'                     (prior covariance of x_{k+1})
 //     G_{k+1} = Pm (Pm + Qr_{k+1}^{-1})^{-1},       C_{k+1} = Pm - G_{k+1} Pm
-// elimination (forward):   m_{k+1} = F_k m_k + Gam_k g^u_k + Pi_k g^x_{k+1},   m_0 = x_0
-// substitution (backward, costate form; lam = 0 after the last block):
-//     x_{k+1} = m_{k+1} + C_{k+1} lam,   nu = lam - Qr_{k+1} x_{k+1} - g^x_{k+1},
-//     u_k = Rr^{-1} (B_k' nu - g^u_k),   lam <- A_k' nu
-// Only inverses of positive definite matrices occur (C_k itself is singular for small k).
-// Leaves f.alt_ok false if a pivot fails or a transfer matrix overflows.
+//     Kb_k    = -Rr^{-1} B_k' Pm^+                                  (backward feedback gain, m x n)
+// elimination (forward, mu_0 = x_0):
+//     db_k     = DK_k mu_k + DG_k g^u_k           -> stored, m rows per stage   (DK = -Kb A, DG = Rr^{-1} (I + B' Kb'))
+//     mu_{k+1} = F_k mu_k + Gam_k g^u_k + Pi_k g^x_{k+1}
+// substitution (backward, x_N = mu_N):
+//     u_k = -Kb_k x_{k+1} - db_k,      x_k = A_k^{-1} (x_{k+1} - B_k u_k)
+// i.e. a feedback law and a rollout, as in the Riccati form but running backward in time; the map
+// x_{k+1} -> x_k is the (stable) smoother gain wherever Pm has full rank.  Pm is rank deficient for
+// the first ceil(n/m) stages (pseudo-inverse: x_{k+1} - m^-_{k+1} lies in its range), and the gains
+// there are large, so the form is verified below against the Riccati form on random data before it
+// is enabled.  Needs every A_k invertible (true for any discretised ODE).
+// Leaves f.alt_ok false if a pivot fails, a transfer matrix overflows or the verification misses.
 void build_alternating(Factor& f, const std::vector<Mat>& A, const std::vector<Mat>& B, const Mat& Q,
                        const Mat& R, const Mat& QN, double rho) {
   const int N = f.N, n = f.n, m = f.m, S = f.S;
@@ -176,14 +263,13 @@ void build_alternating(Factor& f, const std::vector<Mat>& A, const std::vector<M
   Mat Qi, QNi;
   if (!spd_inverse(Qr, n, Qi) || !spd_inverse(QNr, n, QNi)) return;
 
-  std::vector<Mat> Fm(N), Gam(N), Pi(N), E(N), Cn(N), Qk(N);
+  std::vector<Mat> Fm(N), Gam(N), Pi(N), DK(N), DG(N), Kb(N), Ai(N), AiB(N), Jb(N);
   Mat C((size_t)n * n, 0.0);
   for (int k = 0; k < N; ++k) {
     const Mat At = tr(A[k], n, n), Bt = tr(B[k], n, m);
     const Mat BRi = mul(B[k], Ri, n, m, m);
     Mat Pm = add(mul(mul(A[k], C, n, n, n), At, n, n, n), mul(BRi, Bt, n, m, n));
     symmetrise(Pm, n);
-    const Mat& Qn = (k + 1 == N) ? QNr : Qr;
     const Mat& Qin = (k + 1 == N) ? QNi : Qi;
     Mat D = add(Pm, Qin);
     symmetrise(D, n);
@@ -191,14 +277,17 @@ void build_alternating(Factor& f, const std::vector<Mat>& A, const std::vector<M
     if (!spd_inverse(D, n, Di)) return;
     const Mat G = mul(Pm, Di, n, n, n);
     const Mat ImG = sub(I, G);
-    C = sub(Pm, mul(G, Pm, n, n, n));
-    symmetrise(C, n);
+    Kb[k] = neg(mul(mul(Ri, Bt, m, m, n), pinv_psd(Pm, n, 1e-13), m, n, n));
+    if (!general_inverse(A[k], n, Ai[k])) return;
+    AiB[k] = mul(Ai[k], B[k], n, n, m);
+    Jb[k] = mul(Ai[k], add(I, mul(B[k], Kb[k], n, m, n)), n, n, n);       // x_k = Jb x_{k+1} + AiB db_k
     Fm[k] = mul(ImG, A[k], n, n, n);
     Gam[k] = neg(mul(ImG, BRi, n, n, m));
     Pi[k] = neg(mul(G, Qin, n, n, n));
-    E[k] = mul(At, sub(I, mul(Qn, C, n, n, n)), n, n, n);
-    Cn[k] = C;
-    Qk[k] = Qn;
+    DK[k] = neg(mul(Kb[k], A[k], m, n, n));
+    DG[k] = add(Ri, mul(Kb[k], BRi, m, n, m));                            // Rr^{-1} - Kb (-B Rr^{-1})
+    C = sub(Pm, mul(G, Pm, n, n, n));
+    symmetrise(C, n);
     // stage-local blocks; the rollout / elimination blocks are copied from the plain records
     double* rfe = &f.recFE[(size_t)k * f.RFE];
     double* rbe = &f.recBE[(size_t)k * f.RBE];
@@ -210,10 +299,11 @@ void build_alternating(Factor& f, const std::vector<Mat>& A, const std::vector<M
     put(rfe + lfe.FM, Fm[k]);
     put(rfe + lfe.GA, Gam[k]);
     put(rfe + lfe.PI, Pi[k]);
-    put(rbe + lbe.CM, C);
-    put(rbe + lbe.QM, Qn);
-    put(rbe + lbe.RB, mul(Ri, Bt, m, m, n));
-    put(rbe + lbe.RI, Ri);
+    put(rfe + lfe.DK, DK[k]);
+    put(rfe + lfe.DG, DG[k]);
+    put(rbe + lbe.KB, Kb[k]);
+    put(rbe + lbe.AI, Ai[k]);
+    put(rbe + lbe.AIB, neg(AiB[k]));                                      // x_k = AI x_{k+1} + AIB u_k
     for (int i = 0; i < even_up(n * n); ++i) rbe[lbe.AT + i] = rb[lb.AT + i];
     for (int i = 0; i < even_up(m * n); ++i) rbe[lbe.BT + i] = rb[lb.BT + i];
     for (int i = 0; i < even_up(m * m); ++i) rbe[lbe.SI + i] = rb[lb.SI + i];
@@ -226,32 +316,25 @@ void build_alternating(Factor& f, const std::vector<Mat>& A, const std::vector<M
     rbe[lbe.UB] = rb[lb.UB];
   }
 
-  // ---- segment algebra ----
-  //   Phf_k = F_k ... F_a,   Omb_k = (E_a ... E_{k-1}) A_k'
-  //   eps(s) = - sum_k Omb_k (Qr_{k+1} m0_{k+1} + g^x_{k+1}) = sum_k (YU_k g^u_k + YX_k g^x_{k+1})
-  //   lam_out(s) = eps(s) + Es(s) lam_in(s) + Xib(s) m_in(s),   m_out(s) = mseg(s) + Phs(s) m_in(s)
-  std::vector<Mat> Phs(S), Es(S), Xib(S);
+  // ---- segment algebra (a = segment start, b = end) ----
+  //   mu_k  = mu0_k + (F_{k-1} ... F_a) m_in              =>  db_k = db0_k + Psb_k m_in,  Psb_k = DK_k F_{k-1} ... F_a
+  //   x_a   = (Jb_a ... Jb_{b-1}) x_b + sum_k Omb_k db_k,      Omb_k = (Jb_a ... Jb_{k-1}) A_k^{-1} B_k
+  //   m_out = mseg + Phs m_in;    x_end(s-1) = ebseg(s) + Thb(s) x_end(s) + Xib(s) m_in(s),   ebseg = sum_k Omb_k db0_k
+  std::vector<Mat> Phs(S), Thb(S), Xib(S);
   for (int s = 0; s < S; ++s) {
     const int a = f.seg_start[s], b = f.seg_start[s + 1];
-    std::vector<Mat> Phf(b - a), Omb(b - a);
-    Mat P = I, Ep = I;
+    Mat P = I, Jp = I, Xi((size_t)n * n, 0.0);
     for (int k = a; k < b; ++k) {
+      const Mat Psb = mul(DK[k], P, m, n, n);
+      const Mat Omb = mul(Jp, AiB[k], n, n, m);
+      put(&f.recBE[(size_t)k * f.RBE + lbe.PSB], Psb);
+      put(&f.recFE[(size_t)k * f.RFE + lfe.OB], Omb);
+      Xi = add(Xi, mul(Omb, Psb, n, m, n));
       P = mul(Fm[k], P, n, n, n);
-      Phf[k - a] = P;
-      Omb[k - a] = mul(Ep, tr(A[k], n, n), n, n, n);
-      Ep = mul(Ep, E[k], n, n, n);
-      put(&f.recBE[(size_t)k * f.RBE + lbe.PHF], P);
+      Jp = mul(Jp, Jb[k], n, n, n);
     }
     Phs[s] = P;
-    Es[s] = Ep;
-    Mat Z((size_t)n * n, 0.0), Xi((size_t)n * n, 0.0);
-    for (int j = b - 1; j >= a; --j) {
-      const Mat OQ = mul(Omb[j - a], Qk[j], n, n, n);
-      Z = (j + 1 < b) ? add(OQ, mul(Z, Fm[j + 1], n, n, n)) : OQ;
-      put(&f.recFE[(size_t)j * f.RFE + lfe.YU], neg(mul(Z, Gam[j], n, n, m)));
-      put(&f.recFE[(size_t)j * f.RFE + lfe.YX], sub(neg(mul(Z, Pi[j], n, n, n)), Omb[j - a]));
-      Xi = sub(Xi, mul(OQ, Phf[j - a], n, n, n));
-    }
+    Thb[s] = Jp;
     Xib[s] = Xi;
   }
   for (int k = 0; k < N; ++k) {                       // (the box blocks may hold +-inf: matrices only)
@@ -260,35 +343,126 @@ void build_alternating(Factor& f, const std::vector<Mat>& A, const std::vector<M
   }
 
   // ---- scan matrix, same shape and layout as scanW ----
+  //   in rows:  mseg(0..S-1) | x0 | ebseg(0..S-1)          out rows:  m_in(0..S-1) | x_end(0..S-1)
   const int Sn = S * n, Mt = f.scanMt, M = f.scanM, K = f.scanK;
   f.scanWB.assign((size_t)M * K, 0.0);
-  const int c_m = 0, c_x0 = Sn, c_e = Sn + n, r_m = 0, r_l = Mt;
-  // m_in(s) = [Phs_{s-1} ... Phs_0] x0 + sum_{s' < s} [Phs_{s-1} ... Phs_{s'+1}] mseg(s')
-  std::vector<std::vector<Mat>> Mm(S, std::vector<Mat>(S));   // Mm[s][s'] (s' < s)
-  std::vector<Mat> Mx0(S);
-  for (int s = 0; s < S; ++s) {
+  const int c_m = 0, c_x0 = Sn, c_e = Sn + n, r_m = 0, r_x = Mt;
+  // m_in(s) = [Phs_{s-1} ... Phs_0] x0 + sum_{s' < s} [Phs_{s-1} ... Phs_{s'+1}] mseg(s'),  s = 0 .. S
+  std::vector<std::vector<Mat>> Mm(S + 1, std::vector<Mat>(S));   // Mm[s][s'] (s' < s)
+  std::vector<Mat> Mx0(S + 1);
+  for (int s = 0; s <= S; ++s) {
     Mat P = I;
     for (int sp = s - 1; sp >= 0; --sp) {
       Mm[s][sp] = P;
-      put_block(f.scanWB, K, r_m + s * n, c_m + sp * n, P, n, false);
+      if (s < S) put_block(f.scanWB, K, r_m + s * n, c_m + sp * n, P, n, false);
       P = mul(P, Phs[sp], n, n, n);
     }
     Mx0[s] = P;
-    put_block(f.scanWB, K, r_m + s * n, c_x0, P, n, false);
+    if (s < S) put_block(f.scanWB, K, r_m + s * n, c_x0, P, n, false);
   }
-  // lam_in(s) = sum_{s' > s} [Es_{s+1} ... Es_{s'-1}] (eps(s') + Xib_{s'} m_in(s'))
+  // x_end(s) = Pb(s, S) m_in(S) + sum_{s' > s} Pb(s, s') (ebseg(s') + Xib_{s'} m_in(s')),  Pb(s, s') = Thb_{s+1} ... Thb_{s'-1}
+  auto add_min = [&](int row, const Mat& coef, int sm) {            // row block += coef * m_in(sm)
+    put_block(f.scanWB, K, row, c_x0, mul(coef, Mx0[sm], n, n, n), n, true);
+    for (int spp = 0; spp < sm; ++spp) put_block(f.scanWB, K, row, c_m + spp * n, mul(coef, Mm[sm][spp], n, n, n), n, true);
+  };
   for (int s = 0; s < S; ++s) {
     Mat P = I;
     for (int sp = s + 1; sp < S; ++sp) {
-      put_block(f.scanWB, K, r_l + s * n, c_e + sp * n, P, n, false);
-      const Mat PX = mul(P, Xib[sp], n, n, n);
-      put_block(f.scanWB, K, r_l + s * n, c_x0, mul(PX, Mx0[sp], n, n, n), n, true);
-      for (int spp = 0; spp < sp; ++spp)
-        put_block(f.scanWB, K, r_l + s * n, c_m + spp * n, mul(PX, Mm[sp][spp], n, n, n), n, true);
-      P = mul(P, Es[sp], n, n, n);
+      put_block(f.scanWB, K, r_x + s * n, c_e + sp * n, P, n, false);
+      add_min(r_x + s * n, mul(P, Xib[sp], n, n, n), sp);
+      P = mul(P, Thb[sp], n, n, n);
     }
+    add_min(r_x + s * n, P, S);
   }
   for (double v : f.scanWB) if (!std::isfinite(v)) return;
+
+  // ---- verification against the Riccati form (one QP, random linear term, the scan as the dense product) ----
+  {
+    const int nb = n + m;
+    uint64_t lcg = 0x9E3779B97F4A7C15ull;
+    auto rnd = [&]() { lcg = lcg * 6364136223846793005ull + 1442695040888963407ull; return ((double)(lcg >> 11) / 9007199254740992.0) * 2.0 - 1.0; };
+    std::vector<double> g((size_t)N * nb), x0(n), wa((size_t)N * nb), wb((size_t)N * nb);
+    for (auto& v : g) v = rnd();
+    for (auto& v : x0) v = rnd();
+    auto matvec = [](const double* Mx, const double* x, int r, int c, double* y, double sgn, bool accumulate) {
+      for (int i = 0; i < r; ++i) {
+        double a = accumulate ? y[i] : 0.0;
+        for (int j = 0; j < c; ++j) a += sgn * Mx[(size_t)i * c + j] * x[j];
+        y[i] = a;
+      }
+    };
+    {  // Riccati form, sequential: records hold AT, BT, SI, KT (backward) and K, A, B (forward)
+      std::vector<double> t(n, 0.0), p(n), h(m), d((size_t)N * m), x(x0), xn(n), u(m), tn(n);
+      for (int k = N - 1; k >= 0; --k) {
+        const double* rb = &f.recB[(size_t)k * f.RB];
+        for (int i = 0; i < n; ++i) p[i] = g[(size_t)k * nb + m + i] + t[i];
+        for (int j = 0; j < m; ++j) h[j] = g[(size_t)k * nb + j];
+        matvec(rb + lb.BT, p.data(), m, n, h.data(), 1.0, true);
+        matvec(rb + lb.SI, h.data(), m, m, &d[(size_t)k * m], 1.0, false);
+        matvec(rb + lb.AT, p.data(), n, n, tn.data(), 1.0, false);
+        matvec(rb + lb.KT, h.data(), n, m, tn.data(), -1.0, true);
+        t = tn;
+      }
+      for (int k = 0; k < N; ++k) {
+        const double* rf = &f.recF[(size_t)k * f.RF];
+        for (int j = 0; j < m; ++j) u[j] = -d[(size_t)k * m + j];
+        matvec(rf + lf.K, x.data(), m, n, u.data(), -1.0, true);
+        matvec(rf + lf.A, x.data(), n, n, xn.data(), 1.0, false);
+        matvec(rf + lf.B, u.data(), n, m, xn.data(), 1.0, true);
+        x = xn;
+        for (int j = 0; j < m; ++j) wa[(size_t)k * nb + j] = u[j];
+        for (int i = 0; i < n; ++i) wa[(size_t)k * nb + m + i] = x[i];
+      }
+    }
+    {  // forward-elimination form through the segment records and WB
+      std::vector<double> db((size_t)N * m), in(K, 0.0), out(M, 0.0), mu(n), mn(n), eb(n), dd(m);
+      for (int s = 0; s < S; ++s) {
+        std::fill(mu.begin(), mu.end(), 0.0);
+        std::fill(eb.begin(), eb.end(), 0.0);
+        for (int k = f.seg_start[s]; k < f.seg_start[s + 1]; ++k) {
+          const double* rfe = &f.recFE[(size_t)k * f.RFE];
+          const double* gu = &g[(size_t)k * nb];
+          const double* gx = gu + m;
+          matvec(rfe + lfe.DK, mu.data(), m, n, dd.data(), 1.0, false);
+          matvec(rfe + lfe.DG, gu, m, m, dd.data(), 1.0, true);
+          for (int j = 0; j < m; ++j) db[(size_t)k * m + j] = dd[j];
+          matvec(rfe + lfe.OB, dd.data(), n, m, eb.data(), 1.0, true);
+          matvec(rfe + lfe.FM, mu.data(), n, n, mn.data(), 1.0, false);
+          matvec(rfe + lfe.GA, gu, n, m, mn.data(), 1.0, true);
+          matvec(rfe + lfe.PI, gx, n, n, mn.data(), 1.0, true);
+          mu = mn;
+        }
+        for (int i = 0; i < n; ++i) { in[c_m + s * n + i] = mu[i]; in[c_e + s * n + i] = eb[i]; }
+      }
+      for (int i = 0; i < n; ++i) in[c_x0 + i] = x0[i];
+      matvec(f.scanWB.data(), in.data(), M, K, out.data(), 1.0, false);
+      std::vector<double> x(n), xk(n), u(m), d(m);
+      for (int s = 0; s < S; ++s) {
+        const double* mi = &out[r_m + s * n];
+        for (int i = 0; i < n; ++i) x[i] = out[r_x + s * n + i];
+        for (int k = f.seg_start[s + 1] - 1; k >= f.seg_start[s]; --k) {
+          const double* rbe = &f.recBE[(size_t)k * f.RBE];
+          for (int j = 0; j < m; ++j) d[j] = db[(size_t)k * m + j];
+          matvec(rbe + lbe.PSB, mi, m, n, d.data(), 1.0, true);
+          for (int j = 0; j < m; ++j) u[j] = -d[j];
+          matvec(rbe + lbe.KB, x.data(), m, n, u.data(), -1.0, true);
+          for (int j = 0; j < m; ++j) wb[(size_t)k * nb + j] = u[j];
+          for (int i = 0; i < n; ++i) wb[(size_t)k * nb + m + i] = x[i];
+          matvec(rbe + lbe.AI, x.data(), n, n, xk.data(), 1.0, false);
+          matvec(rbe + lbe.AIB, u.data(), n, m, xk.data(), 1.0, true);
+          x = xk;
+        }
+      }
+    }
+    double err = 0.0, scale = 1.0;
+    for (size_t i = 0; i < wa.size(); ++i) {
+      if (!std::isfinite(wb[i])) return;
+      err = std::max(err, std::fabs(wa[i] - wb[i]));
+      scale = std::max(scale, std::fabs(wa[i]));
+    }
+    f.alt_check = err / scale;
+    if (!(f.alt_check <= 2e-11)) return;             // an order of magnitude inside the 1e-10 parity tolerance
+  }
   pack_scan(f.scanWB, M, K, f.scanWpB, f.scanRangeB);
   f.alt_ok = true;
 }

@@ -61,9 +61,10 @@ struct Factor {
   // Alternating-direction iteration: records of the two fused kernels
   // (layouts in admm_layout.hpp) and the scan matrix of the forward-elimination form, same
   // shape and row/column layout as scanW:
-  //   in  rows: mseg(0..S-1) | x0 | epsseg(0..S-1)          out rows: m_in(0..S-1) | lam_in(0..S-1)
+  //   in  rows: mseg(0..S-1) | x0 | ebseg(0..S-1)           out rows: m_in(0..S-1) | x_end(0..S-1)
   // alt_ok is false when that form could not be built (then only the plain iteration runs).
   bool alt_ok = false;
+  double alt_check = -1.0;          // relative mismatch of the two forms on the host verification vector (-1: not run)
   int RFE = 0, RBE = 0;
   std::vector<double> recFE;        // N * RFE
   std::vector<double> recBE;        // N * RBE

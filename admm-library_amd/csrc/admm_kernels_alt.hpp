@@ -5,16 +5,16 @@
 // (xb_kernel backward, xfz_kernel forward), and the next iteration's backward sweep has to
 // re-read the state v the forward sweep has just written.  Here consecutive iterations solve
 // the same KKT system in opposite elimination orders:
-//     even iteration:  backward elimination (Riccati)        + forward substitution
-//     odd iteration:   forward elimination (information form) + backward substitution
+//     even iteration:  backward elimination (Riccati)            + forward substitution (feedback + rollout)
+//     odd iteration:   forward elimination (its mirror in time)   + backward substitution (feedback + backward rollout)
 // so every substitution sweep runs in the direction of the NEXT iteration's elimination sweep
 // and the two are one kernel: the fresh v+ of a stage is eliminated while still in registers.
 //     xfze_kernel  (forward):   rollout (as xfz_kernel) | z-update | forward elimination of v+
-//     xbze_kernel  (backward):  costate substitution    | z-update | backward elimination of v+
+//     xbze_kernel  (backward):  backward rollout        | z-update | backward elimination of v+
 // One kernel + one scan per iteration.  Algorithmic HBM bytes per stacked element (n = 6, m = 3):
-//     xfze: d read 2.67 + v read 8 + v+ written 8 + m written 5.33 = 24
-//     xbze: m read 5.33 + v read 8 + v+ written 8 + d written 2.67 = 24
-// against 29.33 for xb + xfz.  Same layout, staging and addressing as admm_kernels.hpp.
+//     xfze: d read 2.67 + v read 8 + v+ written 8 + db written 2.67 = 21.33
+//     xbze: db read 2.67 + v read 8 + v+ written 8 + d written 2.67 = 21.33
+// against 29.33 for xb + xfz (each elimination leaves only its m-row feed-forward term per stage).  Same layout, staging and addressing as admm_kernels.hpp.
 #pragma once
 
 #include "admm_kernels.hpp"
@@ -74,15 +74,16 @@ __device__ __forceinline__ double scan_row(const double* base, size_t o, int nsp
 //     (z, y) = (clip(v), v - clip(v));  wh = alpha w + (1 - alpha) z;  v+ = wh + y   -> v (in place)
 //     z+ = clip(v+), y+ = v+ - z+;  RESID: the five per-QP partial sums           -> part
 //     g  = -rho (z+ - y+)                                 (linear term of the NEXT x-update)
-//     eps += YU_k g^u + YX_k g^x
-//     mu  = FM_k mu + GA_k g^u + PI_k g^x                 (mu = 0 on entry)        -> mvec block k
-// and on exit mu -> mseg[s], eps -> epsseg[s].
+//     db  = DK_k mu + DG_k g^u                            (mu = 0 on entry)        -> dbb block k (m rows)
+//     eb += OB_k db
+//     mu  = FM_k mu + GA_k g^u + PI_k g^x
+// and on exit mu -> mseg[s], eb -> ebseg[s].
 // ---------------------------------------------------------------------------
 template <int NX, int NU, bool RESID, bool RELAX>
 __global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY void xfze_kernel(
     const double* __restrict__ dbuf, const double* __restrict__ tin, const double* __restrict__ xin,
     const double* __restrict__ recFE, const int* __restrict__ seg_start_, double* __restrict__ v,
-    double* __restrict__ mvec, double* __restrict__ mseg, double* __restrict__ epsseg,
+    double* __restrict__ dbb, double* __restrict__ mseg, double* __restrict__ epsseg,
     double* __restrict__ part, double alpha, double rho, int pitch, int nsplit, size_t split_stride) {
   constexpr int NB = NX + NU;
   constexpr RecFELayout LF = rec_fe_layout(NX, NU);
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY void xfze_kernel(
   const unsigned PB = (unsigned)pitch * 8u;
   const RowView vv(v, (size_t)k0 * NB * P, (size_t)(k1 - k0) * NB * P * 8);
   const RowView vd(dbuf, (size_t)k0 * NU * P, (size_t)(k1 - k0) * NU * P * 8);
-  const RowView vm(mvec, (size_t)k0 * NX * P, (size_t)(k1 - k0) * NX * P * 8);
+  const RowView vm(dbb, (size_t)k0 * NU * P, (size_t)(k1 - k0) * NU * P * 8);
   double t[NX], x[NX], mu[NX], eps[NX];
   {
     const size_t o = (size_t)s * NX * P + col;
@@ -200,23 +201,23 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY void xfze_kernel(
         __builtin_amdgcn_sched_barrier(0);
         // ---- forward elimination of stage k for the next x-update ----
         {
-          double gu[NU], gx[NX], mn[NX];
+          double gu[NU], gx[NX], dn[NU], mn[NX];
 #pragma unroll
-          for (int jj = 0; jj < NU; ++jj) gu[jj] = g[jj];
+          for (int jj = 0; jj < NU; ++jj) { gu[jj] = g[jj]; dn[jj] = 0.0; }
 #pragma unroll
           for (int i = 0; i < NX; ++i) { gx[i] = g[NU + i]; mn[i] = 0.0; }
-          lds_matvec_acc<NX, NU, false, ALT_G>(rf + LF.YU, gu, eps);
-          lds_matvec_acc<NX, NX, false, ALT_G>(rf + LF.YX, gx, eps);
+          lds_matvec_acc<NU, NX, false, ALT_G>(rf + LF.DK, mu, dn);       // db = DK mu
+          lds_matvec_acc<NU, NU, false, ALT_G>(rf + LF.DG, gu, dn);       //      + DG g^u
+          const unsigned m0 = (unsigned)(k - k0) * NU * PB;
+#pragma unroll
+          for (int jj = 0; jj < NU; ++jj) vm.store<ADMM_ALT_STORE_AUX>(dn[jj], lb_st, m0 + jj * PB);
+          lds_matvec_acc<NX, NU, false, ALT_G>(rf + LF.OB, dn, eps);      // eb += OB db
           __builtin_amdgcn_sched_barrier(0);
           lds_matvec_acc<NX, NX, false, ALT_G>(rf + LF.FM, mu, mn);
           lds_matvec_acc<NX, NU, false, ALT_G>(rf + LF.GA, gu, mn);
           lds_matvec_acc<NX, NX, false, ALT_G>(rf + LF.PI, gx, mn);
-          const unsigned m0 = (unsigned)(k - k0) * NX * PB;
 #pragma unroll
-          for (int i = 0; i < NX; ++i) {
-            mu[i] = mn[i];
-            vm.store<ADMM_ALT_STORE_AUX>(mn[i], lb_st, m0 + i * PB);
-          }
+          for (int i = 0; i < NX; ++i) mu[i] = mn[i];
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -242,18 +243,18 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY void xfze_kernel(
 
 // ---------------------------------------------------------------------------
 // Backward fused kernel.  One lane = one QP, blockIdx.y = segment, stages k = b-1 .. a, with
-// lam = lam_in(s), m_in = m_in(s) from the scan and t = e = 0 on entry:
-//     (z, y) = (clip(v), v - clip(v));  gold = -rho (z - y)            (the CURRENT x-update's linear term)
-//     x  = m0_k + PHF_k m_in + CM_k lam                                 (x_{k+1})
-//     nu = lam - QM_k x - gold^x;   u = RB_k nu - RI_k gold^u;   lam = AT_k nu      (w block k = (u, x))
-//     wh = alpha w + (1 - alpha) z;  v+ = wh + y   -> v (in place);  z+, y+, RESID partials as above
+// x = x_end(s) (the state at the segment's end), m_in = m_in(s) from the scan and t = e = 0 on entry:
+//     d  = db_k + PSB_k m_in;   u = -KB_k x - d                          (w block k = (u, x);  x = x_{k+1})
+//     x  <- AI_k x + AIB_k u                                             (x_k: backward rollout)
+//     (z, y) = (clip(v), v - clip(v));  wh = alpha w + (1 - alpha) z;  v+ = wh + y   -> v (in place);
+//     z+, y+, RESID partials as above
 //     g  = -rho (z+ - y+)
 //     p = g^x + t;  h = BT_k p + g^u;  d0_k = SI_k h -> dbuf;  t = AT_k p - KT_k h;  e += OM_k d0_k
 // and on exit t -> tseg[s], e -> eseg[s]: exactly what xb_kernel leaves for the plain scan.
 // ---------------------------------------------------------------------------
 template <int NX, int NU, bool RESID, bool RELAX>
 __global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY void xbze_kernel(
-    const double* __restrict__ mvec, const double* __restrict__ min_, const double* __restrict__ lin,
+    const double* __restrict__ dbb, const double* __restrict__ min_, const double* __restrict__ xend,
     const double* __restrict__ recBE, const int* __restrict__ seg_start_, double* __restrict__ v,
     double* __restrict__ dbuf, double* __restrict__ tseg, double* __restrict__ eseg,
     double* __restrict__ part, double alpha, double rho, int pitch, int nsplit, size_t split_stride) {
@@ -276,30 +277,30 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY void xbze_kernel(
   const unsigned PB = (unsigned)pitch * 8u;
   const RowView vv(v, (size_t)k0 * NB * P, (size_t)(k1 - k0) * NB * P * 8);
   const RowView vd(dbuf, (size_t)k0 * NU * P, (size_t)(k1 - k0) * NU * P * 8);
-  const RowView vm(mvec, (size_t)k0 * NX * P, (size_t)(k1 - k0) * NX * P * 8);
+  const RowView vm(dbb, (size_t)k0 * NU * P, (size_t)(k1 - k0) * NU * P * 8);
 #ifdef ADMM_ABLATE_REVERSE   // timing-only diagnostic: the backward sweep walks ASCENDING addresses (wrong results)
 #define SIDX(kk) (k1 - 1 - (kk))
 #else
 #define SIDX(kk) ((kk) - k0)
 #endif
-  double t[NX], e[NX], lam[NX], mi[NX];
+  double t[NX], e[NX], x[NX], mi[NX];
   {
     const size_t o = (size_t)s * NX * P + col;
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
       mi[i] = scan_row(min_, o + i * P, nsplit, split_stride);
-      lam[i] = scan_row(lin, o + i * P, nsplit, split_stride);
+      x[i] = scan_row(xend, o + i * P, nsplit, split_stride);
       t[i] = 0.0;
       e[i] = 0.0;
     }
   }
-  double lm[PF][NX], l0[PF][NB];
+  double lm[PF][NU], l0[PF][NB];
 #pragma unroll
   for (int j = 0; j < PF; ++j) {
     const int kj = (k1 - 1 - j > k0) ? k1 - 1 - j : k0;
-    const unsigned m0 = (unsigned)SIDX(kj) * NX * PB;
+    const unsigned m0 = (unsigned)SIDX(kj) * NU * PB;
 #pragma unroll
-    for (int i = 0; i < NX; ++i) lm[j][i] = vm.load<ADMM_ALT_LOAD_AUX>(lb, m0 + i * PB);
+    for (int i = 0; i < NU; ++i) lm[j][i] = vm.load<ADMM_ALT_LOAD_AUX>(lb, m0 + i * PB);
     const unsigned r0 = (unsigned)SIDX(kj) * NB * PB;
 #pragma unroll
     for (int r = 0; r < NB; ++r) l0[j][r] = vv.load<ADMM_ALT_LOAD_AUX>(lb, r0 + r * PB);
@@ -316,60 +317,40 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY void xbze_kernel(
         const int k = kb - j;
         if (k < klo) break;
         const double* rb = rec + (k - klo) * RB;
-        double c0[NB], xk[NX];
+        double c0[NB], d[NU];
 #pragma unroll
         for (int r = 0; r < NB; ++r) c0[r] = l0[j][r];
 #pragma unroll
-        for (int i = 0; i < NX; ++i) xk[i] = lm[j][i];
+        for (int jj = 0; jj < NU; ++jj) d[jj] = lm[j][jj];
         {  // refill this slot with stage k - PF (clamped: the re-read rows near the segment start
            // are overwritten by this lane only later, in program order, and the values are unused)
           const int kn = (k - PF > k0) ? k - PF : k0;
-          const unsigned m0 = (unsigned)SIDX(kn) * NX * PB;
+          const unsigned m0 = (unsigned)SIDX(kn) * NU * PB;
 #pragma unroll
-          for (int i = 0; i < NX; ++i) lm[j][i] = vm.load<ADMM_ALT_LOAD_AUX>(lb, m0 + i * PB);
+          for (int i = 0; i < NU; ++i) lm[j][i] = vm.load<ADMM_ALT_LOAD_AUX>(lb, m0 + i * PB);
           const unsigned r0 = (unsigned)SIDX(kn) * NB * PB;
 #pragma unroll
           for (int r = 0; r < NB; ++r) l0[j][r] = vv.load<ADMM_ALT_LOAD_AUX>(lb, r0 + r * PB);
         }
-        // ---- substitution: costate step of stage k ----
-        // (the old state z = clip(v), y = v - z is rebuilt twice -- here for the linear term of the
-        //  CURRENT x-update, below for the z-update -- rather than kept live across the mat-vecs:
-        //  registers are the scarce resource of this kernel)
+        // ---- substitution: feedback law and backward rollout of stage k ----
         double wv[NB];
         {
-          double nu[NX], gou[NU], uu[NU];
-          {
-            double mLO[even_up(NB)], mHI[even_up(NB)];
-            lds_block(rb + LB.LO, mLO);
-            lds_block(rb + LB.HI, mHI);
+          double uu[NU], xk[NX];
+          lds_matvec_acc<NU, NX, false, ALT_G>(rb + LB.PSB, mi, d);       // d = db + PSB m_in
 #pragma unroll
-            for (int r = 0; r < NB; ++r) {
-              const double zo = fmin(fmax(c0[r], mLO[r]), mHI[r]);
-              const double yo = c0[r] - zo;
-              if (r < NU) gou[r] = -rho * (zo - yo);
-              else nu[r - NU] = lam[r - NU] + rho * (zo - yo);    // lam - gold^x
-            }
-          }
-          __builtin_amdgcn_sched_barrier(0);
-          lds_matvec_acc<NX, NX, false, ALT_G>(rb + LB.PHF, mi, xk);     // m_{k+1} = m0 + PHF m_in
-          lds_matvec_acc<NX, NX, false, ALT_G>(rb + LB.CM, lam, xk);     // x_{k+1} = m_{k+1} + C lam
-          __builtin_amdgcn_sched_barrier(0);
-          lds_matvec_acc<NX, NX, true, ALT_G>(rb + LB.QM, xk, nu);       // nu = lam - gold^x - Qr x
-#pragma unroll
-          for (int jj = 0; jj < NU; ++jj) uu[jj] = 0.0;
-          lds_matvec_acc<NU, NX, false, ALT_G>(rb + LB.RB, nu, uu);      // u = Rr^-1 B' nu
-          lds_matvec_acc<NU, NU, true, ALT_G>(rb + LB.RI, gou, uu);      //     - Rr^-1 gold^u
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int i = 0; i < NX; ++i) lam[i] = 0.0;
-          lds_matvec_acc<NX, NX, false, ALT_G>(rb + LB.AT, nu, lam);     // lam = A' nu
+          for (int jj = 0; jj < NU; ++jj) uu[jj] = -d[jj];
+          lds_matvec_acc<NU, NX, true, ALT_G>(rb + LB.KB, x, uu);         // u = -d - KB x
 #pragma unroll
           for (int jj = 0; jj < NU; ++jj) wv[jj] = uu[jj];
 #pragma unroll
-          for (int i = 0; i < NX; ++i) wv[NU + i] = xk[i];
+          for (int i = 0; i < NX; ++i) { wv[NU + i] = x[i]; xk[i] = 0.0; }
+          __builtin_amdgcn_sched_barrier(0);
+          lds_matvec_acc<NX, NX, false, ALT_G>(rb + LB.AI, x, xk);        // x_k = AI x_{k+1}
+          lds_matvec_acc<NX, NU, false, ALT_G>(rb + LB.AIB, uu, xk);      //       + AIB u
+#pragma unroll
+          for (int i = 0; i < NX; ++i) x[i] = xk[i];
         }
         __builtin_amdgcn_sched_barrier(0);
-        asm volatile("" ::: "memory");     // the box is re-read from LDS below, not carried in registers
         // ---- z-update, dual ascent, residual partials ----
         double g[NB];
         const unsigned r0 = (unsigned)SIDX(k) * NB * PB;

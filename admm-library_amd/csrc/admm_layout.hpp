@@ -49,16 +49,17 @@ constexpr RecFLayout rec_f_layout(int n, int m) {
 
 // Records of the alternating-direction iteration.  Even iterations solve the
 // x-update by backward elimination / forward substitution (the Riccati form above), odd ones by
-// forward elimination / backward substitution (information-filter form), so that each substitution
+// forward elimination / backward substitution (its time-reversed mirror), so that each substitution
 // sweep runs in the same direction as -- and is fused with -- the next iteration's elimination.
 //
 // Forward fused record (xfze_kernel):  the forward record's blocks, then
-//   FM [n][n]  F_k   = (I - G_{k+1}) A_k                 m_{k+1} = F m_k + GA g^u + PI g^x
+//   FM [n][n]  F_k   = (I - G_{k+1}) A_k                 mu_{k+1} = F mu_k + GA g^u + PI g^x
 //   GA [n][m]  Gam_k = -(I - G_{k+1}) B_k Rr^{-1}
 //   PI [n][n]  Pi_k  = -G_{k+1} Qr_{k+1}^{-1}
-//   YU [n][m], YX [n][n]   the segment's costate summary  eps += YU g^u + YX g^x
+//   DK [m][n], DG [m][m]    db_k = DK mu_k + DG g^u        (the stored m rows of the stage)
+//   OB [n][m]  Omb_k                                       ebseg += OB db_k
 struct RecFELayout {
-  int PSI, K, A, B, FM, GA, PI, YU, YX, LO, HI, UB, SIZE;
+  int PSI, K, A, B, FM, GA, PI, DK, DG, OB, LO, HI, UB, SIZE;
 };
 constexpr RecFELayout rec_fe_layout(int n, int m) {
   RecFELayout l{};
@@ -69,9 +70,10 @@ constexpr RecFELayout rec_fe_layout(int n, int m) {
   l.FM = l.B + even_up(n * m);
   l.GA = l.FM + even_up(n * n);
   l.PI = l.GA + even_up(n * m);
-  l.YU = l.PI + even_up(n * n);
-  l.YX = l.YU + even_up(n * m);
-  l.LO = l.YX + even_up(n * n);
+  l.DK = l.PI + even_up(n * n);
+  l.DG = l.DK + even_up(m * n);
+  l.OB = l.DG + even_up(m * m);
+  l.LO = l.OB + even_up(n * m);
   l.HI = l.LO + even_up(n + m);
   l.UB = l.HI + even_up(n + m);
   l.SIZE = l.UB + 2;
@@ -79,24 +81,21 @@ constexpr RecFELayout rec_fe_layout(int n, int m) {
 }
 
 // Backward fused record (xbze_kernel):
-//   PHF [n][n]  F_k ... F_a            m_{k+1} = m0_{k+1} + PHF m_in        (a = segment start)
-//   CM  [n][n]  C_{k+1}                x_{k+1} = m_{k+1} + CM lam
-//   QM  [n][n]  Qr_{k+1}               nu      = lam - QM x_{k+1} - g^x
-//   RB  [m][n]  Rr^{-1} B_k'           u_k     = RB nu - RI g^u
-//   RI  [m][m]  Rr^{-1}
-//   AT  [n][n]  A_k'                   lam'    = AT nu        (also the elimination's A' p)
-//   BT, SI, KT, OM                      as in the backward record
+//   PSB [m][n]  Psb_k                  d    = db_k + PSB m_in
+//   KB  [m][n]  Kb_k                   u_k  = -KB x_{k+1} - d
+//   AI  [n][n]  A_k^{-1}               x_k  = AI x_{k+1} + AIB u_k
+//   AIB [n][m]  -A_k^{-1} B_k
+//   AT, BT, SI, KT, OM                  as in the backward record (the elimination half)
 struct RecBELayout {
-  int PHF, CM, QM, RB, RI, AT, BT, SI, KT, OM, LO, HI, UB, SIZE;
+  int PSB, KB, AI, AIB, AT, BT, SI, KT, OM, LO, HI, UB, SIZE;
 };
 constexpr RecBELayout rec_be_layout(int n, int m) {
   RecBELayout l{};
-  l.PHF = 0;
-  l.CM = l.PHF + even_up(n * n);
-  l.QM = l.CM + even_up(n * n);
-  l.RB = l.QM + even_up(n * n);
-  l.RI = l.RB + even_up(m * n);
-  l.AT = l.RI + even_up(m * m);
+  l.PSB = 0;
+  l.KB = l.PSB + even_up(m * n);
+  l.AI = l.KB + even_up(m * n);
+  l.AIB = l.AI + even_up(n * n);
+  l.AT = l.AIB + even_up(n * m);
   l.BT = l.AT + even_up(n * n);
   l.SI = l.BT + even_up(m * n);
   l.KT = l.SI + even_up(m * m);

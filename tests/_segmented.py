@@ -141,9 +141,9 @@ def _blocks(a, spec):
 def unpack_alt(rec, n, m):
     nb = n + m
     fe, o = _blocks(rec["recFE"], (("PSI", m, n), ("K", m, n), ("A", n, n), ("B", n, m), ("FM", n, n), ("GA", n, m),
-                                   ("PI", n, n), ("YU", n, m), ("YX", n, n)))
+                                   ("PI", n, n), ("DK", m, n), ("DG", m, m), ("OB", n, m)))
     assert o + 2 * _even(nb) + 2 == rec["recFE"].shape[1]
-    be, o = _blocks(rec["recBE"], (("PHF", n, n), ("CM", n, n), ("QM", n, n), ("RB", m, n), ("RI", m, m), ("AT", n, n),
+    be, o = _blocks(rec["recBE"], (("PSB", m, n), ("KB", m, n), ("AI", n, n), ("AIB", n, m), ("AT", n, n),
                                    ("BT", m, n), ("SI", m, m), ("KT", n, m), ("OM", n, m)))
     assert o + 2 * _even(nb) + 2 == rec["recBE"].shape[1]
     u = unpack(rec, n, m)
@@ -157,7 +157,7 @@ def unpack_alt(rec, n, m):
 
 def x_update_alt(rec, n, m, g, x0):
     """The x-update by forward elimination (segment-local), one dense scan product and backward
-    substitution.  g: (batch, L), x0: (batch, n).  Returns w (batch, L)."""
+    substitution (feedback law + backward rollout).  g: (batch, L), x0: (batch, n).  Returns w (batch, L)."""
     a = unpack_alt(rec, n, m)
     seg = rec["seg_start"]
     S = len(seg) - 1
@@ -165,15 +165,16 @@ def x_update_alt(rec, n, m, g, x0):
     nb = n + m
     batch = g.shape[0]
     gb = g.reshape(batch, N, nb)
-    mst = np.zeros((N, batch, n)); mseg = np.zeros((S, batch, n)); eseg = np.zeros((S, batch, n))
+    db = np.zeros((N, batch, m)); mseg = np.zeros((S, batch, n)); eseg = np.zeros((S, batch, n))
     for s in range(S):                                   # elimination half of xfze_kernel
-        mm = np.zeros((batch, n)); ee = np.zeros((batch, n))
+        mu = np.zeros((batch, n)); ee = np.zeros((batch, n))
         for k in range(seg[s], seg[s + 1]):
             gu, gx = gb[:, k, :m], gb[:, k, m:]
-            ee = ee + gu @ a["YU"][k].T + gx @ a["YX"][k].T
-            mm = mm @ a["FM"][k].T + gu @ a["GA"][k].T + gx @ a["PI"][k].T
-            mst[k] = mm
-        mseg[s], eseg[s] = mm, ee
+            d = mu @ a["DK"][k].T + gu @ a["DG"][k].T
+            db[k] = d
+            ee = ee + d @ a["OB"][k].T
+            mu = mu @ a["FM"][k].T + gu @ a["GA"][k].T + gx @ a["PI"][k].T
+        mseg[s], eseg[s] = mu, ee
     Wm, Mt = rec["scanWB"], rec["scanMt"]                # the scan (same kernel, other matrix)
     cin = np.zeros((Wm.shape[1], batch))
     cin[:S * n] = mseg.transpose(0, 2, 1).reshape(S * n, batch)
@@ -181,15 +182,14 @@ def x_update_alt(rec, n, m, g, x0):
     cin[S * n + n:2 * S * n + n] = eseg.transpose(0, 2, 1).reshape(S * n, batch)
     out = Wm @ cin
     min_ = out[:S * n].reshape(S, n, batch).transpose(0, 2, 1)
-    lin = out[Mt:Mt + S * n].reshape(S, n, batch).transpose(0, 2, 1)
+    xend = out[Mt:Mt + S * n].reshape(S, n, batch).transpose(0, 2, 1)
     w = np.zeros((batch, N, nb))
     for s in range(S):                                   # substitution half of xbze_kernel
-        lam = lin[s].copy()
+        x = xend[s].copy()
         for k in range(seg[s + 1] - 1, seg[s] - 1, -1):
-            x = mst[k] + min_[s] @ a["PHF"][k].T + lam @ a["CM"][k].T
-            nu = lam - x @ a["QM"][k].T - gb[:, k, m:]
-            u = nu @ a["RB"][k].T - gb[:, k, :m] @ a["RI"][k].T
-            lam = nu @ a["AT"][k].T
+            d = db[k] + min_[s] @ a["PSB"][k].T
+            u = -(x @ a["KB"][k].T) - d
             w[:, k, :m] = u
             w[:, k, m:] = x
+            x = x @ a["AI"][k].T + u @ a["AIB"][k].T
     return w.reshape(batch, N * nb)
