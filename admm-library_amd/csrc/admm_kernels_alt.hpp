@@ -29,33 +29,54 @@ namespace admm {
 #define ADMM_ALT_STORE_AUX 0
 #endif
 
-// Operand prefetch depth (stages) of the forward / backward fused kernel.
-#ifndef ADMM_ALT_PF_F
-#define ADMM_ALT_PF_F 2
+// Tuning constants of the fused kernels by block size nb = n + m (measured at (6, 3); larger blocks by
+// register fit: 0 spills / no accumulator-register traffic on the operand ring, tools/alt_sweep.sh).
+// A macro, where defined, overrides the rule (A/B sweeps).
+//   prefetch depth (stages) and LDS operand pairs read ahead of their FMAs, forward / backward kernel
+constexpr int alt_pf_f(int nb) {
+#ifdef ADMM_ALT_PF_F
+  return ADMM_ALT_PF_F;
+#else
+  return nb <= 9 ? 2 : 1;
 #endif
-#ifndef ADMM_ALT_PF_B
-#define ADMM_ALT_PF_B 1
+}
+constexpr int alt_pf_b(int nb) {
+#ifdef ADMM_ALT_PF_B
+  return ADMM_ALT_PF_B;
+#else
+  return 1;
 #endif
-// Register budget of the fused kernels: asking for two waves per SIMD caps a wave at 256 registers
-// (arch + accumulator), which keeps the whole working set in arch VGPRs.  Left at (1, 2) the
-// scheduler spends up to 512, parks the operand prefetch ring in accumulator registers and then
-// serialises every prefetch load behind an `s_waitcnt vmcnt(0)` + v_accvgpr_write (measured: 3x slower).
-#ifndef ADMM_ALT_MIN_WAVES
-#define ADMM_ALT_MIN_WAVES 2
+}
+constexpr int alt_g_f(int nb) {
+#ifdef ADMM_ALT_G_F
+  return ADMM_ALT_G_F;
+#else
+  return nb <= 9 ? 9 : 12;
 #endif
-#define ADMM_ALT_OCCUPANCY __attribute__((amdgpu_waves_per_eu(ADMM_ALT_MIN_WAVES, 2)))
+}
+constexpr int alt_g_b(int nb) {
+#ifdef ADMM_ALT_G_B
+  return ADMM_ALT_G_B;
+#else
+  return 12;
+#endif
+}
+// Register budget: asking for two waves per SIMD caps a wave at 256 registers (arch + accumulator),
+// which keeps the whole working set in arch VGPRs.  Left at (1, 2) for the small blocks the scheduler
+// spends up to 512, parks the operand prefetch ring in accumulator registers and then serialises every
+// prefetch load behind an `s_waitcnt vmcnt(0)` + v_accvgpr_write (measured: 3x slower).  Blocks above
+// 14 rows do not fit 256 registers and take the 512 budget (the ring stays in arch VGPRs there).
+constexpr int alt_min_waves(int nb) {
+#ifdef ADMM_ALT_MIN_WAVES
+  return ADMM_ALT_MIN_WAVES;
+#else
+  return nb <= 14 ? 2 : 1;
+#endif
+}
+#define ADMM_ALT_OCCUPANCY(NB_) __attribute__((amdgpu_waves_per_eu(alt_min_waves(NB_), 2)))
 
-// 16-byte operand pairs read from LDS ahead of their FMAs in the fused kernels' mat-vecs (see
-// lds_matvec_acc): smaller than the plain kernels' 24, again for registers.
-#ifndef ADMM_ALT_G_F
-#define ADMM_ALT_G_F 12
-#endif
-#ifndef ADMM_ALT_G_B
-#define ADMM_ALT_G_B 12
-#endif
-
-// the alternating kernels are compiled for the block sizes that stay in registers
-constexpr bool alt_dims(int nx, int nu) { return nx + nu <= 9; }
+// the alternating kernels are compiled for every (n, m) pair of admm_dims_g*.hip
+constexpr bool alt_dims(int nx, int nu) { return nx >= 1 && nu >= 1; }
 
 // Sum of the (<= 8) split-K slabs of one scan output row (see xf_kernel).
 __device__ __forceinline__ double scan_row(const double* base, size_t o, int nsplit, size_t split_stride) {
@@ -80,7 +101,7 @@ __device__ __forceinline__ double scan_row(const double* base, size_t o, int nsp
 // and on exit mu -> mseg[s], eb -> ebseg[s].
 // ---------------------------------------------------------------------------
 template <int NX, int NU, bool RESID, bool RELAX>
-__global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY void xfze_kernel(
+__global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY(NX + NU) void xfze_kernel(
     const double* __restrict__ dbuf, const double* __restrict__ tin, const double* __restrict__ xin,
     const double* __restrict__ recFE, const int* __restrict__ seg_start_, double* __restrict__ v,
     double* __restrict__ dbb, double* __restrict__ mseg, double* __restrict__ epsseg,
@@ -88,8 +109,8 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY void xfze_kernel(
   constexpr int NB = NX + NU;
   constexpr RecFELayout LF = rec_fe_layout(NX, NU);
   constexpr int RF = LF.SIZE;
-  constexpr int PF = ADMM_ALT_PF_F;
-  constexpr int ALT_G = ADMM_ALT_G_F;
+  constexpr int PF = alt_pf_f(NB);
+  constexpr int ALT_G = alt_g_f(NB);
   constexpr int CH = stage_chunk(RF, PF);
   __shared__ __attribute__((aligned(16))) double rec[CH * RF];
 
@@ -253,7 +274,7 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY void xfze_kernel(
 // and on exit t -> tseg[s], e -> eseg[s]: exactly what xb_kernel leaves for the plain scan.
 // ---------------------------------------------------------------------------
 template <int NX, int NU, bool RESID, bool RELAX>
-__global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY void xbze_kernel(
+__global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY(NX + NU) void xbze_kernel(
     const double* __restrict__ dbb, const double* __restrict__ min_, const double* __restrict__ xend,
     const double* __restrict__ recBE, const int* __restrict__ seg_start_, double* __restrict__ v,
     double* __restrict__ dbuf, double* __restrict__ tseg, double* __restrict__ eseg,
@@ -261,8 +282,8 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY void xbze_kernel(
   constexpr int NB = NX + NU;
   constexpr RecBELayout LB = rec_be_layout(NX, NU);
   constexpr int RB = LB.SIZE;
-  constexpr int PF = ADMM_ALT_PF_B;
-  constexpr int ALT_G = ADMM_ALT_G_B;
+  constexpr int PF = alt_pf_b(NB);
+  constexpr int ALT_G = alt_g_b(NB);
   constexpr int CH = stage_chunk(RB, PF);
   __shared__ __attribute__((aligned(16))) double rec[CH * RB];
 

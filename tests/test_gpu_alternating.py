@@ -1,7 +1,7 @@
 """GPU tests of the alternating-direction iteration (xfze_kernel / xbze_kernel):
 consecutive iterations solve the x-update in opposite elimination orders so that each
 substitution sweep is fused with the next elimination sweep.  It is the default iteration where
-compiled (n + m <= 9, no q, no thrust-magnitude bound); ADMM_FLAG_NO_ALTERNATE (8) selects the
+compiled (no q, no thrust-magnitude bound); ADMM_FLAG_NO_ALTERNATE (8) selects the
 plain xb + xfz kernels.  Checked against the C oracle (PARITY UNPINNED, see test_gpu_parity.py)
 and against the plain path, tolerance 1e-10 on O(1) iterates."""
 import numpy as np
@@ -28,6 +28,13 @@ ALT_CASES = [
     (lambda: pkg.random_ltv(N=1, n=4, m=2, batch=3, seed=18, with_q=False), 0.3, 0),
     (lambda: pkg.random_ltv(N=2, n=6, m=3, batch=2, seed=19, with_q=False), 0.3, 0),
     (lambda: pkg.random_ltv(N=90, n=5, m=3, batch=10, seed=21, with_q=False), 0.3, 2),  # several LDS refills per segment
+    # larger blocks (other prefetch depth / register budget rules, admm_kernels_alt.hpp)
+    (lambda: pkg.random_ltv(N=30, n=8, m=4, batch=64, seed=10, with_q=False), 0.2, 3),
+    (lambda: pkg.random_ltv(N=20, n=9, m=3, batch=5, seed=54, with_q=False), 0.3, 2),
+    (lambda: pkg.random_ltv(N=20, n=10, m=4, batch=5, seed=55, with_q=False), 0.3, 2),
+    (lambda: pkg.random_ltv(N=40, n=12, m=3, batch=4, seed=16, with_q=False), 0.2, 3),
+    (lambda: pkg.random_ltv(N=40, n=12, m=6, batch=3, seed=17, with_q=False), 0.4, 2),
+    (lambda: pkg.cw_formation(N=120, batch=66), 0.05, 0),
 ]
 
 
