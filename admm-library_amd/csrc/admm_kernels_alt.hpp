@@ -12,8 +12,8 @@
 //     xfze_kernel  (forward):   rollout (as xfz_kernel) | z-update | forward elimination of v+
 //     xbze_kernel  (backward):  backward rollout        | z-update | backward elimination of v+
 // One kernel + one scan per iteration.  Algorithmic HBM bytes per stacked element (n = 6, m = 3):
-//     xfze: d read 2.67 + v read 8 + v+ written 8 + db written 2.67 = 21.33
-//     xbze: db read 2.67 + v read 8 + v+ written 8 + d written 2.67 = 21.33
+//     xfze: d read 2.67 + v read 8 + v+ written 8 + db written 2.67 = 21.33   (+8 with a linear term q)
+//     xbze: db read 2.67 + v read 8 + v+ written 8 + d written 2.67 = 21.33   (+8 with q)
 // against 29.33 for xb + xfz (each elimination leaves only its m-row feed-forward term per stage).  Same layout, staging and addressing as admm_kernels.hpp.
 #pragma once
 
@@ -33,11 +33,11 @@ namespace admm {
 // register fit: 0 spills / no accumulator-register traffic on the operand ring, tools/alt_sweep.sh).
 // A macro, where defined, overrides the rule (A/B sweeps).
 //   prefetch depth (stages) and LDS operand pairs read ahead of their FMAs, forward / backward kernel
-constexpr int alt_pf_f(int nb) {
+constexpr int alt_pf_f(int nb, bool hasq) {
 #ifdef ADMM_ALT_PF_F
   return ADMM_ALT_PF_F;
 #else
-  return nb <= 9 ? 2 : 1;
+  return (nb <= 9 && !hasq) ? 2 : 1;        // the q rows ride in the ring too
 #endif
 }
 constexpr int alt_pf_b(int nb) {
@@ -65,15 +65,15 @@ constexpr int alt_g_b(int nb) {
 // which keeps the whole working set in arch VGPRs.  Left at (1, 2) for the small blocks the scheduler
 // spends up to 512, parks the operand prefetch ring in accumulator registers and then serialises every
 // prefetch load behind an `s_waitcnt vmcnt(0)` + v_accvgpr_write (measured: 3x slower).  Blocks above
-// 14 rows do not fit 256 registers and take the 512 budget (the ring stays in arch VGPRs there).
-constexpr int alt_min_waves(int nb) {
+// 14 rows (9 with q) do not fit 256 registers and take the 512 budget (the ring stays in arch VGPRs there).
+constexpr int alt_min_waves(int nb, bool hasq) {
 #ifdef ADMM_ALT_MIN_WAVES
   return ADMM_ALT_MIN_WAVES;
 #else
-  return nb <= 14 ? 2 : 1;
+  return nb <= (hasq ? 9 : 14) ? 2 : 1;     // the q rows cost 2 nb registers per ring slot plus 2 nb live
 #endif
 }
-#define ADMM_ALT_OCCUPANCY(NB_) __attribute__((amdgpu_waves_per_eu(alt_min_waves(NB_), 2)))
+#define ADMM_ALT_OCCUPANCY(NB_, HQ_) __attribute__((amdgpu_waves_per_eu(alt_min_waves(NB_, HQ_), 2)))
 
 // the alternating kernels are compiled for every (n, m) pair of admm_dims_g*.hip
 constexpr bool alt_dims(int nx, int nu) { return nx >= 1 && nu >= 1; }
@@ -94,22 +94,23 @@ __device__ __forceinline__ double scan_row(const double* base, size_t o, int nsp
 //     d  = d0_k + Psi_k t_in;  u = -K_k x - d;  x = A_k x + B_k u         (w block k = (u, x))
 //     (z, y) = (clip(v), v - clip(v));  wh = alpha w + (1 - alpha) z;  v+ = wh + y   -> v (in place)
 //     z+ = clip(v+), y+ = v+ - z+;  RESID: the five per-QP partial sums           -> part
-//     g  = -rho (z+ - y+)                                 (linear term of the NEXT x-update)
+//     g  = q - rho (z+ - y+)                              (linear term of the NEXT x-update; q if HASQ)
 //     db  = DK_k mu + DG_k g^u                            (mu = 0 on entry)        -> dbb block k (m rows)
 //     eb += OB_k db
 //     mu  = FM_k mu + GA_k g^u + PI_k g^x
 // and on exit mu -> mseg[s], eb -> ebseg[s].
 // ---------------------------------------------------------------------------
-template <int NX, int NU, bool RESID, bool RELAX>
-__global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY(NX + NU) void xfze_kernel(
+template <int NX, int NU, bool RESID, bool RELAX, bool HASQ>
+__global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY(NX + NU, HASQ) void xfze_kernel(
     const double* __restrict__ dbuf, const double* __restrict__ tin, const double* __restrict__ xin,
-    const double* __restrict__ recFE, const int* __restrict__ seg_start_, double* __restrict__ v,
+    const double* __restrict__ recFE, const int* __restrict__ seg_start_, const double* __restrict__ q,
+    double* __restrict__ v,
     double* __restrict__ dbb, double* __restrict__ mseg, double* __restrict__ epsseg,
     double* __restrict__ part, double alpha, double rho, int pitch, int nsplit, size_t split_stride) {
   constexpr int NB = NX + NU;
   constexpr RecFELayout LF = rec_fe_layout(NX, NU);
   constexpr int RF = LF.SIZE;
-  constexpr int PF = alt_pf_f(NB);
+  constexpr int PF = alt_pf_f(NB, HASQ);
   constexpr int ALT_G = alt_g_f(NB);
   constexpr int CH = stage_chunk(RF, PF);
   __shared__ __attribute__((aligned(16))) double rec[CH * RF];
@@ -126,6 +127,7 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY(NX + NU) void xfze_k
   const RowView vv(v, (size_t)k0 * NB * P, (size_t)(k1 - k0) * NB * P * 8);
   const RowView vd(dbuf, (size_t)k0 * NU * P, (size_t)(k1 - k0) * NU * P * 8);
   const RowView vm(dbb, (size_t)k0 * NU * P, (size_t)(k1 - k0) * NU * P * 8);
+  const RowView vq(HASQ ? q : v, (size_t)k0 * NB * P, (size_t)(k1 - k0) * NB * P * 8);
   double t[NX], x[NX], mu[NX], eps[NX];
   {
     const size_t o = (size_t)s * NX * P + col;
@@ -137,7 +139,7 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY(NX + NU) void xfze_k
       eps[i] = 0.0;
     }
   }
-  double ld[PF][NU], l0[PF][NB];
+  double ld[PF][NU], l0[PF][NB], lq[PF][NB];
 #pragma unroll
   for (int j = 0; j < PF; ++j) {
     const int kj = (k0 + j < k1) ? k0 + j : k1 - 1;
@@ -146,7 +148,10 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY(NX + NU) void xfze_k
     for (int jj = 0; jj < NU; ++jj) ld[j][jj] = vd.load<ADMM_ALT_LOAD_AUX>(lb, d0 + jj * PB);
     const unsigned r0 = (unsigned)(kj - k0) * NB * PB;
 #pragma unroll
-    for (int r = 0; r < NB; ++r) l0[j][r] = vv.load<ADMM_ALT_LOAD_AUX>(lb, r0 + r * PB);
+    for (int r = 0; r < NB; ++r) {
+      l0[j][r] = vv.load<ADMM_ALT_LOAD_AUX>(lb, r0 + r * PB);
+      if (HASQ) lq[j][r] = vq.load<ADMM_ALT_LOAD_AUX>(lb, r0 + r * PB);
+    }
   }
   double a_r = 0, a_s = 0, a_w = 0, a_z = 0, a_y = 0;
   for (int kc = k0; kc < k1; kc += CH) {
@@ -160,11 +165,14 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY(NX + NU) void xfze_k
         const int k = kb + j;
         if (k > khi) break;
         const double* rf = rec + (k - kc) * RF;
-        double d[NU], c0[NB];
+        double d[NU], c0[NB], cq[NB];
 #pragma unroll
         for (int jj = 0; jj < NU; ++jj) d[jj] = ld[j][jj];
 #pragma unroll
-        for (int r = 0; r < NB; ++r) c0[r] = l0[j][r];
+        for (int r = 0; r < NB; ++r) {
+          c0[r] = l0[j][r];
+          if (HASQ) cq[r] = lq[j][r];
+        }
         {  // refill this slot with stage k + PF (clamped; see xfz_kernel)
           const int kn = (k + PF < k1) ? k + PF : k1 - 1;
           const unsigned d0 = (unsigned)(kn - k0) * NU * PB;
@@ -172,7 +180,10 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY(NX + NU) void xfze_k
           for (int jj = 0; jj < NU; ++jj) ld[j][jj] = vd.load<ADMM_ALT_LOAD_AUX>(lb, d0 + jj * PB);
           const unsigned r0 = (unsigned)(kn - k0) * NB * PB;
 #pragma unroll
-          for (int r = 0; r < NB; ++r) l0[j][r] = vv.load<ADMM_ALT_LOAD_AUX>(lb, r0 + r * PB);
+          for (int r = 0; r < NB; ++r) {
+            l0[j][r] = vv.load<ADMM_ALT_LOAD_AUX>(lb, r0 + r * PB);
+            if (HASQ) lq[j][r] = vq.load<ADMM_ALT_LOAD_AUX>(lb, r0 + r * PB);
+          }
         }
         // ---- substitution: rollout of stage k ----
         double wv[NB];
@@ -209,6 +220,7 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY(NX + NU) void xfze_k
           const double zn = fmin(fmax(vn, mLO[r]), mHI[r]);
           const double yn = vn - zn;
           g[r] = -rho * (zn - yn);
+          if (HASQ) g[r] += cq[r];
           if (RESID) {
             const double dr = wv[r] - zn, ds = zn - zo;
             a_r = fma(dr, dr, a_r);
@@ -273,10 +285,11 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY(NX + NU) void xfze_k
 //     p = g^x + t;  h = BT_k p + g^u;  d0_k = SI_k h -> dbuf;  t = AT_k p - KT_k h;  e += OM_k d0_k
 // and on exit t -> tseg[s], e -> eseg[s]: exactly what xb_kernel leaves for the plain scan.
 // ---------------------------------------------------------------------------
-template <int NX, int NU, bool RESID, bool RELAX>
-__global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY(NX + NU) void xbze_kernel(
+template <int NX, int NU, bool RESID, bool RELAX, bool HASQ>
+__global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY(NX + NU, HASQ) void xbze_kernel(
     const double* __restrict__ dbb, const double* __restrict__ min_, const double* __restrict__ xend,
-    const double* __restrict__ recBE, const int* __restrict__ seg_start_, double* __restrict__ v,
+    const double* __restrict__ recBE, const int* __restrict__ seg_start_, const double* __restrict__ q,
+    double* __restrict__ v,
     double* __restrict__ dbuf, double* __restrict__ tseg, double* __restrict__ eseg,
     double* __restrict__ part, double alpha, double rho, int pitch, int nsplit, size_t split_stride) {
   constexpr int NB = NX + NU;
@@ -299,6 +312,7 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY(NX + NU) void xbze_k
   const RowView vv(v, (size_t)k0 * NB * P, (size_t)(k1 - k0) * NB * P * 8);
   const RowView vd(dbuf, (size_t)k0 * NU * P, (size_t)(k1 - k0) * NU * P * 8);
   const RowView vm(dbb, (size_t)k0 * NU * P, (size_t)(k1 - k0) * NU * P * 8);
+  const RowView vq(HASQ ? q : v, (size_t)k0 * NB * P, (size_t)(k1 - k0) * NB * P * 8);
 #ifdef ADMM_ABLATE_REVERSE   // timing-only diagnostic: the backward sweep walks ASCENDING addresses (wrong results)
 #define SIDX(kk) (k1 - 1 - (kk))
 #else
@@ -315,7 +329,7 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY(NX + NU) void xbze_k
       e[i] = 0.0;
     }
   }
-  double lm[PF][NU], l0[PF][NB];
+  double lm[PF][NU], l0[PF][NB], lq[PF][NB];
 #pragma unroll
   for (int j = 0; j < PF; ++j) {
     const int kj = (k1 - 1 - j > k0) ? k1 - 1 - j : k0;
@@ -324,7 +338,10 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY(NX + NU) void xbze_k
     for (int i = 0; i < NU; ++i) lm[j][i] = vm.load<ADMM_ALT_LOAD_AUX>(lb, m0 + i * PB);
     const unsigned r0 = (unsigned)SIDX(kj) * NB * PB;
 #pragma unroll
-    for (int r = 0; r < NB; ++r) l0[j][r] = vv.load<ADMM_ALT_LOAD_AUX>(lb, r0 + r * PB);
+    for (int r = 0; r < NB; ++r) {
+      l0[j][r] = vv.load<ADMM_ALT_LOAD_AUX>(lb, r0 + r * PB);
+      if (HASQ) lq[j][r] = vq.load<ADMM_ALT_LOAD_AUX>(lb, r0 + r * PB);
+    }
   }
   double a_r = 0, a_s = 0, a_w = 0, a_z = 0, a_y = 0;
   for (int kc = k1 - 1; kc >= k0; kc -= CH) {
@@ -338,9 +355,12 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY(NX + NU) void xbze_k
         const int k = kb - j;
         if (k < klo) break;
         const double* rb = rec + (k - klo) * RB;
-        double c0[NB], d[NU];
+        double c0[NB], d[NU], cq[NB];
 #pragma unroll
-        for (int r = 0; r < NB; ++r) c0[r] = l0[j][r];
+        for (int r = 0; r < NB; ++r) {
+          c0[r] = l0[j][r];
+          if (HASQ) cq[r] = lq[j][r];
+        }
 #pragma unroll
         for (int jj = 0; jj < NU; ++jj) d[jj] = lm[j][jj];
         {  // refill this slot with stage k - PF (clamped: the re-read rows near the segment start
@@ -351,7 +371,10 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY(NX + NU) void xbze_k
           for (int i = 0; i < NU; ++i) lm[j][i] = vm.load<ADMM_ALT_LOAD_AUX>(lb, m0 + i * PB);
           const unsigned r0 = (unsigned)SIDX(kn) * NB * PB;
 #pragma unroll
-          for (int r = 0; r < NB; ++r) l0[j][r] = vv.load<ADMM_ALT_LOAD_AUX>(lb, r0 + r * PB);
+          for (int r = 0; r < NB; ++r) {
+            l0[j][r] = vv.load<ADMM_ALT_LOAD_AUX>(lb, r0 + r * PB);
+            if (HASQ) lq[j][r] = vq.load<ADMM_ALT_LOAD_AUX>(lb, r0 + r * PB);
+          }
         }
         // ---- substitution: feedback law and backward rollout of stage k ----
         double wv[NB];
@@ -389,6 +412,7 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY(NX + NU) void xbze_k
             const double zn = fmin(fmax(vn, lo), hi);
             const double yn = vn - zn;
             g[r] = -rho * (zn - yn);
+            if (HASQ) g[r] += cq[r];
             if (RESID) {
               const double dr = wv[r] - zn, ds = zn - zo;
               a_r = fma(dr, dr, a_r);

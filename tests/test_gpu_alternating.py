@@ -35,6 +35,11 @@ ALT_CASES = [
     (lambda: pkg.random_ltv(N=40, n=12, m=3, batch=4, seed=16, with_q=False), 0.2, 3),
     (lambda: pkg.random_ltv(N=40, n=12, m=6, batch=3, seed=17, with_q=False), 0.4, 2),
     (lambda: pkg.cw_formation(N=120, batch=66), 0.05, 0),
+    # with a linear term q (per-stage bounds, full weights): the HASQ kernel forms
+    (lambda: pkg.random_ltv(N=37, n=6, m=3, batch=70, seed=2), 0.3, 5),
+    (lambda: pkg.random_ltv(N=30, n=4, m=2, batch=130, seed=22), 0.3, 4),
+    (lambda: pkg.random_ltv(N=20, n=10, m=4, batch=5, seed=55), 0.3, 2),
+    (lambda: pkg.random_ltv(N=24, n=12, m=6, batch=3, seed=6), 0.4, 4),
 ]
 
 
@@ -59,7 +64,7 @@ def test_alternating_iterates_match_oracle(gpu, idx):
 
 def test_alternating_is_enabled_and_optional(gpu):
     """The alternating kernels run by default for the headline shape and can be switched off;
-    with q (or a thrust-magnitude bound) the handle falls back to the plain kernels."""
+    with a thrust-magnitude bound the handle falls back to the plain kernels."""
     p = pkg.cw_rendezvous(N=100, batch=66)
     with pkg.Solver(p, pkg.Options(rho=0.05)) as s:
         pr = s.profile(2, residuals=True, alternating=True)
@@ -67,11 +72,10 @@ def test_alternating_is_enabled_and_optional(gpu):
     with pkg.Solver(p, pkg.Options(rho=0.05, flags=NO_ALT)) as s:
         with pytest.raises(pkg.AdmmError):
             s.profile(2, alternating=True)
-    pq = pkg.random_ltv(N=20, n=4, m=2, batch=5, seed=3)          # has q
+    pq = pkg.random_ltv(N=20, n=4, m=2, batch=5, seed=3)          # a linear term q rides along (HASQ kernel forms)
     assert pq.q is not None
     with pkg.Solver(pq, pkg.Options(rho=0.3)) as s:
-        with pytest.raises(pkg.AdmmError):
-            s.profile(2, alternating=True)
+        assert s.profile(2, alternating=True)["xbze_ms"] > 0
     ps = pkg.cw_rendezvous(N=60, batch=5, thrust_norm=True)
     with pkg.Solver(ps, pkg.Options(rho=0.05)) as s:
         with pytest.raises(pkg.AdmmError):
