@@ -665,7 +665,7 @@ int admm_setup(admm_handle** out, const admm_problem* p, const admm_options* o_i
     TRY_RELEASE(dalloc(&h->scan_range, h->fac.scanRange.size()));
   }
   // alternating-direction iteration: compiled for this (n, m), buildable for this problem, not disabled
-  h->alt = h->fac.alt_ok && !h->has_soc && fused(h) &&
+  h->alt = h->fac.alt_ok && fused(h) &&
            !(h->opt.flags & (ADMM_FLAG_SCAN_CHAIN | ADMM_FLAG_NO_ALTERNATE)) &&
            dispatch_x(xlaunch_of(h), admm::XKernel::XFZE, false, false, /*query_only=*/true);
   if (h->alt) {

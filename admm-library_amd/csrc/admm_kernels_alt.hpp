@@ -100,7 +100,7 @@ __device__ __forceinline__ double scan_row(const double* base, size_t o, int nsp
 //     mu  = FM_k mu + GA_k g^u + PI_k g^x
 // and on exit mu -> mseg[s], eb -> ebseg[s].
 // ---------------------------------------------------------------------------
-template <int NX, int NU, bool RESID, bool RELAX, bool HASQ>
+template <int NX, int NU, bool RESID, bool RELAX, bool HASQ, bool SOC>
 __global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY(NX + NU, HASQ) void xfze_kernel(
     const double* __restrict__ dbuf, const double* __restrict__ tin, const double* __restrict__ xin,
     const double* __restrict__ recFE, const int* __restrict__ seg_start_, const double* __restrict__ q,
@@ -209,15 +209,36 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY(NX + NU, HASQ) void 
         lds_block(rf + LF.LO, mLO);
         lds_block(rf + LF.HI, mHI);
         const unsigned r0 = (unsigned)(k - k0) * NB * PB;
+        // thrust-magnitude bound on this stage's control rows (SOC forms only): the two
+        // ball-projection factors, of the old state and of v+ (soc is wave-uniform)
+        double cs_old = 1.0, cs_new = 1.0;
+        bool soc = false;
+        if (SOC) {
+          const double ub = rf[LF.UB];
+          soc = ub < INFINITY;
+          if (soc) {
+            cs_old = soc_scale<NU, NB>(c0, ub);
+            double vnu[NB];
+#pragma unroll
+            for (int r = 0; r < NB; ++r) {
+              const double zo = c0[r] * cs_old, yo = c0[r] - zo;
+              double wh = wv[r];
+              if (RELAX) wh = fma(alpha, wv[r], (1.0 - alpha) * zo);
+              vnu[r] = r < NU ? wh + yo : 0.0;
+            }
+            cs_new = soc_scale<NU, NB>(vnu, ub);
+          }
+        }
 #pragma unroll
         for (int r = 0; r < NB; ++r) {
-          const double zo = fmin(fmax(c0[r], mLO[r]), mHI[r]);
+          const bool ball = SOC && soc && r < NU;
+          const double zo = ball ? c0[r] * cs_old : fmin(fmax(c0[r], mLO[r]), mHI[r]);
           const double yo = c0[r] - zo;
           double wh = wv[r];
           if (RELAX) wh = fma(alpha, wv[r], (1.0 - alpha) * zo);
           const double vn = wh + yo;
           vv.store<ADMM_ALT_STORE_AUX>(vn, lb_st, r0 + r * PB);
-          const double zn = fmin(fmax(vn, mLO[r]), mHI[r]);
+          const double zn = ball ? vn * cs_new : fmin(fmax(vn, mLO[r]), mHI[r]);
           const double yn = vn - zn;
           g[r] = -rho * (zn - yn);
           if (HASQ) g[r] += cq[r];
@@ -285,7 +306,7 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY(NX + NU, HASQ) void 
 //     p = g^x + t;  h = BT_k p + g^u;  d0_k = SI_k h -> dbuf;  t = AT_k p - KT_k h;  e += OM_k d0_k
 // and on exit t -> tseg[s], e -> eseg[s]: exactly what xb_kernel leaves for the plain scan.
 // ---------------------------------------------------------------------------
-template <int NX, int NU, bool RESID, bool RELAX, bool HASQ>
+template <int NX, int NU, bool RESID, bool RELAX, bool HASQ, bool SOC>
 __global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY(NX + NU, HASQ) void xbze_kernel(
     const double* __restrict__ dbb, const double* __restrict__ min_, const double* __restrict__ xend,
     const double* __restrict__ recBE, const int* __restrict__ seg_start_, const double* __restrict__ q,
@@ -398,18 +419,37 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY(NX + NU, HASQ) void 
         // ---- z-update, dual ascent, residual partials ----
         double g[NB];
         const unsigned r0 = (unsigned)SIDX(k) * NB * PB;
+        double cs_old = 1.0, cs_new = 1.0;     // thrust-magnitude bound (see xfze_kernel)
+        bool soc = false;
+        if (SOC) {
+          const double ub = rb[LB.UB];
+          soc = ub < INFINITY;
+          if (soc) {
+            cs_old = soc_scale<NU, NB>(c0, ub);
+            double vnu[NB];
+#pragma unroll
+            for (int r = 0; r < NB; ++r) {
+              const double zo = c0[r] * cs_old, yo = c0[r] - zo;
+              double wh = wv[r];
+              if (RELAX) wh = fma(alpha, wv[r], (1.0 - alpha) * zo);
+              vnu[r] = r < NU ? wh + yo : 0.0;
+            }
+            cs_new = soc_scale<NU, NB>(vnu, ub);
+          }
+        }
 #pragma unroll
         for (int r3 = 0; r3 < NB; r3 += 3) {
 #pragma unroll
           for (int r = r3; r < r3 + 3 && r < NB; ++r) {
+            const bool ball = SOC && soc && r < NU;
             const double lo = rb[LB.LO + r], hi = rb[LB.HI + r];
-            const double zo = fmin(fmax(c0[r], lo), hi);
+            const double zo = ball ? c0[r] * cs_old : fmin(fmax(c0[r], lo), hi);
             const double yo = c0[r] - zo;
             double wh = wv[r];
             if (RELAX) wh = fma(alpha, wv[r], (1.0 - alpha) * zo);
             const double vn = wh + yo;
             vv.store<ADMM_ALT_STORE_AUX>(vn, lb_st, r0 + r * PB);
-            const double zn = fmin(fmax(vn, lo), hi);
+            const double zn = ball ? vn * cs_new : fmin(fmax(vn, lo), hi);
             const double yn = vn - zn;
             g[r] = -rho * (zn - yn);
             if (HASQ) g[r] += cq[r];

@@ -105,7 +105,7 @@ typedef struct admm_options {
                                   every iteration) instead of the fused xfz kernel */
 
 #define ADMM_FLAG_NO_ALTERNATE 8 /* always eliminate backward / substitute forward (xb + xfz kernels); by
-                                  default (unless a thrust-magnitude bound is set or the forward form fails its host check),
+                                  default (unless the forward form fails its host check for the problem),
                                   consecutive iterations alternate the elimination direction so that each
                                   substitution sweep is fused with the next elimination sweep */
 

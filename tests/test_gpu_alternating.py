@@ -1,7 +1,7 @@
 """GPU tests of the alternating-direction iteration (xfze_kernel / xbze_kernel):
 consecutive iterations solve the x-update in opposite elimination orders so that each
 substitution sweep is fused with the next elimination sweep.  It is the default iteration where
-compiled (no q, no thrust-magnitude bound); ADMM_FLAG_NO_ALTERNATE (8) selects the
+the forward form passes its host check (practically always); ADMM_FLAG_NO_ALTERNATE (8) selects the
 plain xb + xfz kernels.  Checked against the C oracle (PARITY UNPINNED, see test_gpu_parity.py)
 and against the plain path, tolerance 1e-10 on O(1) iterates."""
 import numpy as np
@@ -40,6 +40,10 @@ ALT_CASES = [
     (lambda: pkg.random_ltv(N=30, n=4, m=2, batch=130, seed=22), 0.3, 4),
     (lambda: pkg.random_ltv(N=20, n=10, m=4, batch=5, seed=55), 0.3, 2),
     (lambda: pkg.random_ltv(N=24, n=12, m=6, batch=3, seed=6), 0.4, 4),
+    # thrust-magnitude (second-order-cone) bound on the control rows: the SOC kernel forms
+    (lambda: pkg.cw_rendezvous(N=200, batch=70, thrust_norm=True), 0.05, 4),
+    (lambda: pkg.random_ltv(N=37, n=6, m=3, batch=9, seed=31, thrust_norm=True), 0.3, 5),
+    (lambda: pkg.random_ltv(N=20, n=4, m=2, batch=5, seed=32, thrust_norm=True, with_q=False), 0.3, 3),
 ]
 
 
@@ -64,7 +68,7 @@ def test_alternating_iterates_match_oracle(gpu, idx):
 
 def test_alternating_is_enabled_and_optional(gpu):
     """The alternating kernels run by default for the headline shape and can be switched off;
-    with a thrust-magnitude bound the handle falls back to the plain kernels."""
+    a linear term or a thrust-magnitude bound selects the HASQ / SOC kernel forms."""
     p = pkg.cw_rendezvous(N=100, batch=66)
     with pkg.Solver(p, pkg.Options(rho=0.05)) as s:
         pr = s.profile(2, residuals=True, alternating=True)
@@ -76,10 +80,9 @@ def test_alternating_is_enabled_and_optional(gpu):
     assert pq.q is not None
     with pkg.Solver(pq, pkg.Options(rho=0.3)) as s:
         assert s.profile(2, alternating=True)["xbze_ms"] > 0
-    ps = pkg.cw_rendezvous(N=60, batch=5, thrust_norm=True)
+    ps = pkg.cw_rendezvous(N=60, batch=5, thrust_norm=True)       # thrust-magnitude bound: SOC kernel forms
     with pkg.Solver(ps, pkg.Options(rho=0.05)) as s:
-        with pytest.raises(pkg.AdmmError):
-            s.profile(2, alternating=True)
+        assert s.profile(2, alternating=True)["xfze_ms"] > 0
 
 
 @pytest.mark.parametrize("alpha", [1.0, 1.6])
