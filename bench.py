@@ -22,9 +22,9 @@ same steps with ADMM_FLAG_NO_ALTERNATE: xb + xscan + xfz + finalise.)
 
 Extra objects on the JSON line:
   roofline     -- the dominant kernels, the pair xfze<RESID> / xbze<RESID>: each
-                  moves 8 m/(n+m) + 16 + 8 n/(n+m) = 24 B per stacked element
-                  (d, v read and v+, m written, resp. m, v read and v+, d written;
-                  fp64, state in v-form, DESIGN.md §4.5) x L x pitch per launch;
+                  moves 16 + 16 m/(n+m) = 21.33 B per stacked element (d, v read
+                  and v+, db written, resp. db, v read and v+, d written; fp64,
+                  state in v-form, DESIGN.md §4.5) x L x pitch per launch;
                   achieved = the pair's bytes / the pair's average launch
                   durations, measured with HIP events on the library's own stream
                   (admm_profile).  `per_kernel` holds each kernel's own figures.
@@ -206,13 +206,12 @@ def main():
                                    "plain path: forward rollout fused with z-update + dual ascent + residual partials, "
                                    "state in v-form", b_xfz, xfz_ms, "xfz_kernel<6, 3, true, false, true")
     if prof_alt is not None:
-        b_alt = 16.0 + 8.0 * m_ / (n_ + m_) + 8.0 * n_ / (n_ + m_)     # v, v+ and the d / m rows
-        rf = kernel_roofline(f"xfze_kernel<{n_},{m_},RESID=true,RELAX=false>",
+        b_alt = 16.0 + 16.0 * m_ / (n_ + m_) + (8.0 if full.q is not None else 0.0)   # v, v+, d and db rows (+ q)
+        rf = kernel_roofline(f"xfze_kernel<{n_},{m_},RESID=true,RELAX=false,HASQ=false,SOC=false>",
                              "forward rollout + z-update + dual ascent + residual partials + forward elimination of v+",
-                             b_alt, prof_alt["xfze_ms"], "xfze_kernel<6, 3, true, false>")
-        rb = kernel_roofline(f"xbze_kernel<{n_},{m_},RESID=true,RELAX=false>",
-                             "backward costate substitution + z-update + dual ascent + residual partials + backward "
-                             "elimination of v+", b_alt, prof_alt["xbze_ms"], "xbze_kernel<6, 3, true, false>")
+                             b_alt, prof_alt["xfze_ms"], "xfze_kernel<6, 3, true, false, false, false>")
+        rb = kernel_roofline(f"xbze_kernel<{n_},{m_},RESID=true,RELAX=false,HASQ=false,SOC=false>",
+                             "backward rollout + z-update + dual ascent + residual partials + backward elimination of v+", b_alt, prof_alt["xbze_ms"], "xbze_kernel<6, 3, true, false, false, false>")
         pair_ms = prof_alt["xfze_ms"] + prof_alt["xbze_ms"]
         ach = 2 * b_alt * elems / (pair_ms * 1e-3) / 1e9
         roofline = {"kernel": f"xfze_kernel / xbze_kernel <{n_},{m_},RESID=true,RELAX=false> (the alternating pair: one of them "
@@ -235,7 +234,7 @@ def main():
     b_xb = 8.0 + 8.0 * m_ / (n_ + m_)             # v read + d written
     xb_gbs = b_xb * elems / (prof["xb_ms"] * 1e-3) / 1e9
     # algorithmic HBM bytes per element per iteration of the timed path
-    b_iter = (16.0 + 8.0 * m_ / (n_ + m_) + 8.0 * n_ / (n_ + m_)) if prof_alt is not None else b_xb + b_xfz
+    b_iter = (16.0 + 16.0 * m_ / (n_ + m_) + (8.0 if full.q is not None else 0.0)) if prof_alt is not None else b_xb + b_xfz
 
     # the same steps on the plain fused path (xb + xscan + xfz + finalise), for the A/B in DESIGN.md §4.8
     plain_path = None
