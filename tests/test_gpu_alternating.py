@@ -85,6 +85,21 @@ def test_alternating_is_enabled_and_optional(gpu):
         assert s.profile(2, alternating=True)["xfze_ms"] > 0
 
 
+def test_falls_back_to_the_plain_kernels_when_the_forward_form_is_unavailable(gpu):
+    """Singular A_k: admm_setup leaves the alternating kernels off; the iteration is the plain one."""
+    p = pkg.random_ltv(N=12, n=3, m=2, batch=5, seed=77, with_q=False)
+    A = np.array(p.A)
+    A[5] = np.diag([1.0, 0.0, 0.5])
+    p = pkg.Problem(N=p.N, A=A, B=p.B, Q=p.Q, R=p.R, QN=p.QN, x0=p.x0, lo=p.lo, hi=p.hi)
+    with pkg.Solver(p, pkg.Options(rho=0.3, segments=3)) as s:
+        with pytest.raises(pkg.AdmmError):
+            s.profile(1, alternating=True)
+        s.iterate(9)
+        w, z, y = s.get()
+    ref = oc.solve(p, rho=0.3, max_iter=9, stop=False)
+    assert _close(w, ref["w"]) and _close(z, ref["z"]) and _close(y, ref["y"])
+
+
 @pytest.mark.parametrize("alpha", [1.0, 1.6])
 def test_call_patterns_and_residuals(gpu, alpha):
     """State carried across calls of every length and parity, read-outs in between (w is

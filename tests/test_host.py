@@ -137,6 +137,20 @@ def test_alternating_form_reproduces_sequential_sweep(lib, make, rho, segs):
     assert np.abs(w_ref - w_alt).max() <= 1e-11 * max(1.0, np.abs(w_ref).max())
 
 
+def test_alternating_form_is_refused_when_it_cannot_be_built(lib):
+    """A singular A_k has no backward rollout: the host factorisation still succeeds (the plain
+    kernels need nothing of the kind) and reports the forward-elimination form as unavailable."""
+    p = pkg.random_ltv(N=12, n=3, m=2, batch=2, seed=77, with_q=False)
+    A = np.array(p.A)
+    A[5] = np.diag([1.0, 0.0, 0.5])
+    p = pkg.Problem(N=p.N, A=A, B=p.B, Q=p.Q, R=p.R, QN=p.QN, x0=p.x0, lo=p.lo, hi=p.hi)
+    rec = host_factor(p, 0.3, 3)
+    assert rec["alt_ok"] is False and np.isfinite(rec["scanW"]).all()
+    g = np.random.default_rng(9).standard_normal((p.batch, p.L))
+    w_ref = ar.x_update(ar.factor(p.A, p.B, p.Q, p.R, p.QN, 0.3, p.N), g, p.x0)
+    assert np.abs(w_ref - x_update_segmented(rec, p.n, p.m, g, p.x0)).max() <= 1e-12 * max(1.0, np.abs(w_ref).max())
+
+
 def _setup_rc(lib, p, opt=None):
     import ctypes as C
     cp, keep = _abi.marshal_problem(p)
