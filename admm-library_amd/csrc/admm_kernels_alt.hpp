@@ -14,7 +14,8 @@
 // One kernel + one scan per iteration.  Algorithmic HBM bytes per stacked element (n = 6, m = 3):
 //     xfze: d read 2.67 + v read 8 + v+ written 8 + db written 2.67 = 21.33   (+8 with a linear term q)
 //     xbze: db read 2.67 + v read 8 + v+ written 8 + d written 2.67 = 21.33   (+8 with q)
-// against 29.33 for xb + xfz (each elimination leaves only its m-row feed-forward term per stage).  Same layout, staging and addressing as admm_kernels.hpp.
+// against 29.33 for xb + xfz (each elimination leaves only its m-row feed-forward term per stage).
+// Same layout, staging and addressing as admm_kernels.hpp.
 #pragma once
 
 #include "admm_kernels.hpp"

@@ -293,6 +293,7 @@ def main():
 
     iters_to_eps = to_eps()
     iters_to_eps_adaptive = to_eps(adapt_interval=50, adapt_mu=10.0, adapt_tau=2.0)
+    iters_to_eps_relaxed = to_eps(adapt_interval=50, adapt_mu=10.0, adapt_tau=2.0, alpha=1.6)   # + over-relaxation
     solver = None
 
     if rank == 0:
@@ -324,6 +325,7 @@ def main():
                            "iteration_GBs": b_iter * elems / (ms_per_step * 1e-3) / 1e9},
             "iters_to_eps": iters_to_eps,
             "iters_to_eps_adaptive_rho": iters_to_eps_adaptive,
+            "iters_to_eps_adaptive_rho_alpha_1p6": iters_to_eps_relaxed,
             "check_interval_10": {"batch_iterations_per_s": a.steps / dt10,
                                   "QP_iterations_per_s": gbatch * a.steps / dt10},
         }
