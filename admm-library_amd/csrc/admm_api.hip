@@ -552,7 +552,11 @@ int admm_setup(admm_handle** out, const admm_problem* p, const admm_options* o_i
     if (S == 0) {
       const int col_blocks = (h->pitch + admm::XB_THREADS - 1) / admm::XB_THREADS;
       S = 256 / col_blocks;
-      const int max_by_len = h->N >= 16 ? h->N / 8 : 1;
+      // (a lone wave per segment is latency-bound at ~2.2 us per stage: with up to 64 QPs shorter segments
+      //  pay -- N = 200, batch 1: 24.9 -> 19.9 us per iteration at S = 50 instead of 25; beyond 64 segments
+      //  the host-side scan-matrix build, O(S^3), costs more than it saves)
+      const int per_seg = h->pitch <= 64 ? 4 : 8;
+      const int max_by_len = h->N >= 2 * per_seg ? h->N / per_seg : 1;
       if (S > max_by_len) S = max_by_len;
       if (S > 64) S = 64;
       // a segment of the state must stay below the 2 GiB a buffer descriptor can span (with margin)
