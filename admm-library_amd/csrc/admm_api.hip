@@ -422,6 +422,65 @@ int capture_iterations(admm_handle* h) {
   return ADMM_OK;
 }
 
+// device copies of everything in h->fac (records, scan matrices; the alternating set if enabled)
+int upload_factor(admm_handle* h) {
+  HIP_TRY(hipMemcpy(h->recB, h->fac.recB.data(), sizeof(double) * h->fac.recB.size(), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->recF, h->fac.recF.data(), sizeof(double) * h->fac.recF.size(), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->recS, h->fac.recS.data(), sizeof(double) * h->fac.recS.size(), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->scanWp, h->fac.scanWp.data(), sizeof(double) * h->fac.scanWp.size(), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->scan_range, h->fac.scanRange.data(), sizeof(int32_t) * h->fac.scanRange.size(), hipMemcpyHostToDevice));
+  h->alt_state = admm_handle::ALT_NONE;
+  if (h->alt && !h->fac.alt_ok) h->alt = false;            // the forward-elimination form did not survive the refactor
+  if (h->alt) {
+    HIP_TRY(hipMemcpy(h->recFE, h->fac.recFE.data(), sizeof(double) * h->fac.recFE.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->recBE, h->fac.recBE.data(), sizeof(double) * h->fac.recBE.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->scanWpB, h->fac.scanWpB.data(), sizeof(double) * h->fac.scanWpB.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->scan_rangeB, h->fac.scanRangeB.data(), sizeof(int32_t) * h->fac.scanRangeB.size(), hipMemcpyHostToDevice));
+  }
+  return ADMM_OK;
+}
+
+// bounds expanded to one entry per stacked row (standalone z kernels), thrust-magnitude bound per stage
+int upload_bounds(admm_handle* h, const admm_problem* p) {
+  const size_t L = h->L;
+  std::vector<double> lo(L), hi(L);
+  for (size_t e = 0; e < L; ++e) {
+    const size_t blk = e / h->nb, row = e % h->nb;
+    lo[e] = p->lo[(p->stage_bounds ? blk * h->nb : 0) + row];
+    hi[e] = p->hi[(p->stage_bounds ? blk * h->nb : 0) + row];
+  }
+  HIP_TRY(hipMemcpy(h->lo, lo.data(), sizeof(double) * L, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->hi, hi.data(), sizeof(double) * L, hipMemcpyHostToDevice));
+  std::vector<double> ub(h->N, INFINITY);
+  if (p->unorm)
+    for (int k = 0; k < h->N; ++k) ub[k] = p->unorm[p->stage_bounds ? k : 0];
+  HIP_TRY(hipMemcpy(h->ub, ub.data(), sizeof(double) * h->N, hipMemcpyHostToDevice));
+  return ADMM_OK;
+}
+
+// host copy of the shared problem data (the caller's pointers are never kept): admm_set_rho refactors from it
+void keep_shared(admm_handle* h, const admm_problem* p) {
+  const size_t nst = p->time_varying ? (size_t)p->N : 1, nbd = (size_t)h->nb * (p->stage_bounds ? p->N : 1);
+  h->pA.assign(p->A, p->A + nst * p->n * p->n);
+  h->pB.assign(p->B, p->B + nst * p->n * p->m);
+  h->pQ.assign(p->Q, p->Q + (size_t)p->n * p->n);
+  h->pR.assign(p->R, p->R + (size_t)p->m * p->m);
+  h->pQN.assign(p->QN, p->QN + (size_t)p->n * p->n);
+  h->plo.assign(p->lo, p->lo + nbd);
+  h->phi.assign(p->hi, p->hi + nbd);
+  h->pun.clear();
+  if (p->unorm) h->pun.assign(p->unorm, p->unorm + (p->stage_bounds ? p->N : 1));
+  h->time_varying = p->time_varying;
+  h->stage_bounds = p->stage_bounds;
+}
+
+bool problem_has_soc(const admm_problem* p) {
+  bool soc = false;
+  if (p->unorm)
+    for (int k = 0; k < (p->stage_bounds ? p->N : 1); ++k) soc = soc || std::isfinite(p->unorm[k]);
+  return soc;
+}
+
 }  // namespace
 
 extern "C" {
@@ -539,8 +598,7 @@ int admm_setup(admm_handle** out, const admm_problem* p, const admm_options* o_i
   h->L = p->N * h->nb;
   h->pitch = ((p->batch + 63) / 64) * 64;
   h->has_q = p->q != nullptr;
-  if (p->unorm)
-    for (int k = 0; k < (p->stage_bounds ? p->N : 1); ++k) h->has_soc = h->has_soc || std::isfinite(p->unorm[k]);
+  h->has_soc = problem_has_soc(p);
 
   // x-update segments: ONE workgroup (256 columns x one segment) per CU -- the grid
   // ceil(pitch / 256) x S should fill the 256 CUs once and not spill into a ragged second round
@@ -609,19 +667,7 @@ int admm_setup(admm_handle** out, const admm_problem* p, const admm_options* o_i
     }
   }
   h->S = h->fac.S;
-  {  // host copy of the shared problem data, for admm_set_rho / the adaptive rule
-    const size_t nst = p->time_varying ? (size_t)p->N : 1, nbd = (size_t)h->nb * (p->stage_bounds ? p->N : 1);
-    h->pA.assign(p->A, p->A + nst * p->n * p->n);
-    h->pB.assign(p->B, p->B + nst * p->n * p->m);
-    h->pQ.assign(p->Q, p->Q + (size_t)p->n * p->n);
-    h->pR.assign(p->R, p->R + (size_t)p->m * p->m);
-    h->pQN.assign(p->QN, p->QN + (size_t)p->n * p->n);
-    h->plo.assign(p->lo, p->lo + nbd);
-    h->phi.assign(p->hi, p->hi + nbd);
-    if (p->unorm) h->pun.assign(p->unorm, p->unorm + (p->stage_bounds ? p->N : 1));
-    h->time_varying = p->time_varying;
-    h->stage_bounds = p->stage_bounds;
-  }
+  keep_shared(h, p);     // host copy of the shared problem data, for admm_set_rho / the adaptive rule
   {  // the x kernels address one segment of an array through a 32-bit buffer descriptor
     int longest = 0;
     for (int s = 0; s < h->S; ++s) longest = std::max(longest, h->fac.seg_start[s + 1] - h->fac.seg_start[s]);
@@ -710,21 +756,7 @@ int admm_setup(admm_handle** out, const admm_problem* p, const admm_options* o_i
   HIP_TRY_RELEASE(hipMemsetAsync(h->status, 0, sizeof(int) * P, h->stream));
   HIP_TRY_RELEASE(hipMemsetAsync(h->iters, 0, sizeof(int) * P, h->stream));
 
-  // bounds expanded to one entry per stacked row
-  {
-    std::vector<double> lo(L), hi(L);
-    for (size_t e = 0; e < L; ++e) {
-      const size_t blk = e / h->nb, row = e % h->nb;
-      lo[e] = p->lo[(p->stage_bounds ? blk * h->nb : 0) + row];
-      hi[e] = p->hi[(p->stage_bounds ? blk * h->nb : 0) + row];
-    }
-    HIP_TRY_RELEASE(hipMemcpy(h->lo, lo.data(), sizeof(double) * L, hipMemcpyHostToDevice));
-    HIP_TRY_RELEASE(hipMemcpy(h->hi, hi.data(), sizeof(double) * L, hipMemcpyHostToDevice));
-    std::vector<double> ub(h->N, INFINITY);
-    if (p->unorm)
-      for (int k = 0; k < h->N; ++k) ub[k] = p->unorm[p->stage_bounds ? k : 0];
-    HIP_TRY_RELEASE(hipMemcpy(h->ub, ub.data(), sizeof(double) * h->N, hipMemcpyHostToDevice));
-  }
+  TRY_RELEASE(upload_bounds(h, p));
   HIP_TRY_RELEASE(hipMemcpy(h->recB, h->fac.recB.data(), sizeof(double) * h->fac.recB.size(), hipMemcpyHostToDevice));
   HIP_TRY_RELEASE(hipMemcpy(h->recF, h->fac.recF.data(), sizeof(double) * h->fac.recF.size(), hipMemcpyHostToDevice));
   HIP_TRY_RELEASE(hipMemcpy(h->recS, h->fac.recS.data(), sizeof(double) * h->fac.recS.size(), hipMemcpyHostToDevice));
@@ -788,19 +820,7 @@ static int set_rho_internal(admm_handle* h, double rho_new) {
   h->v_valid = false;
   HIP_TRY(hipStreamSynchronize(h->stream));                // kernels of the old rho are done before the records change
   h->fac = std::move(f);
-  HIP_TRY(hipMemcpy(h->recB, h->fac.recB.data(), sizeof(double) * h->fac.recB.size(), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(h->recF, h->fac.recF.data(), sizeof(double) * h->fac.recF.size(), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(h->recS, h->fac.recS.data(), sizeof(double) * h->fac.recS.size(), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(h->scanWp, h->fac.scanWp.data(), sizeof(double) * h->fac.scanWp.size(), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(h->scan_range, h->fac.scanRange.data(), sizeof(int32_t) * h->fac.scanRange.size(), hipMemcpyHostToDevice));
-  h->alt_state = admm_handle::ALT_NONE;
-  if (h->alt && !h->fac.alt_ok) h->alt = false;            // the forward-elimination form did not survive the new rho
-  if (h->alt) {
-    HIP_TRY(hipMemcpy(h->recFE, h->fac.recFE.data(), sizeof(double) * h->fac.recFE.size(), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(h->recBE, h->fac.recBE.data(), sizeof(double) * h->fac.recBE.size(), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(h->scanWpB, h->fac.scanWpB.data(), sizeof(double) * h->fac.scanWpB.size(), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(h->scan_rangeB, h->fac.scanRangeB.data(), sizeof(int32_t) * h->fac.scanRangeB.size(), hipMemcpyHostToDevice));
-  }
+  if ((rc = upload_factor(h))) return rc;
   h->opt.rho = rho_new;
   destroy_graph(h);                                        // rho is a captured kernel argument
   return ADMM_OK;
@@ -810,6 +830,37 @@ int admm_set_rho(admm_handle* h, double rho) {
   if (!h) return fail(ADMM_ERR_INVALID, "NULL handle");
   HIP_TRY(hipSetDevice(h->device));
   return set_rho_internal(h, rho);
+}
+
+int admm_update_problem(admm_handle* h, const admm_problem* p) {
+  if (!h || !p) return fail(ADMM_ERR_INVALID, "NULL argument");
+  HIP_TRY(hipSetDevice(h->device));
+  int rc;
+  if ((rc = validate_problem(p))) return rc;
+  if (p->N != h->N || p->n != h->n || p->m != h->m || p->batch != h->batch)
+    return fail(ADMM_ERR_INVALID, "admm_update_problem: N, n, m, batch must equal those of admm_setup");
+  if ((p->q != nullptr) != h->has_q)
+    return fail(ADMM_ERR_INVALID, "admm_update_problem: q must be given iff the handle was set up with one");
+  if (problem_has_soc(p) != h->has_soc)
+    return fail(ADMM_ERR_INVALID, "admm_update_problem: a thrust-magnitude bound cannot be added to or removed from a handle");
+  admm::Factor f;
+  std::string err;
+  if ((rc = admm::factorise(*p, h->opt.rho, h->S, f, err))) return fail(rc, err);
+  if (f.recB.size() != h->fac.recB.size() || f.scanWp.size() != h->fac.scanWp.size())
+    return fail(ADMM_ERR_NUMERIC, "internal: record sizes changed on refactor");
+  if ((rc = ensure_w(h))) return rc;           // w of the last x-update belongs to the old problem data
+  if ((rc = ensure_zy(h))) return rc;          // the state is kept as the (z, y) pair it was under the old box
+  h->zy_valid = true;
+  h->v_valid = false;
+  HIP_TRY(hipStreamSynchronize(h->stream));    // kernels of the old records are done before they change
+  keep_shared(h, p);
+  h->fac = std::move(f);
+  if ((rc = upload_factor(h))) return rc;
+  if ((rc = upload_bounds(h, p))) return rc;
+  if ((rc = upload_transposed(h, p->x0, h->x0, h->n))) return rc;
+  if (h->has_q && (rc = upload_transposed(h, p->q, h->q, h->L))) return rc;
+  destroy_graph(h);
+  return ADMM_OK;
 }
 
 int admm_set_state(admm_handle* h, const double* w, const double* z, const double* y) {

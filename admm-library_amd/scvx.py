@@ -129,11 +129,24 @@ def correction_qp(xb: np.ndarray, ub: np.ndarray, x0: np.ndarray, dt: float, Q, 
 
 
 def gpu_qp_solver(**options) -> Callable[[Problem], Tuple[np.ndarray, int]]:
-    """QP solver for scvx(): admm_solve on the HIP device (raises without one: no CPU fallback)."""
-    from .solver import Options, admm_solve
+    """QP solver for scvx(): the HIP solver (raises without a device: no CPU fallback).  One handle
+    serves every outer iteration: admm_update_problem refactors in place (same N, n, m, batch), each
+    solve starts cold (z = y = 0), like a fresh handle."""
+    from .solver import Options, Solver
+    state = {"solver": None, "shape": None}
 
     def solve(p: Problem):
-        w, z, _, info = admm_solve(p, Options(**options))
+        shape = (p.N, p.n, p.m, p.batch, p.q is not None, p.unorm is not None)
+        if state["solver"] is None or state["shape"] != shape:
+            if state["solver"] is not None:
+                state["solver"].close()
+            state["solver"], state["shape"] = Solver(p, Options(**options)), shape
+        else:
+            state["solver"].update_problem(p)
+        s = state["solver"]
+        zero = np.zeros((p.batch, p.L))
+        info = s.solve(z0=zero, y0=zero)
+        _, z, _ = s.get(w=False)
         return z, int(info.iters_run)      # z: the feasible (projected) iterate
     return solve
 

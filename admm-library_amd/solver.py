@@ -69,6 +69,7 @@ _SIGNATURES = {
                                         c_int32_p, c_int32_p]),
     "admm_host_factor": (C.c_int, [C.POINTER(CProblem), C.c_double, C.c_int32, c_double_p, c_double_p,
                                    c_double_p, c_double_p, c_double_p, c_int32_p]),
+    "admm_update_problem": (C.c_int, [C.c_void_p, C.POINTER(CProblem)]),
     "admm_record_sizes_alt": (C.c_int, [C.c_int32, C.c_int32, c_int32_p, c_int32_p]),
     "admm_host_factor_alt": (C.c_int, [C.POINTER(CProblem), C.c_double, C.c_int32, c_double_p, c_double_p,
                                        c_double_p, c_int32_p]),
@@ -188,6 +189,14 @@ class Solver:
         x0 = self._vec(x0, self.problem.n)
         q = self._vec(q)
         _check(self._lib, self._lib.admm_update_instances(self._h, dptr(x0), dptr(q)))
+
+    def update_problem(self, problem: Problem):
+        """New shared data (dynamics, weights, box, x0, q) on this handle; same N, n, m, batch."""
+        problem.validate()
+        cp, keep = _abi.marshal_problem(problem)
+        _check(self._lib, self._lib.admm_update_problem(self._h, C.byref(cp)))
+        del keep
+        self.problem = problem
 
     def set_rho(self, rho: float):
         _check(self._lib, self._lib.admm_set_rho(self._h, float(rho)))

@@ -139,6 +139,14 @@ int admm_update_instances(admm_handle* h, const double* x0, const double* q);
  * rho y is unchanged. */
 int admm_set_rho(admm_handle* h, double rho);
 
+/* New shared problem data on an existing handle: dynamics, weights, box, thrust-magnitude bounds, x0 and
+ * q of *p replace those of admm_setup (same N, n, m, batch; q present iff it was; a thrust-magnitude
+ * bound present iff one was).  The KKT system is refactored with the current rho and segment count and
+ * everything re-uploaded; device buffers, the state (kept as the (z, y) pair) and per-QP results are left
+ * alone.  This is what a successive-convexification caller does between outer iterations instead of
+ * admm_free + admm_setup.  On failure the handle is unchanged. */
+int admm_update_problem(admm_handle* h, const admm_problem* p);
+
 /* Warm start / test hook: overwrite device state.  Any pointer may be NULL
  * (left unchanged).  Each is L*batch. */
 int admm_set_state(admm_handle* h, const double* w, const double* z, const double* y);

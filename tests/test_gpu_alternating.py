@@ -155,6 +155,35 @@ def test_state_changes_between_alternating_iterations(gpu):
         assert np.abs(a - b).max() <= 1e-11 * max(1.0, np.abs(b).max())
 
 
+def test_update_problem_equals_a_fresh_handle(gpu):
+    """admm_update_problem: new dynamics, weights, box, x0 and q on an existing handle (what a
+    successive-convexification caller does between outer iterations) = admm_setup on the new data."""
+    p1 = pkg.random_ltv(N=33, n=6, m=3, batch=20, seed=41)
+    p2 = pkg.random_ltv(N=33, n=6, m=3, batch=20, seed=42)
+    zero = np.zeros((p2.batch, p2.L))
+    with pkg.Solver(p1, pkg.Options(rho=0.3, segments=4)) as s:
+        s.run(7, residual_every=1)
+        s.update_problem(p2)
+        s.set_state(z=zero, y=zero)
+        s.run(12, residual_every=1)
+        got = s.get() + tuple(s.residuals())
+        info = s.solve(z0=zero, y0=zero)             # and a full solve on the updated handle
+        with pytest.raises(pkg.AdmmError):           # shape changes are refused, the handle stays usable
+            s.update_problem(pkg.random_ltv(N=34, n=6, m=3, batch=20, seed=42))
+        with pytest.raises(pkg.AdmmError):
+            s.update_problem(pkg.random_ltv(N=33, n=6, m=3, batch=20, seed=42, with_q=False))
+        s.iterate(2)
+    with pkg.Solver(p2, pkg.Options(rho=0.3, segments=4)) as s:
+        s.run(12, residual_every=1)
+        want = s.get() + tuple(s.residuals())
+        info2 = s.solve(z0=zero, y0=zero)
+    for a, b in zip(got, want):
+        assert np.abs(a - b).max() <= 1e-12 * max(1.0, np.abs(b).max())
+    ref = oc.solve(p2, rho=0.3, max_iter=12, check_interval=1, eps_abs=0, eps_rel=0, stop=False)
+    assert _close(got[0], ref["w"]) and _close(got[1], ref["z"]) and _close(got[2], ref["y"])
+    assert info.iters_run == info2.iters_run and np.array_equal(info.iters, info2.iters)
+
+
 @pytest.mark.parametrize("kw", [dict(), dict(alpha=1.5), dict(check_interval=7), dict(adapt_interval=20),
                                 dict(max_iter=33, check_interval=10)])
 def test_solve_with_alternating_iterations(gpu, kw):
