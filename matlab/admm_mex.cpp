@@ -77,6 +77,35 @@ Dims* lookup(admm_handle* h) {
   return nullptr;
 }
 
+// MATLAB problem struct -> admm_problem (pointers into the struct's arrays; valid while P is)
+void parse_problem(const mxArray* P, admm_problem& p) {
+  const mxArray *A = field(P, "A", true), *B = field(P, "B", true), *x0 = field(P, "x0", true);
+  const mxArray *lo = field(P, "lo", true), *hi = field(P, "hi", true), *q = field(P, "q", false);
+  std::memset(&p, 0, sizeof p);
+  p.N = static_cast<int32_t>(mxGetScalar(field(P, "N", true)));
+  p.n = static_cast<int32_t>(mxGetM(B));
+  const mwSize* bd = mxGetDimensions(B);
+  p.m = static_cast<int32_t>(bd[1]);
+  p.batch = static_cast<int32_t>(mxGetN(x0));
+  p.time_varying = mxGetNumberOfDimensions(A) == 3 ? 1 : 0;
+  p.stage_bounds = mxGetN(lo) > 1 ? 1 : 0;
+  if (static_cast<int32_t>(mxGetM(x0)) != p.n) fail("admm:input", "x0 must be n x batch");
+  if (static_cast<int32_t>(mxGetM(lo)) != p.n + p.m || static_cast<int32_t>(mxGetM(hi)) != p.n + p.m)
+    fail("admm:input", "lo/hi must have m+n rows (u block, then x block)");
+  if (p.stage_bounds && static_cast<int32_t>(mxGetN(lo)) != p.N) fail("admm:input", "per-stage bounds need N columns");
+  if (p.time_varying && static_cast<int32_t>(mxGetDimensions(A)[2]) != p.N) fail("admm:input", "time-varying A needs N pages");
+  p.A = dbl(A, "A"); p.B = dbl(B, "B");
+  p.Q = dbl(field(P, "Q", true), "Q"); p.R = dbl(field(P, "R", true), "R"); p.QN = dbl(field(P, "QN", true), "QN");
+  p.x0 = dbl(x0, "x0"); p.lo = dbl(lo, "lo"); p.hi = dbl(hi, "hi");
+  p.q = dbl(q, "q");
+  const mxArray* un = field(P, "unorm", false);     // thrust-magnitude bound, optional: 1 or N entries
+  p.unorm = dbl(un, "unorm");
+  if (p.unorm && static_cast<int32_t>(mxGetNumberOfElements(un)) != (p.stage_bounds ? p.N : 1))
+    fail("admm:input", "unorm must have 1 entry, or N entries together with per-stage bounds");
+  const int L = p.N * (p.n + p.m);
+  if (p.q && (static_cast<int>(mxGetM(q)) != L || static_cast<int32_t>(mxGetN(q)) != p.batch)) fail("admm:input", "q must be L x batch");
+}
+
 }  // namespace
 
 void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
@@ -88,32 +117,9 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     if (nrhs < 2 || !mxIsStruct(prhs[1])) fail("admm:input", "setup needs a problem struct");
     const mxArray* P = prhs[1];
     const mxArray* O = (nrhs > 2 && mxIsStruct(prhs[2])) ? prhs[2] : nullptr;
-    const mxArray *A = field(P, "A", true), *B = field(P, "B", true), *x0 = field(P, "x0", true);
-    const mxArray *lo = field(P, "lo", true), *hi = field(P, "hi", true), *q = field(P, "q", false);
     admm_problem p;
-    std::memset(&p, 0, sizeof p);
-    p.N = static_cast<int32_t>(mxGetScalar(field(P, "N", true)));
-    p.n = static_cast<int32_t>(mxGetM(B));
-    const mwSize* bd = mxGetDimensions(B);
-    p.m = static_cast<int32_t>(bd[1]);
-    p.batch = static_cast<int32_t>(mxGetN(x0));
-    p.time_varying = mxGetNumberOfDimensions(A) == 3 ? 1 : 0;
-    p.stage_bounds = mxGetN(lo) > 1 ? 1 : 0;
-    if (static_cast<int32_t>(mxGetM(x0)) != p.n) fail("admm:input", "x0 must be n x batch");
-    if (static_cast<int32_t>(mxGetM(lo)) != p.n + p.m || static_cast<int32_t>(mxGetM(hi)) != p.n + p.m)
-      fail("admm:input", "lo/hi must have m+n rows (u block, then x block)");
-    if (p.stage_bounds && static_cast<int32_t>(mxGetN(lo)) != p.N) fail("admm:input", "per-stage bounds need N columns");
-    if (p.time_varying && static_cast<int32_t>(mxGetDimensions(A)[2]) != p.N) fail("admm:input", "time-varying A needs N pages");
-    p.A = dbl(A, "A"); p.B = dbl(B, "B");
-    p.Q = dbl(field(P, "Q", true), "Q"); p.R = dbl(field(P, "R", true), "R"); p.QN = dbl(field(P, "QN", true), "QN");
-    p.x0 = dbl(x0, "x0"); p.lo = dbl(lo, "lo"); p.hi = dbl(hi, "hi");
-    p.q = dbl(q, "q");
-    const mxArray* un = field(P, "unorm", false);     // thrust-magnitude bound, optional: 1 or N entries
-    p.unorm = dbl(un, "unorm");
-    if (p.unorm && static_cast<int32_t>(mxGetNumberOfElements(un)) != (p.stage_bounds ? p.N : 1))
-      fail("admm:input", "unorm must have 1 entry, or N entries together with per-stage bounds");
+    parse_problem(P, p);
     const int L = p.N * (p.n + p.m);
-    if (p.q && (static_cast<int>(mxGetM(q)) != L || static_cast<int32_t>(mxGetN(q)) != p.batch)) fail("admm:input", "q must be L x batch");
     admm_options o;
     admm_default_options(&o);
     o.rho = scalar_or(O, "rho", o.rho);
@@ -178,6 +184,11 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     if (nrhs < 3) fail("admm:input", "iterate needs an iteration count");
     check(admm_iterate(h, static_cast<int32_t>(mxGetScalar(prhs[2]))));
     check(admm_sync(h));
+  } else if (!std::strcmp(cmd, "update")) {       // admm_mex('update', h, problem): new shared data, same shape
+    if (nrhs < 3 || !mxIsStruct(prhs[2])) fail("admm:input", "update needs a problem struct");
+    admm_problem p;
+    parse_problem(prhs[2], p);
+    check(admm_update_problem(h, &p));
   } else if (!std::strcmp(cmd, "free")) {
     d->h = nullptr;
     admm_free(h);
