@@ -134,12 +134,32 @@ Mat neg(const Mat& a) {
 void put(double* dst, const Mat& a) {
   for (size_t i = 0; i < a.size(); ++i) dst[i] = a[i];
 }
-void put_block(std::vector<double>& W, int K, int r0, int c0, const Mat& a, int n, bool accumulate) {
+
+// Row-block recurrences on a dense scan matrix W (row-major, K columns, blocks of n rows): the chains the
+// scan solves are linear, so each row block of W is the chain step applied to earlier row blocks,
+//     W[dst] = M1 W[src1] (+ M2 W[src2]) (+ I in the n columns starting at unit_col)
+// -- O(S^2 n^3) for the whole matrix instead of summing products of transfer matrices per entry.
+// src < 0 = absent; dst must differ from src1 and src2.
+void rowblock_step(std::vector<double>& W, int K, int n, int dst, const Mat* M1, int src1, const Mat* M2, int src2,
+                   int unit_col) {
+  double* d = &W[(size_t)dst * K];
   for (int i = 0; i < n; ++i)
-    for (int j = 0; j < n; ++j) {
-      double& w = W[(size_t)(r0 + i) * K + c0 + j];
-      w = accumulate ? w + a[(size_t)i * n + j] : a[(size_t)i * n + j];
-    }
+    for (int c = 0; c < K; ++c) d[(size_t)i * K + c] = 0.0;
+  auto acc = [&](const Mat& Mx, int src) {
+    const double* sp = &W[(size_t)src * K];
+    for (int i = 0; i < n; ++i)
+      for (int l = 0; l < n; ++l) {
+        const double a = Mx[(size_t)i * n + l];
+        if (a == 0.0) continue;
+        const double* srow = sp + (size_t)l * K;
+        double* drow = d + (size_t)i * K;
+        for (int c = 0; c < K; ++c) drow[c] += a * srow[c];
+      }
+  };
+  if (M1 && src1 >= 0) acc(*M1, src1);
+  if (M2 && src2 >= 0) acc(*M2, src2);
+  if (unit_col >= 0)
+    for (int i = 0; i < n; ++i) d[(size_t)i * K + unit_col + i] += 1.0;
 }
 
 // general n x n inverse (Gauss-Jordan, partial pivoting); false if a pivot is tiny relative to the matrix
@@ -347,33 +367,15 @@ void build_alternating(Factor& f, const std::vector<Mat>& A, const std::vector<M
   const int Sn = S * n, Mt = f.scanMt, M = f.scanM, K = f.scanK;
   f.scanWB.assign((size_t)M * K, 0.0);
   const int c_m = 0, c_x0 = Sn, c_e = Sn + n, r_m = 0, r_x = Mt;
-  // m_in(s) = [Phs_{s-1} ... Phs_0] x0 + sum_{s' < s} [Phs_{s-1} ... Phs_{s'+1}] mseg(s'),  s = 0 .. S
-  std::vector<std::vector<Mat>> Mm(S + 1, std::vector<Mat>(S));   // Mm[s][s'] (s' < s)
-  std::vector<Mat> Mx0(S + 1);
-  for (int s = 0; s <= S; ++s) {
-    Mat P = I;
-    for (int sp = s - 1; sp >= 0; --sp) {
-      Mm[s][sp] = P;
-      if (s < S) put_block(f.scanWB, K, r_m + s * n, c_m + sp * n, P, n, false);
-      P = mul(P, Phs[sp], n, n, n);
-    }
-    Mx0[s] = P;
-    if (s < S) put_block(f.scanWB, K, r_m + s * n, c_x0, P, n, false);
-  }
-  // x_end(s) = Pb(s, S) m_in(S) + sum_{s' > s} Pb(s, s') (ebseg(s') + Xib_{s'} m_in(s')),  Pb(s, s') = Thb_{s+1} ... Thb_{s'-1}
-  auto add_min = [&](int row, const Mat& coef, int sm) {            // row block += coef * m_in(sm)
-    put_block(f.scanWB, K, row, c_x0, mul(coef, Mx0[sm], n, n, n), n, true);
-    for (int spp = 0; spp < sm; ++spp) put_block(f.scanWB, K, row, c_m + spp * n, mul(coef, Mm[sm][spp], n, n, n), n, true);
-  };
-  for (int s = 0; s < S; ++s) {
-    Mat P = I;
-    for (int sp = s + 1; sp < S; ++sp) {
-      put_block(f.scanWB, K, r_x + s * n, c_e + sp * n, P, n, false);
-      add_min(r_x + s * n, mul(P, Xib[sp], n, n, n), sp);
-      P = mul(P, Thb[sp], n, n, n);
-    }
-    add_min(r_x + s * n, P, S);
-  }
+  // The chains applied to row blocks of WB (rowblock_step):
+  //   m_in(0)    = x0;       m_in(s+1)  = mseg(s) + Phs_s m_in(s)
+  //   x_end(S-1) = m_in(S);  x_end(s-1) = ebseg(s) + Thb_s x_end(s) + Xib_s m_in(s)
+  rowblock_step(f.scanWB, K, n, r_m, nullptr, -1, nullptr, -1, c_x0);
+  for (int s = 0; s + 1 < S; ++s)
+    rowblock_step(f.scanWB, K, n, r_m + (s + 1) * n, &Phs[s], r_m + s * n, nullptr, -1, c_m + s * n);
+  rowblock_step(f.scanWB, K, n, r_x + (S - 1) * n, &Phs[S - 1], r_m + (S - 1) * n, nullptr, -1, c_m + (S - 1) * n);
+  for (int s = S - 1; s >= 1; --s)
+    rowblock_step(f.scanWB, K, n, r_x + (s - 1) * n, &Thb[s], r_x + s * n, &Xib[s], r_m + s * n, c_e + s * n);
   for (double v : f.scanWB) if (!std::isfinite(v)) return;
 
   // ---- verification against the Riccati form (one QP, random linear term, the scan as the dense product) ----
@@ -605,7 +607,6 @@ int factorise(const admm_problem& p, double rho, int segments, Factor& f, std::s
     const int K = round_up(2 * Sn + n, 4 * SCAN_KALIGN);
     f.scanM = M; f.scanMt = Mt; f.scanK = K;
     f.scanW.assign((size_t)M * K, 0.0);
-    auto W = [&](int r, int c) -> double& { return f.scanW[(size_t)r * K + c]; };
     auto blk = [&](const double* rs, int which) { return Mat(rs + (size_t)which * n * n, rs + (size_t)(which + 1) * n * n); };
     std::vector<Mat> Phi(S), Xi(S), Th(S);
     for (int s = 0; s < S; ++s) {
@@ -614,34 +615,14 @@ int factorise(const admm_problem& p, double rho, int segments, Factor& f, std::s
     }
     const int c_t = 0, c_x0 = Sn, c_e = Sn + n;           // column offsets of tseg | x0 | eseg
     const int r_t = 0, r_x = Mt;                          // row offsets of t_in | x_in
-    // t_in(s) = sum_{s' > s} [Phi_{s+1} ... Phi_{s'-1}] tseg(s')
-    std::vector<std::vector<Mat>> MtB(S, std::vector<Mat>(S));   // MtB[s][s'] (s' > s)
-    for (int s = 0; s < S; ++s) {
-      Mat P = eye(n);
-      for (int sp = s + 1; sp < S; ++sp) {
-        MtB[s][sp] = P;
-        for (int i = 0; i < n; ++i)
-          for (int j = 0; j < n; ++j) W(r_t + s * n + i, c_t + sp * n + j) = P[(size_t)i * n + j];
-        P = mul(P, Phi[sp], n, n, n);
-      }
-    }
-    // x_in(s) = [Th_{s-1}...Th_0] x0 + sum_{s' < s} [Th_{s-1}...Th_{s'+1}] (eseg(s') + Xi_{s'} t_in(s'))
-    for (int s = 0; s < S; ++s) {
-      Mat P = eye(n);
-      for (int sp = s - 1; sp >= 0; --sp) {
-        for (int i = 0; i < n; ++i)
-          for (int j = 0; j < n; ++j) W(r_x + s * n + i, c_e + sp * n + j) = P[(size_t)i * n + j];
-        const Mat PX = mul(P, Xi[sp], n, n, n);            // U(s, s') Xi_{s'}
-        for (int spp = sp + 1; spp < S; ++spp) {           // ... times Mt(s', s'')
-          const Mat G = mul(PX, MtB[sp][spp], n, n, n);
-          for (int i = 0; i < n; ++i)
-            for (int j = 0; j < n; ++j) W(r_x + s * n + i, c_t + spp * n + j) += G[(size_t)i * n + j];
-        }
-        P = mul(P, Th[sp], n, n, n);
-      }
-      for (int i = 0; i < n; ++i)
-        for (int j = 0; j < n; ++j) W(r_x + s * n + i, c_x0 + j) = P[(size_t)i * n + j];
-    }
+    // The chains of xscan_kernel applied to row blocks of W (rowblock_step):
+    //   t_in(S-1) = 0;   t_in(s-1) = tseg(s) + Phi_s t_in(s)
+    //   x_in(0)   = x0;  x_in(s+1) = eseg(s) + Xi_s t_in(s) + Th_s x_in(s)
+    for (int s = S - 1; s >= 1; --s)
+      rowblock_step(f.scanW, K, n, r_t + (s - 1) * n, &Phi[s], r_t + s * n, nullptr, -1, c_t + s * n);
+    rowblock_step(f.scanW, K, n, r_x, nullptr, -1, nullptr, -1, c_x0);
+    for (int s = 0; s + 1 < S; ++s)
+      rowblock_step(f.scanW, K, n, r_x + (s + 1) * n, &Th[s], r_x + s * n, &Xi[s], r_t + s * n, c_e + s * n);
     for (double v : f.scanW)
       if (!std::isfinite(v)) { err = "scan matrix overflowed; use more segments"; return ADMM_ERR_NUMERIC; }
     pack_scan(f.scanW, M, K, f.scanWp, f.scanRange);
