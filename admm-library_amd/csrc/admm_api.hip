@@ -612,7 +612,7 @@ int admm_setup(admm_handle** out, const admm_problem* p, const admm_options* o_i
       S = 256 / col_blocks;
       // (a lone wave per segment is latency-bound at ~2.2 us per stage: with up to 64 QPs shorter segments
       //  pay -- N = 200, batch 1: 24.9 -> 19.9 us per iteration at S = 50 instead of 25; beyond 64 segments
-      //  the host-side scan-matrix build, O(S^3), costs more than it saves)
+      //  the host-side factorisation -- 80 ms at S = 125 -- costs more than a solve saves)
       const int per_seg = h->pitch <= 64 ? 4 : 8;
       const int max_by_len = h->N >= 2 * per_seg ? h->N / per_seg : 1;
       if (S > max_by_len) S = max_by_len;
