@@ -6,7 +6,7 @@ import admm_library_amd as pkg
 flags = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 resid = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 segs = int(sys.argv[3]) if len(sys.argv) > 3 else 0
-p = pkg.cw_rendezvous(N=1000, batch=4096)
+p = pkg.cw_rendezvous(N=int(os.environ.get('ALT_N', 1000)), batch=int(os.environ.get('ALT_BATCH', 4096)))
 with pkg.Solver(p, pkg.Options(rho=0.05, flags=flags, segments=segs)) as s:
     s.run(20, resid); s.sync()
     t0 = time.perf_counter(); s.run(200, resid); s.sync(); dt = time.perf_counter() - t0
