@@ -50,9 +50,9 @@ constexpr int prefetch_depth(int nb) {
 // multiple of the prefetch depth so that ring slots stay aligned across refills.
 constexpr int stage_chunk(int rec_doubles, int pf) {
   int ch = 8192 / rec_doubles;
-  ch = (ch / pf) * pf;
-  if (ch < pf) ch = pf;
   if (ch > 128) ch = 128;
+  ch = (ch / pf) * pf;          // AFTER the cap: 128 is not a multiple of a 3-deep ring (tiny blocks, segments > 128 stages)
+  if (ch < pf) ch = pf;
   return ch;
 }
 

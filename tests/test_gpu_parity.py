@@ -367,6 +367,22 @@ def test_randomised_configurations(gpu):
             assert np.abs(a - b).max() <= TOL * max(1.0, np.abs(b).max()), ctx
 
 
+@pytest.mark.parametrize("flags", [0, 8, 2], ids=["default", "fused_plain", "unfused"])
+@pytest.mark.parametrize("shape", [(148, 1, 1, 300), (300, 2, 2, 64), (200, 3, 1, 5)])
+def test_tiny_blocks_with_segments_longer_than_one_record_chunk(gpu, shape, flags):
+    """Regression (found by tools/stress_alt.py): for tiny (n, m) the per-stage records are so small
+    that the LDS chunk hits its 128-stage cap, which was not a multiple of the 3-deep prefetch ring --
+    segments longer than 128 stages then read misaligned ring slots (errors of 1e-5)."""
+    N, n, m, batch = shape
+    p = pkg.random_ltv(N=N, n=n, m=m, batch=batch, seed=3238, with_q=False, state_bounds=False)
+    with pkg.Solver(p, pkg.Options(rho=0.1, segments=1, flags=flags)) as s:
+        s.iterate(5)
+        w, z, y = s.get()
+    ref = oc.solve(p, rho=0.1, max_iter=5, stop=False)
+    for a, b in ((w, ref["w"]), (z, ref["z"]), (y, ref["y"])):
+        assert np.abs(a - b).max() <= TOL * max(1.0, np.abs(b).max())
+
+
 def test_plain_c_program_over_the_abi(gpu, tmp_path):
     """examples/c_abi_demo.c: the boundary really is a C ABI -- a C11 program compiled with gcc,
     linked against libadmm_hip.so only, sets up, solves and reads back a batch."""
