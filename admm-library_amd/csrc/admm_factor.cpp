@@ -463,7 +463,9 @@ void build_alternating(Factor& f, const std::vector<Mat>& A, const std::vector<M
       scale = std::max(scale, std::fabs(wa[i]));
     }
     f.alt_check = err / scale;
-    if (!(f.alt_check <= 2e-11)) return;             // an order of magnitude inside the 1e-10 parity tolerance
+    // 5e-12 on one x-update: iterates then stay within ~3e-11 of the Riccati-form iterates (900 random problems,
+    // tools/stress_alt.py: max 2.5e-11), inside the 1e-10 parity tolerance with margin
+    if (!(f.alt_check <= 5e-12)) return;
   }
   pack_scan(f.scanWB, M, K, f.scanWpB, f.scanRangeB);
   f.alt_ok = true;
