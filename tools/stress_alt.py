@@ -1,4 +1,5 @@
-"""One-off stress of the default (alternating) path on a GPU box: seeded random problems over the
+"""Stress of the iteration paths on a GPU box (STRESS_FLAGS=1: random option flags too; default: the
+alternating path only): seeded random problems over the
 compiled (n, m) set, with / without q, box or thrust-magnitude bound, many rho -- more iterations and far
 more draws than the unit tests -- against the C oracle.  Prints the error distribution."""
 import os, sys
@@ -23,13 +24,14 @@ for trial in range(trials):
     soc = bool(rng.integers(4) == 0)
     rho = float(rng.choice([0.02, 0.1, 0.5, 2.0, 8.0]))
     iters = int(rng.choice([3, 8, 17, 40]))
+    flags = int(rng.choice([0, 0, 0, 8, 2, 16, 4, 6, 24])) if os.environ.get("STRESS_FLAGS") else 0
     if rng.integers(3) == 0:
         p = pkg.cw_rendezvous(N=max(N, 8) * 4, batch=batch, seed0=500 + trial, thrust_norm=soc)
     else:
         p = pkg.random_ltv(N=N, n=n, m=m, batch=batch, seed=3000 + trial, with_q=with_q, state_bounds=bool(rng.integers(2)),
                            thrust_norm=soc)
     ref = oc.solve(p, rho=rho, alpha=alpha, max_iter=iters, check_interval=1, eps_abs=0, eps_rel=0, stop=False)
-    with pkg.Solver(p, pkg.Options(rho=rho, alpha=alpha, segments=segs)) as s:
+    with pkg.Solver(p, pkg.Options(rho=rho, alpha=alpha, segments=segs, flags=flags)) as s:
         try:
             s.profile(1, alternating=True); on = True
         except pkg.AdmmError:
@@ -42,7 +44,7 @@ for trial in range(trials):
     errs.append(e)
     if e > worst[0]:
         worst = (e, dict(trial=trial, name=p.name, n=p.n, m=p.m, N=p.N, batch=batch, segs=segs, alpha=alpha, rho=rho, q=p.q is not None,
-                         soc=soc, iters=iters, alt=on))
+                         soc=soc, iters=iters, alt=on, flags=flags))
     if e > 1e-10:
         print("FAIL", e, worst[1], flush=True)
 errs = np.array(errs)
