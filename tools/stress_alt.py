@@ -17,7 +17,7 @@ worst, alt_on, errs = (0.0, None), 0, []
 for trial in range(trials):
     n, m = dims[rng.integers(len(dims))]
     N = int(rng.integers(1, 160))
-    batch = int(rng.choice([1, 3, 64, 65, 130, 300]))
+    batch = int(rng.choice([511, 1025, 2049, 4096, 4160]) if os.environ.get("STRESS_BIG") else rng.choice([1, 3, 64, 65, 130, 300]))
     segs = int(rng.choice([0, 0, 1, 2, 3, 5, 8, 13]))
     alpha = float(rng.choice([1.0, 1.0, 1.5]))
     with_q = bool(rng.integers(2))
