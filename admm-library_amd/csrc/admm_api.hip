@@ -42,6 +42,8 @@ struct admm_handle {
   int S = 0, zrows = 0, zchunks = 0;
   int scan_split = 1;            // split-K factor of the MFMA scan (small batches)
   int device = 0;
+  int num_cus = 256;             // hipDeviceProp_t::multiProcessorCount of the handle's device
+  bool auto_segments = false;    // the segment count was chosen by admm_setup (and is guarded by scan_growth)
   bool has_q = false;
   bool has_soc = false;          // some stage has a finite thrust-magnitude bound
   admm_options opt{};
@@ -372,6 +374,14 @@ int validate_problem(const admm_problem* p) {
   return ADMM_OK;
 }
 
+// Conditioning guard of the parallel-in-time form (see admm_setup): largest entry of the dense scan matrices.
+constexpr double SCAN_GROWTH_MAX = 100.0;
+double scan_growth(const admm::Factor& f) {
+  double g = 0.0;
+  for (double v : f.scanW) g = std::max(g, std::fabs(v));
+  return g;
+}
+
 void destroy_graph(admm_handle* h) {
   for (int v = 0; v < 16; ++v) {
     if (h->graph_exec[v]) { (void)hipGraphExecDestroy(h->graph_exec[v]); h->graph_exec[v] = nullptr; }
@@ -593,6 +603,10 @@ int admm_setup(admm_handle** out, const admm_problem* p, const admm_options* o_i
 
   admm_handle* h = new admm_handle();
   h->device = dev;
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) h->num_cus = prop.multiProcessorCount;
+  }
   h->opt = o;
   h->N = p->N; h->n = p->n; h->m = p->m; h->nb = p->n + p->m; h->batch = p->batch;
   h->L = p->N * h->nb;
@@ -609,7 +623,7 @@ int admm_setup(admm_handle** out, const admm_problem* p, const admm_options* o_i
     int S = o.segments;
     if (S == 0) {
       const int col_blocks = (h->pitch + admm::XB_THREADS - 1) / admm::XB_THREADS;
-      S = 256 / col_blocks;
+      S = h->num_cus / col_blocks;
       // (a lone wave per segment is latency-bound at ~2.2 us per stage: with up to 64 QPs shorter segments
       //  pay -- N = 200, batch 1: 24.9 -> 19.9 us per iteration at S = 50 instead of 25; beyond 64 segments
       //  the host-side factorisation -- 80 ms at S = 125 -- costs more than a solve saves)
@@ -634,7 +648,7 @@ int admm_setup(admm_handle** out, const admm_problem* p, const admm_options* o_i
     int zr = o.zrows;
     if (zr == 0) {
       const int col_groups = (h->pitch / 2 + Z_THREADS - 1) / Z_THREADS;
-      int chunks = (256 + col_groups - 1) / col_groups;
+      int chunks = (h->num_cus + col_groups - 1) / col_groups;
       if (chunks < 1) chunks = 1;
       zr = (h->L + chunks - 1) / chunks;
       zr = ((zr + 3) / 4) * 4;
@@ -654,13 +668,9 @@ int admm_setup(admm_handle** out, const admm_problem* p, const admm_options* o_i
   // segments and amplify rounding (measured: max|W| 1e3 -> 1e-5 relative error in w, against
   // 1e-14 for the workloads of DESIGN.md §3 where max|W| is O(1)).  With an automatic segment
   // count, fall back to fewer, longer segments until the growth is benign.
+  h->auto_segments = o.segments == 0;
   if (o.segments == 0) {
-    auto growth = [](const admm::Factor& f) {
-      double g = 0.0;
-      for (double v : f.scanW) g = std::max(g, std::fabs(v));
-      return g;
-    };
-    while (h->fac.S > 1 && growth(h->fac) > 100.0) {
+    while (h->fac.S > 1 && scan_growth(h->fac) > SCAN_GROWTH_MAX) {
       const int S2 = std::max(1, h->fac.S / 2);
       rc = admm::factorise(*p, o.rho, S2, h->fac, err);
       if (rc) { release(h); return fail(rc, err); }
@@ -694,7 +704,7 @@ int admm_setup(admm_handle** out, const admm_problem* p, const admm_options* o_i
     {  // split-K of the scan when the grid would be small: aim at >= 256 workgroups, <= 8 slices
       const int wgs = (h->pitch / 64) * (h->fac.scanM / 16 / admm::SCAN_MT);
       int sp = 1;
-      while (sp < 8 && wgs * sp < 256) sp *= 2;
+      while (sp < 8 && wgs * sp < h->num_cus) sp *= 2;
       const int ksteps = h->fac.scanK / 4;
       while (sp > 1 && ksteps / sp < 2 * admm::SCAN_U) sp /= 2;     // at least two batches per slice
       if (const char* e = std::getenv("ADMM_SCAN_SPLIT")) {           // tuning override (1, 2, 4, 8)
@@ -808,6 +818,11 @@ static int set_rho_internal(admm_handle* h, double rho_new) {
   if (rc) return fail(rc, err);
   if (f.recB.size() != h->fac.recB.size() || f.scanWp.size() != h->fac.scanWp.size())
     return fail(ADMM_ERR_NUMERIC, "internal: record sizes changed on refactor");
+  // the segment count is frozen on a live handle, so the conditioning guard of admm_setup can only refuse here
+  if (h->auto_segments && h->S > 1 && scan_growth(f) > SCAN_GROWTH_MAX)
+    return fail(ADMM_ERR_NUMERIC, "rho change refused: with this rho the segment transfer matrices of the handle's " +
+                                      std::to_string(h->S) + " segments grow beyond the conditioning bound (max |W| > 100); "
+                                      "set the handle up with this rho (fewer segments are chosen then) or give options.segments");
   if ((rc = ensure_w(h))) return rc;          // w of the last x-update must be rebuilt with the OLD records
   if ((rc = ensure_zy(h))) return rc;
   {
@@ -848,6 +863,10 @@ int admm_update_problem(admm_handle* h, const admm_problem* p) {
   if ((rc = admm::factorise(*p, h->opt.rho, h->S, f, err))) return fail(rc, err);
   if (f.recB.size() != h->fac.recB.size() || f.scanWp.size() != h->fac.scanWp.size())
     return fail(ADMM_ERR_NUMERIC, "internal: record sizes changed on refactor");
+  if (h->auto_segments && h->S > 1 && scan_growth(f) > SCAN_GROWTH_MAX)
+    return fail(ADMM_ERR_NUMERIC, "problem update refused: the new dynamics make the segment transfer matrices of the handle's " +
+                                      std::to_string(h->S) + " segments grow beyond the conditioning bound (max |W| > 100); "
+                                      "set up a new handle (fewer segments are chosen then) or give options.segments");
   if ((rc = ensure_w(h))) return rc;           // w of the last x-update belongs to the old problem data
   if ((rc = ensure_zy(h))) return rc;          // the state is kept as the (z, y) pair it was under the old box
   h->zy_valid = true;
@@ -867,6 +886,10 @@ int admm_set_state(admm_handle* h, const double* w, const double* z, const doubl
   if (!h) return fail(ADMM_ERR_INVALID, "NULL handle");
   HIP_TRY(hipSetDevice(h->device));
   int rc;
+  // the device code is compiled with -fno-honor-nans on the premise that nothing non-finite gets in
+  const size_t cnt = (size_t)h->L * h->batch;
+  if ((w && !finite_all(w, cnt)) || (z && !finite_all(z, cnt)) || (y && !finite_all(y, cnt)))
+    return fail(ADMM_ERR_INVALID, "non-finite entry in w, z or y");
   if (w) {
     if ((rc = upload_transposed(h, w, h->w, h->L))) return rc;
     h->w_stale = false;
@@ -1058,6 +1081,10 @@ int admm_solve_adapt(admm_handle* h, double R, double S, int32_t* changed) {
   else if (S > mu2 * R) rho_new = h->opt.rho / h->opt.adapt_tau;
   if (rho_new != h->opt.rho) {
     int rc = set_rho_internal(h, rho_new);
+    if (rc == ADMM_ERR_NUMERIC) {          // refused (conditioning guard / factorisation): keep rho, stop adapting
+      h->rho_updates = h->opt.adapt_max;
+      return ADMM_OK;
+    }
     if (rc) return rc;
     ++h->rho_updates;
     if (changed) *changed = 1;

@@ -3,8 +3,9 @@
 QP instances do not interact, so the partition is a contiguous slice of the
 batch per rank and the iteration needs NO collective: each rank runs the 1-GPU
 path on its slice.  RCCL (torch.distributed backend "nccl") is used only for
-the optional global stop decision (one MAX all-reduce of two doubles per check)
-and for gathering per-QP results; both are off the hot loop.
+the global stop / adaptive-rho decision of solve_sharded (ONE all-reduce, SUM,
+of three doubles per checked iteration: QPs still unconverged, sum r^2, sum
+s^2) and for gathering per-QP results; both are off the hot loop.
 """
 from __future__ import annotations
 
@@ -49,8 +50,9 @@ def gather_batch(local, batch: int, group=None):
 
 
 def global_residual_max(r_max: float, s_max: float, device="cpu", group=None):
-    """One MAX all-reduce of two doubles: the global stop decision of a sharded
-    solve.  Latency-bound, once per convergence check."""
+    """Helper for callers that only want the worst residual pair of the whole batch (reporting):
+    one MAX all-reduce of two doubles.  solve_sharded does NOT use it -- its stop decision is the
+    3-double SUM described there."""
     import torch
     import torch.distributed as dist
     t = torch.tensor([r_max, s_max], dtype=torch.float64, device=device)

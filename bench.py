@@ -62,6 +62,13 @@ def parse():
                          "shape (n=12, m=6) in fp64 -- a side measurement, never the reported metric's config")
     ap.add_argument("--segments", type=int, default=0)
     ap.add_argument("--zrows", type=int, default=0)
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="timed blocks of --steps steps each; the median block is reported (all blocks are listed)")
+    ap.add_argument("--warm-seconds", type=float, default=0.6,
+                    help="after the --warmup steps, keep iterating until at least this much wall time has been spent "
+                         "warming up, so that the timed region runs at steady clocks however small --warmup is")
+    ap.add_argument("--profile-launches", type=int, default=200,
+                    help="launches of each kernel averaged by the HIP-event per-kernel timing (admm_profile)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
@@ -107,13 +114,45 @@ def cpu_baseline(N, target_s):
                       f"residuals every iteration, {dt:.1f} s"}
 
 
+def launch_ranks(a):
+    """`python bench.py --gpus N` without an external launcher: spawn the N ranks ourselves, as fresh child
+    processes created BEFORE anything in this process touches the GPU (never an exec of a process that has),
+    one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment exactly as
+    torch.distributed.run would set them.  Rank 0's JSON line is this process's stdout."""
+    import socket
+    import subprocess
+    import torch
+    backend = os.environ.get("ADMM_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()           # counting devices does not initialise the GPU on this image
+    if backend == "nccl" and ndev < a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but only {ndev} GPU(s) visible: refusing to report a "
+                         f"{a.gpus}-GPU figure from fewer devices")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    raise SystemExit(rc)
+
+
 def main():
     a = parse()
+    if a.gpus < 1 or a.steps < 1 or a.repeats < 1:
+        raise SystemExit("bench.py: --gpus, --steps, --repeats must be >= 1")
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        launch_ranks(a)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and world > 1:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: one rank per GPU, launch with "
+                         f"--nproc-per-node {a.gpus} (or leave WORLD_SIZE unset and bench.py spawns the ranks itself)")
     import numpy as np
     import torch
     import admm_library_amd as pkg
@@ -125,10 +164,18 @@ def main():
     if pkg.device_count() < 1:
         raise SystemExit("bench.py: no HIP device visible; the solver has no CPU fallback")
 
+    # The CPU baseline runs FIRST (rank 0, N = 1 only): ~15 s of host work between the GPU legs would leave the
+    # GPU at idle clocks for whatever is timed next (r01: the driver's 3.3 ms timed region ran on a 0.8 %-busy GPU).
+    cpu_base = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu_base = cpu_baseline(a.horizon, a.cpu_seconds)
+
     # One process per GPU.  ADMM_BENCH_BACKEND=gloo (+ several ranks sharing one GPU) exists only to
     # rehearse the N > 1 code path on a 1-GPU box; the driver's runs use RCCL ("nccl").
     backend = os.environ.get("ADMM_BENCH_BACKEND", "nccl")
     ndev = torch.cuda.device_count()
+    if backend == "nccl" and ndev < world:
+        raise SystemExit(f"bench.py: {world} ranks but only {ndev} GPU(s) visible (backend nccl needs one GPU per rank)")
     dev_index = local_rank % max(ndev, 1) if backend != "nccl" else local_rank
     dist = None
     if world > 1:
@@ -146,6 +193,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=red_device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     # global problem = batch * world QPs; this rank's contiguous shard
     gbatch = a.batch * world
     lo_i, hi_i = pkg.shard_bounds(gbatch, world, rank)
@@ -158,25 +212,37 @@ def main():
     solver = pkg.Solver(full, opt)
     geo = solver.geometry()
 
-    solver.run(a.warmup, residual_every=1)
-    barrier()
-    t0 = time.perf_counter()
-    solver.run(a.steps, residual_every=1, sync=True)
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=red_device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    def warm(sv, seconds, every=1):
+        """steady clocks: iterate until `seconds` of wall time have gone by (the state simply keeps converging)"""
+        t_end = time.perf_counter() + seconds
+        while time.perf_counter() < t_end:
+            sv.run(200, residual_every=every, sync=True)
+
+    def timed_blocks(sv, every):
+        """`repeats` blocks of EXACTLY --steps steps, each bracketed by barrier + synchronize on both sides and
+        reduced with MAX over the ranks; returns the per-block seconds."""
+        out = []
+        for _ in range(a.repeats):
+            barrier()
+            t0 = time.perf_counter()
+            sv.run(a.steps, residual_every=every, sync=True)
+            barrier()
+            out.append(max_over_ranks(time.perf_counter() - t0))
+        return out
+
+    solver.run(a.warmup, residual_every=1)          # the W untimed warmup steps ...
+    warm(solver, a.warm_seconds)                    # ... and then by time, whatever W was
+    blocks = timed_blocks(solver, 1)
+    dt = float(np.median(blocks))
 
     ms_per_step = dt / a.steps * 1e3
     value = gbatch * a.steps / dt
 
     # per-kernel timing on the library's stream (HIP events)
-    npf = min(a.steps, 100)
+    npf = max(1, min(a.profile_launches, 4096))     # launches of each kernel, regardless of --steps
     try:
-        prof_alt = solver.profile(max(1, npf // 2), residuals=True, alternating=True)     # the timed path
-        prof_alt_plain = solver.profile(max(1, npf // 2), residuals=False, alternating=True)
+        prof_alt = solver.profile(npf, residuals=True, alternating=True)     # the timed path (npf PAIRS of iterations)
+        prof_alt_plain = solver.profile(npf, residuals=False, alternating=True)
     except pkg.AdmmError:                          # no alternating kernels for this shape: the plain kernels are timed
         prof_alt = prof_alt_plain = None
     prof = solver.profile(npf, residuals=True, fused=True)           # plain fused path (the timed path without alternation)
@@ -243,24 +309,14 @@ def main():
         with pkg.Solver(full, pkg.Options(rho=0.05, check_interval=1, segments=a.segments, zrows=a.zrows, device=dev_index,
                                           flags=_abi.FLAG_NO_ALTERNATE)) as sp:
             sp.run(a.warmup, residual_every=1)
-            barrier()
-            t0 = time.perf_counter()
-            sp.run(a.steps, residual_every=1, sync=True)
-            dtp = time.perf_counter() - t0
+            warm(sp, 0.5 * a.warm_seconds)
+            dtp = float(np.median(timed_blocks(sp, 1)))
         plain_path = {"batch_iterations_per_s": a.steps / dtp, "ms_per_step": dtp / a.steps * 1e3,
                       "iteration_bytes_per_element": b_xb + b_xfz, "roofline_xfz": roofline_xfz}
 
     # mixed mode a solver would normally run: residuals every 10th iteration
-    solver.run(10, residual_every=10)
-    barrier()
-    t0 = time.perf_counter()
-    solver.run(a.steps, residual_every=10, sync=True)
-    barrier()
-    dt10 = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt10], dtype=torch.float64, device=red_device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt10 = float(t.item())
+    warm(solver, 0.25 * a.warm_seconds, every=10)
+    dt10 = float(np.median(timed_blocks(solver, 10)))
 
     # iterations-to-epsilon (second half of BASELINE.json's metric; "vs MATLAB" -> vs the CPU oracle):
     # a full admm_solve of this rank's shard to eps_abs = eps_rel = 1e-6, stop test every 10 iterations,
@@ -302,6 +358,9 @@ def main():
             "value": value, "unit": "QP-iterations/s",
             "batch_iterations_per_s": a.steps / dt,
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
+            "repeats": a.repeats, "ms_per_step_blocks": [b / a.steps * 1e3 for b in blocks],
+            "timing": (f"median of {a.repeats} blocks of exactly {a.steps} steps, each bracketed by barrier + "
+                       f"synchronize and reduced with MAX over ranks; warm-up = {a.warmup} steps + {a.warm_seconds} s"),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": (f"configs[2]: batch of {a.batch} independent N={a.horizon} n=6 m=3 "
@@ -329,8 +388,8 @@ def main():
             "check_interval_10": {"batch_iterations_per_s": a.steps / dt10,
                                   "QP_iterations_per_s": gbatch * a.steps / dt10},
         }
-        if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(a.horizon, a.cpu_seconds)
+        if cpu_base is not None:
+            out["cpu_baseline"] = cpu_base
         print(json.dumps(out))
     if solver is not None:
         solver.close()

@@ -136,7 +136,11 @@ int admm_update_instances(admm_handle* h, const double* x0, const double* q);
 
 /* Change rho on an existing handle: refactors the KKT system on the host, re-uploads the
  * records and rescales the scaled dual (y *= rho_old / rho_new) so that the unscaled multiplier
- * rho y is unchanged. */
+ * rho y is unchanged.  If the handle's segment count was chosen by admm_setup (options.segments = 0), the
+ * conditioning bound applied there (largest entry of the segment-scan matrix <= 100) is re-checked on the new
+ * factor: a rho that breaks it is refused with ADMM_ERR_NUMERIC and the handle is unchanged (the segment count
+ * of a live handle is frozen).  The adaptive rule of admm_solve treats such a refusal as "keep rho and stop
+ * adapting". */
 int admm_set_rho(admm_handle* h, double rho);
 
 /* New shared problem data on an existing handle: dynamics, weights, box, thrust-magnitude bounds, x0 and
@@ -144,11 +148,12 @@ int admm_set_rho(admm_handle* h, double rho);
  * bound present iff one was).  The KKT system is refactored with the current rho and segment count and
  * everything re-uploaded; device buffers, the state (kept as the (z, y) pair) and per-QP results are left
  * alone.  This is what a successive-convexification caller does between outer iterations instead of
- * admm_free + admm_setup.  On failure the handle is unchanged. */
+ * admm_free + admm_setup.  The conditioning bound of admm_set_rho applies here too.  On failure the handle is
+ * unchanged. */
 int admm_update_problem(admm_handle* h, const admm_problem* p);
 
 /* Warm start / test hook: overwrite device state.  Any pointer may be NULL
- * (left unchanged).  Each is L*batch. */
+ * (left unchanged).  Each is L*batch and must be finite (ADMM_ERR_INVALID otherwise, nothing uploaded). */
 int admm_set_state(admm_handle* h, const double* w, const double* z, const double* y);
 
 /* Run until every QP met the rule at a checked iteration, or max_iter.

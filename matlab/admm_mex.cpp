@@ -23,6 +23,7 @@
 // (m+n) x N) are passed by pointer, no copies.
 #include <cstdint>
 #include <cstring>
+#include <vector>
 
 #include "mex.h"
 
@@ -61,18 +62,25 @@ admm_handle* handle_of(const mxArray* a) {
   return h;
 }
 
-// sizes remembered per handle so that 'get' can size its outputs
+// sizes remembered per handle so that 'get' can size its outputs.  Unbounded (a vector, freed slots are
+// reused); every handle still alive when MATLAB clears the MEX file or exits is released by at_exit().
 struct Dims { admm_handle* h; int L, batch; };
-Dims g_dims[64];
-int g_ndims = 0;
+std::vector<Dims> g_dims;
+bool g_at_exit_registered = false;
+
+void at_exit() {
+  for (Dims& d : g_dims)
+    if (d.h) { admm_free(d.h); d.h = nullptr; }
+  g_dims.clear();
+}
 
 void remember(admm_handle* h, int L, int batch) {
-  for (int i = 0; i < g_ndims; ++i) if (!g_dims[i].h) { g_dims[i] = {h, L, batch}; return; }
-  if (g_ndims < 64) g_dims[g_ndims++] = {h, L, batch};
-  else fail("admm:limit", "too many live handles (64)");
+  if (!g_at_exit_registered) { mexAtExit(at_exit); g_at_exit_registered = true; }
+  for (Dims& d : g_dims) if (!d.h) { d = {h, L, batch}; return; }
+  g_dims.push_back({h, L, batch});
 }
 Dims* lookup(admm_handle* h) {
-  for (int i = 0; i < g_ndims; ++i) if (g_dims[i].h == h) return &g_dims[i];
+  for (Dims& d : g_dims) if (d.h == h) return &d;
   fail("admm:input", "unknown handle");
   return nullptr;
 }

@@ -1,0 +1,78 @@
+"""Guards on a live handle: non-finite warm starts are refused, and a refactor (admm_set_rho,
+the adaptive rule, admm_update_problem) re-checks the conditioning bound that admm_setup applied when it
+chose the segment count."""
+import numpy as np
+import pytest
+
+import admm_library_amd as pkg
+import oracle_c as oc
+from admm_library_amd import _abi
+
+pytestmark = pytest.mark.gpu
+
+
+def _code(name):
+    return {v: k for k, v in _abi.STATUS_NAMES.items()}[name]
+
+
+@pytest.mark.parametrize("which", ["w", "z", "y"])
+@pytest.mark.parametrize("bad", [np.nan, np.inf, -np.inf])
+def test_set_state_rejects_non_finite(gpu, which, bad):
+    p = pkg.cw_rendezvous(N=40, batch=5)
+    with pkg.Solver(p, pkg.Options(rho=0.05)) as s:
+        s.iterate(3)
+        w0, z0, y0 = s.get()
+        a = np.zeros((p.batch, p.L))
+        a[3, 17] = bad
+        with pytest.raises(pkg.AdmmError) as e:
+            s.set_state(**{which: a})
+        assert e.value.code == _code("ADMM_ERR_INVALID")
+        if which != "w":                           # the warm start of admm_solve goes through the same check
+            with pytest.raises(pkg.AdmmError):
+                s.solve(**{which + "0": a})
+        w1, z1, y1 = s.get()                       # the handle's state is untouched
+        for a0, a1 in ((w0, w1), (z0, z1), (y0, y1)):
+            np.testing.assert_array_equal(a0, a1)
+
+
+def _rho_sensitive_plant(batch=3):
+    """Unstable plant, no state cost: the closed loop does not depend on rho, but the segment transfer matrix
+    Xi ~ 1 / rho, so max |W| = 2.48 at rho = 0.1 and 2.5e3 at rho = 1e-4 (tests/test_host.py has the host check)."""
+    n, m, N = 2, 1, 64
+    A = np.array([[1.3, 1.0], [0.0, 1.3]])
+    B = np.array([[0.0], [1.0]])
+    rng = np.random.default_rng(7)
+    return pkg.Problem(N=N, A=A, B=B, Q=np.zeros((n, n)), R=1e-9 * np.eye(m), QN=np.zeros((n, n)),
+                       x0=rng.standard_normal((batch, n)), lo=np.r_[-0.5, -np.inf, -np.inf], hi=np.r_[0.5, np.inf, np.inf])
+
+
+def test_set_rho_rechecks_the_conditioning_bound(gpu):
+    p = _rho_sensitive_plant()
+    with pkg.Solver(p, pkg.Options(rho=0.1)) as s:
+        assert s.geometry()["segments"] > 1
+        s.iterate(5)
+        with pytest.raises(pkg.AdmmError) as e:
+            s.set_rho(1e-4)                         # max |W| would be 2.5e3 with the handle's frozen segment count
+        assert e.value.code == _code("ADMM_ERR_NUMERIC") and "segment" in str(e.value)
+        s.iterate(5)                                # the handle is unchanged and keeps iterating at rho = 0.1
+        w, z, y = s.get()
+    ref = oc.solve(p, rho=0.1, max_iter=10, stop=False)
+    assert np.abs(z - ref["z"]).max() <= 1e-10 and np.abs(w - ref["w"]).max() <= 1e-10
+    # a fixed segment count is the caller's responsibility: no guard, the change goes through
+    with pkg.Solver(p, pkg.Options(rho=0.1, segments=4)) as s:
+        s.set_rho(1e-4)
+    # set up at the small rho, the automatic choice backs off to fewer segments by itself
+    with pkg.Solver(p, pkg.Options(rho=1e-4)) as s:
+        assert s.geometry()["segments"] == 1
+
+
+def test_adaptive_rule_stops_adapting_when_a_change_is_refused(gpu):
+    """The adaptive rule wants rho lower than the conditioning bound allows: the solve keeps the last admissible
+    rho (and stops adapting) instead of failing or running an ill-conditioned factor."""
+    p = _rho_sensitive_plant()
+    opt = pkg.Options(rho=0.1, max_iter=400, check_interval=10, adapt_interval=10, adapt_mu=1.0001, adapt_tau=10.0,
+                      eps_abs=1e-12, eps_rel=1e-12)
+    with pkg.Solver(p, opt) as s:
+        info = s.solve()
+        assert np.isfinite(s.get()[0]).all()
+    assert info.rho >= 5e-3          # 0.1 -> 0.01 is admissible (max |W| = 24.8); 1e-3 (248) is refused

@@ -59,3 +59,46 @@ def test_two_rank_sharded_solve_equals_unsharded(gpu, tmp_path, adapt):
     assert float(got["rho"]) == ref["rho"]
     assert (np.abs(got["iters"] - ref["iters"]) <= 10).all()
     assert np.abs(got["z"] - ref["z"]).max() <= 1e-10
+
+
+def _nccl_worker(rank, world, port, out_dir):
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    import admm_library_amd as pkg
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    batch = 21
+    full = pkg.cw_rendezvous(N=120, batch=batch)
+    shard = pkg.shard_problem(full, world, rank)
+    opt = pkg.Options(rho=0.05, eps_abs=1e-6, eps_rel=1e-6, max_iter=3000, check_interval=10, device=0, adapt_interval=20)
+    with pkg.Solver(shard, opt) as s:
+        info = pkg.solve_sharded(s, batch, device="cuda:0")          # the 3-double all-reduce runs over RCCL
+        _, z, _ = s.get(False, True, False)
+    zf = pkg.gather_batch(torch.from_numpy(z).to("cuda:0"), batch)  # all_gather of CUDA tensors over RCCL
+    itf = pkg.gather_batch(torch.from_numpy(info.iters).to("cuda:0"), batch)
+    r2, s2 = pkg.global_residual_max(float(info.max_r), float(info.max_s), device="cuda:0")
+    dist.barrier()
+    torch.cuda.synchronize()
+    np.savez(os.path.join(out_dir, "nccl.npz"), z=zf.cpu().numpy(), iters=itf.cpu().numpy(), iters_run=info.iters_run,
+             rho=info.rho, r=r2, s=s2, max_r=info.max_r)
+    dist.destroy_process_group()
+
+
+def test_rccl_path_world_size_one(gpu, tmp_path):
+    """backend "nccl" (= RCCL) initialised for real, at the only world size a 1-GPU box allows: solve_sharded with
+    device="cuda:0" and gather_batch / global_residual_max on CUDA tensors -- the code path bench.py --gpus N and a
+    multi-GPU caller run, minus the second GPU.  Runs in a child process so RCCL's state dies with it."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import admm_library_amd as pkg
+    import oracle_c as oc
+    mp.spawn(_nccl_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    got = np.load(tmp_path / "nccl.npz")
+    ref = oc.solve(pkg.cw_rendezvous(N=120, batch=21), rho=0.05, eps_abs=1e-6, eps_rel=1e-6, max_iter=3000,
+                   check_interval=10, adapt_interval=20)
+    assert int(got["iters_run"]) == ref["iters_run"] and float(got["rho"]) == ref["rho"]
+    assert (np.abs(got["iters"] - ref["iters"]) <= 10).all()
+    assert np.abs(got["z"] - ref["z"]).max() <= 1e-10
+    assert float(got["r"]) == float(got["max_r"])
