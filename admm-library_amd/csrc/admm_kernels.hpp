@@ -291,22 +291,20 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_X_OCCUPANCY void xb_kernel(
         const double* rb = rec + (k - klo) * RB;     // wave-uniform address: LDS broadcast reads
         double mLO[even_up(NB)], mHI[even_up(NB)];
         double cs = 1.0;
-        bool soc = false;
         if (VFORM) {
           lds_block(rb + LB.LO, mLO);
           lds_block(rb + LB.HI, mHI);
-          if (SOC) {                                 // compiled only for problems with a thrust-magnitude bound
-            const double ub = rb[LB.UB];
-            soc = ub < INFINITY;                     // wave-uniform
-            if (soc) cs = soc_scale<NU, NB>(lz[j], ub);
-          }
+          // compiled only for problems with a thrust-magnitude bound.  Branch-free: ub = +inf (no bound at this
+          // stage) gives cs = 1 exactly, and where ub is finite the control rows' box is (-inf, inf), so
+          // clip(cs v_u) is the ball projection there and the box projection elsewhere (see xfze_kernel)
+          if (SOC) cs = soc_scale<NU, NB>(lz[j], rb[LB.UB]);
         }
         double g[NB];
 #pragma unroll
         for (int r = 0; r < NB; ++r) {
           double zz = lz[j][r], yy;
           if (VFORM) {
-            zz = (SOC && soc && r < NU) ? lz[j][r] * cs : fmin(fmax(lz[j][r], mLO[r]), mHI[r]);
+            zz = fmin(fmax((SOC && r < NU) ? lz[j][r] * cs : lz[j][r], mLO[r]), mHI[r]);
             yy = lz[j][r] - zz;
           } else {
             yy = ly[j][r];
@@ -942,33 +940,37 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_X_OCCUPANCY void xfz_kernel(
         // split into rollout | row | row | ... each region gets a latency-aware schedule.
         __builtin_amdgcn_sched_barrier(0);
         const unsigned r0 = (unsigned)(k - k0) * NB * PB;
-        const double ub = SOC ? rf[LF.UB] : INFINITY;
-        const bool soc = SOC && ub < INFINITY;   // wave-uniform: thrust-magnitude bound on this stage's control rows
+        // thrust-magnitude bound on this stage's control rows, branch-free: ub = +inf (no bound here) gives both
+        // factors = 1 exactly; where ub is finite the control rows' box is (-inf, inf) (see xfze_kernel)
         double cs_old = 1.0, cs_new = 1.0;
-        double vnew[NB];
-        if (SOC && soc) {
+        if constexpr (SOC) {
+          const double ub = rf[LF.UB];
           if (VIN) cs_old = soc_scale<NU, NB>(c0, ub);
           if (RESID) {                           // z+ needs ||v+_u||: form the control rows of v+ first
+            double vnew[NB];
 #pragma unroll
-            for (int r = 0; r < NU; ++r) {
-              double zo, yo;
-              if (VIN) { zo = c0[r] * cs_old; yo = c0[r] - zo; } else { yo = c0[r]; zo = NEEDZ ? c1[r] : 0.0; }
-              double wh = wv[r];
-              if (RELAX) wh = fma(alpha, wv[r], (1.0 - alpha) * zo);
-              vnew[r] = wh + yo;
+            for (int r = 0; r < NB; ++r) {
+              if (r < NU) {
+                double zo, yo;
+                if (VIN) { zo = fmin(fmax(c0[r] * cs_old, rf[LF.LO + r]), rf[LF.HI + r]); yo = c0[r] - zo; }
+                else { yo = c0[r]; zo = NEEDZ ? c1[r] : 0.0; }
+                double wh = wv[r];
+                if (RELAX) wh = fma(alpha, wv[r], (1.0 - alpha) * zo);
+                vnew[r] = wh + yo;
+              } else {
+                vnew[r] = 0.0;
+              }
             }
-#pragma unroll
-            for (int r = NU; r < NB; ++r) vnew[r] = 0.0;
             cs_new = soc_scale<NU, NB>(vnew, ub);
           }
         }
 #pragma unroll
         for (int r = 0; r < NB; ++r) {
           const double l = rf[LF.LO + r], h = rf[LF.HI + r];
-          const bool ball = SOC && soc && r < NU;
+          const bool ball = SOC && r < NU;
           double zo, yo;                       // state before this z-update
           if (VIN) {
-            zo = ball ? c0[r] * cs_old : fmin(fmax(c0[r], l), h);
+            zo = fmin(fmax(ball ? c0[r] * cs_old : c0[r], l), h);
             yo = c0[r] - zo;
           } else {
             yo = c0[r];
@@ -983,7 +985,7 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_X_OCCUPANCY void xfz_kernel(
           if (st) vv.store(vn, lb_st, r0 + r * PB);
 #endif
           if (RESID) {
-            const double zn = ball ? vn * cs_new : fmin(fmax(vn, l), h);
+            const double zn = fmin(fmax(ball ? vn * cs_new : vn, l), h);
             const double yn = vn - zn;
             const double dr = wv[r] - zn, ds = zn - zo;
             a_r = fma(dr, dr, a_r);

@@ -34,10 +34,11 @@ namespace admm {
 // register fit: 0 spills / no accumulator-register traffic on the operand ring, tools/alt_sweep.sh).
 // A macro, where defined, overrides the rule (A/B sweeps).
 //   prefetch depth (stages) and LDS operand pairs read ahead of their FMAs, forward / backward kernel
-constexpr int alt_pf_f(int nb, bool hasq) {
+constexpr int alt_pf_f(int nb, bool hasq, bool soc) {
 #ifdef ADMM_ALT_PF_F
   return ADMM_ALT_PF_F;
 #else
+  (void)soc;
   return (nb <= 9 && !hasq) ? 2 : 1;        // the q rows ride in the ring too
 #endif
 }
@@ -67,14 +68,17 @@ constexpr int alt_g_b(int nb) {
 // spends up to 512, parks the operand prefetch ring in accumulator registers and then serialises every
 // prefetch load behind an `s_waitcnt vmcnt(0)` + v_accvgpr_write (measured: 3x slower).  Blocks above
 // 14 rows (9 with q) do not fit 256 registers and take the 512 budget (the ring stays in arch VGPRs there).
-constexpr int alt_min_waves(int nb, bool hasq) {
+constexpr int alt_min_waves(int nb, bool hasq, bool soc) {
 #ifdef ADMM_ALT_MIN_WAVES
   return ADMM_ALT_MIN_WAVES;
 #else
-  return nb <= (hasq ? 9 : 14) ? 2 : 1;     // the q rows cost 2 nb registers per ring slot plus 2 nb live
+  // the q rows cost 2 nb registers per ring slot plus 2 nb live; q AND the thrust-magnitude bound together do not
+  // fit 256 registers at n + m = 9 (37 registers went to scratch): those forms take the 512 budget (about 30
+  // values parked in accumulator registers, no scratch)
+  return nb <= (hasq ? (soc ? 6 : 9) : (soc ? 12 : 14)) ? 2 : 1;
 #endif
 }
-#define ADMM_ALT_OCCUPANCY(NB_, HQ_) __attribute__((amdgpu_waves_per_eu(alt_min_waves(NB_, HQ_), 2)))
+#define ADMM_ALT_OCCUPANCY(NB_, HQ_, SOC_) __attribute__((amdgpu_waves_per_eu(alt_min_waves(NB_, HQ_, SOC_), 2)))
 
 // the alternating kernels are compiled for every (n, m) pair of admm_dims_g*.hip
 constexpr bool alt_dims(int nx, int nu) { return nx >= 1 && nu >= 1; }
@@ -102,7 +106,7 @@ __device__ __forceinline__ double scan_row(const double* base, size_t o, int nsp
 // and on exit mu -> mseg[s], eb -> ebseg[s].
 // ---------------------------------------------------------------------------
 template <int NX, int NU, bool RESID, bool RELAX, bool HASQ, bool SOC>
-__global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY(NX + NU, HASQ) void xfze_kernel(
+__global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY(NX + NU, HASQ, SOC) void xfze_kernel(
     const double* __restrict__ dbuf, const double* __restrict__ tin, const double* __restrict__ xin,
     const double* __restrict__ recFE, const int* __restrict__ seg_start_, const double* __restrict__ q,
     double* __restrict__ v,
@@ -111,7 +115,7 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY(NX + NU, HASQ) void 
   constexpr int NB = NX + NU;
   constexpr RecFELayout LF = rec_fe_layout(NX, NU);
   constexpr int RF = LF.SIZE;
-  constexpr int PF = alt_pf_f(NB, HASQ);
+  constexpr int PF = alt_pf_f(NB, HASQ, SOC);
   constexpr int ALT_G = alt_g_f(NB);
   constexpr int CH = stage_chunk(RF, PF);
   __shared__ __attribute__((aligned(16))) double rec[CH * RF];
@@ -206,40 +210,51 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY(NX + NU, HASQ) void 
         }
         __builtin_amdgcn_sched_barrier(0);
         // ---- z-update, dual ascent, residual partials; g = linear term of the next x-update ----
-        double mLO[even_up(NB)], mHI[even_up(NB)], g[NB];
-        lds_block(rf + LF.LO, mLO);
-        lds_block(rf + LF.HI, mHI);
+        // the box of the block: read as two 16-byte-pair blocks up front -- except in the SOC forms, whose two
+        // ball-projection factors (sqrt + division each) keep every row live at once: there the 4 (n + m) registers
+        // of the box are what pushed the kernel into scratch, and each row reads its own bounds instead
+        double mLO[SOC ? 2 : even_up(NB)], mHI[SOC ? 2 : even_up(NB)], g[NB];
+        if constexpr (!SOC) {
+          lds_block(rf + LF.LO, mLO);
+          lds_block(rf + LF.HI, mHI);
+        }
         const unsigned r0 = (unsigned)(k - k0) * NB * PB;
         // thrust-magnitude bound on this stage's control rows (SOC forms only): the two
-        // ball-projection factors, of the old state and of v+ (soc is wave-uniform)
+        // ball-projection factors, of the old state and of v+.  BRANCH-FREE: a stage without the bound carries
+        // ub = +inf, for which both factors are exactly 1 (norm > inf is false), and where the bound is finite the
+        // box of the control rows is (-inf, inf) (validated at setup), so  z_u = clip(c v_u, lo, hi)  is the ball
+        // projection in the one case and the box projection in the other, bit for bit.  (The first version branched
+        // on the wave-uniform `ub < inf`: every row of the block then stayed live across the branch and the two
+        // sqrt / division sequences inside it, and the kernels went to scratch at most shapes.)
         double cs_old = 1.0, cs_new = 1.0;
-        bool soc = false;
-        if (SOC) {
+        if constexpr (SOC) {
           const double ub = rf[LF.UB];
-          soc = ub < INFINITY;
-          if (soc) {
-            cs_old = soc_scale<NU, NB>(c0, ub);
-            double vnu[NB];
+          cs_old = soc_scale<NU, NB>(c0, ub);
+          double vnu[NB];
 #pragma unroll
-            for (int r = 0; r < NB; ++r) {
-              const double zo = c0[r] * cs_old, yo = c0[r] - zo;
+          for (int r = 0; r < NB; ++r) {
+            if (r < NU) {
+              const double zo = fmin(fmax(c0[r] * cs_old, rf[LF.LO + r]), rf[LF.HI + r]), yo = c0[r] - zo;
               double wh = wv[r];
               if (RELAX) wh = fma(alpha, wv[r], (1.0 - alpha) * zo);
-              vnu[r] = r < NU ? wh + yo : 0.0;
+              vnu[r] = wh + yo;
+            } else {
+              vnu[r] = 0.0;
             }
-            cs_new = soc_scale<NU, NB>(vnu, ub);
           }
+          cs_new = soc_scale<NU, NB>(vnu, ub);
         }
 #pragma unroll
         for (int r = 0; r < NB; ++r) {
-          const bool ball = SOC && soc && r < NU;
-          const double zo = ball ? c0[r] * cs_old : fmin(fmax(c0[r], mLO[r]), mHI[r]);
+          const bool ball = SOC && r < NU;
+          const double lo_r = SOC ? rf[LF.LO + r] : mLO[SOC ? 0 : r], hi_r = SOC ? rf[LF.HI + r] : mHI[SOC ? 0 : r];
+          const double zo = fmin(fmax(ball ? c0[r] * cs_old : c0[r], lo_r), hi_r);
           const double yo = c0[r] - zo;
           double wh = wv[r];
           if (RELAX) wh = fma(alpha, wv[r], (1.0 - alpha) * zo);
           const double vn = wh + yo;
           vv.store<ADMM_ALT_STORE_AUX>(vn, lb_st, r0 + r * PB);
-          const double zn = ball ? vn * cs_new : fmin(fmax(vn, mLO[r]), mHI[r]);
+          const double zn = fmin(fmax(ball ? vn * cs_new : vn, lo_r), hi_r);
           const double yn = vn - zn;
           g[r] = -rho * (zn - yn);
           if (HASQ) g[r] += cq[r];
@@ -308,7 +323,7 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY(NX + NU, HASQ) void 
 // and on exit t -> tseg[s], e -> eseg[s]: exactly what xb_kernel leaves for the plain scan.
 // ---------------------------------------------------------------------------
 template <int NX, int NU, bool RESID, bool RELAX, bool HASQ, bool SOC>
-__global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY(NX + NU, HASQ) void xbze_kernel(
+__global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY(NX + NU, HASQ, SOC) void xbze_kernel(
     const double* __restrict__ dbb, const double* __restrict__ min_, const double* __restrict__ xend,
     const double* __restrict__ recBE, const int* __restrict__ seg_start_, const double* __restrict__ q,
     double* __restrict__ v,
@@ -420,37 +435,37 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY(NX + NU, HASQ) void 
         // ---- z-update, dual ascent, residual partials ----
         double g[NB];
         const unsigned r0 = (unsigned)SIDX(k) * NB * PB;
-        double cs_old = 1.0, cs_new = 1.0;     // thrust-magnitude bound (see xfze_kernel)
-        bool soc = false;
-        if (SOC) {
+        double cs_old = 1.0, cs_new = 1.0;     // thrust-magnitude bound, branch-free (see xfze_kernel)
+        if constexpr (SOC) {
           const double ub = rb[LB.UB];
-          soc = ub < INFINITY;
-          if (soc) {
-            cs_old = soc_scale<NU, NB>(c0, ub);
-            double vnu[NB];
+          cs_old = soc_scale<NU, NB>(c0, ub);
+          double vnu[NB];
 #pragma unroll
-            for (int r = 0; r < NB; ++r) {
-              const double zo = c0[r] * cs_old, yo = c0[r] - zo;
+          for (int r = 0; r < NB; ++r) {
+            if (r < NU) {
+              const double zo = fmin(fmax(c0[r] * cs_old, rb[LB.LO + r]), rb[LB.HI + r]), yo = c0[r] - zo;
               double wh = wv[r];
               if (RELAX) wh = fma(alpha, wv[r], (1.0 - alpha) * zo);
-              vnu[r] = r < NU ? wh + yo : 0.0;
+              vnu[r] = wh + yo;
+            } else {
+              vnu[r] = 0.0;
             }
-            cs_new = soc_scale<NU, NB>(vnu, ub);
           }
+          cs_new = soc_scale<NU, NB>(vnu, ub);
         }
 #pragma unroll
         for (int r3 = 0; r3 < NB; r3 += 3) {
 #pragma unroll
           for (int r = r3; r < r3 + 3 && r < NB; ++r) {
-            const bool ball = SOC && soc && r < NU;
+            const bool ball = SOC && r < NU;
             const double lo = rb[LB.LO + r], hi = rb[LB.HI + r];
-            const double zo = ball ? c0[r] * cs_old : fmin(fmax(c0[r], lo), hi);
+            const double zo = fmin(fmax(ball ? c0[r] * cs_old : c0[r], lo), hi);
             const double yo = c0[r] - zo;
             double wh = wv[r];
             if (RELAX) wh = fma(alpha, wv[r], (1.0 - alpha) * zo);
             const double vn = wh + yo;
             vv.store<ADMM_ALT_STORE_AUX>(vn, lb_st, r0 + r * PB);
-            const double zn = ball ? vn * cs_new : fmin(fmax(vn, lo), hi);
+            const double zn = fmin(fmax(ball ? vn * cs_new : vn, lo), hi);
             const double yn = vn - zn;
             g[r] = -rho * (zn - yn);
             if (HASQ) g[r] += cq[r];

@@ -273,11 +273,14 @@ class Solver:
         _check(self._lib, self._lib.admm_get(self._h, *[dptr(o) for o in outs]))
         return tuple(outs)
 
-    def profile(self, iters: int, residuals: bool = True, fused: bool = True, alternating: bool = False):
+    def profile(self, iters: int, residuals: bool = True, fused: bool = True, alternating: bool = False,
+                back_to_back: bool = False):
         """Per-kernel HIP-event timings (ms).  alternating: `iters` PAIRS of the alternating-direction
-        iteration (forward form, backward form) instead of the plain kernels."""
+        iteration (forward form, backward form) instead of the plain kernels; with
+        back_to_back each of the pair's kernels is launched `iters` times in a row between two events
+        (admm_profile mode 3: no event-record bubble inside the averages)."""
         ms = np.zeros(6)
-        mode = 2 if alternating else int(bool(fused))
+        mode = (3 if back_to_back else 2) if alternating else int(bool(fused))
         _check(self._lib, self._lib.admm_profile(self._h, int(iters), int(bool(residuals)), mode, dptr(ms)))
         if alternating:
             return {"xscan_ms": ms[0], "xfze_ms": ms[1], "finalize_xscan_ms": ms[2], "xbze_ms": ms[3],

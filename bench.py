@@ -241,10 +241,13 @@ def main():
     # per-kernel timing on the library's stream (HIP events)
     npf = max(1, min(a.profile_launches, 4096))     # launches of each kernel, regardless of --steps
     try:
-        prof_alt = solver.profile(npf, residuals=True, alternating=True)     # the timed path (npf PAIRS of iterations)
-        prof_alt_plain = solver.profile(npf, residuals=False, alternating=True)
+        # the timed path.  Back-to-back mode: each kernel npf times in a row between two events (no event-record bubble
+        # inside the averages: they add up to the step time); the per-launch-bracketed figures are kept beside them.
+        prof_alt = solver.profile(npf, residuals=True, alternating=True, back_to_back=True)
+        prof_alt_bracketed = solver.profile(npf, residuals=True, alternating=True)
+        prof_alt_plain = solver.profile(npf, residuals=False, alternating=True, back_to_back=True)
     except pkg.AdmmError:                          # no alternating kernels for this shape: the plain kernels are timed
-        prof_alt = prof_alt_plain = None
+        prof_alt = prof_alt_plain = prof_alt_bracketed = None
     prof = solver.profile(npf, residuals=True, fused=True)           # plain fused path (the timed path without alternation)
     prof_plain = solver.profile(npf, residuals=False, fused=True)
     prof_unf = solver.profile(npf, residuals=True, fused=False)      # standalone z/dual kernel
@@ -375,6 +378,11 @@ def main():
             "roofline_zdual_standalone": standalone,
             "plain_path": plain_path,
             "kernels_ms": {"alternating_resid": None if prof_alt is None else {k: round(v, 5) for k, v in prof_alt.items()},
+                           "alternating_resid_event_per_launch": None if prof_alt_bracketed is None else
+                           {k: round(v, 5) for k, v in prof_alt_bracketed.items()},
+                           "measurement": (f"HIP events on the library's stream; alternating_*: {npf} consecutive launches of "
+                                           "each kernel between two events (admm_profile mode 3); *_event_per_launch: one "
+                                           "event pair per launch (each interval then includes an event-record bubble)"),
                            "alternating_plain": None if prof_alt_plain is None else {k: round(v, 5) for k, v in prof_alt_plain.items()},
                            "fused_resid": {k: round(v, 5) for k, v in prof.items()},
                            "fused_plain": {k: round(v, 5) for k, v in prof_plain.items()},

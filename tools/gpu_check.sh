@@ -19,7 +19,7 @@ if [ -n "$1" ]; then
   cd /tmp && export TMPDIR=/tmp
   rm -rf "$O/prof_stats" "$O/prof_fetch" "$O/prof_write"
   rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_stats" -- python3 "$R/bench.py" --steps 100 --warmup 10 --no-cpu-baseline > "$O/prof_stats.log" 2>&1 &&
-  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$O/prof_fetch" -- python3 "$R/bench.py" --steps 20 --warmup 2 --no-cpu-baseline > "$O/prof_fetch.log" 2>&1 &&
-  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$O/prof_write" -- python3 "$R/bench.py" --steps 20 --warmup 2 --no-cpu-baseline > "$O/prof_write.log" 2>&1 &&
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$O/prof_fetch" -- python3 "$R/bench.py" --steps 20 --warmup 2 --repeats 2 --profile-launches 40 --no-cpu-baseline > "$O/prof_fetch.log" 2>&1 &&
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$O/prof_write" -- python3 "$R/bench.py" --steps 20 --warmup 2 --repeats 2 --profile-launches 40 --no-cpu-baseline > "$O/prof_write.log" 2>&1 &&
   echo "profiles collected: python profiles/summarize.py $1 gpurun_out/prof_stats gpurun_out/prof_fetch gpurun_out/prof_write"
 fi
