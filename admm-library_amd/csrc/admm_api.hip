@@ -1174,12 +1174,12 @@ int admm_profile(admm_handle* h, int32_t iters, int32_t residuals, int32_t fused
   constexpr int NE = 6;     // events per iteration
   if ((fused_path == 2 || fused_path == 3) && !h->alt) return fail(ADMM_ERR_UNSUPPORTED, "the alternating-direction kernels are not enabled for this handle");
   if (fused_path == 3) {
-    // Back-to-back mode: each of the four kernels of an alternating pair is launched `iters` times IN A ROW between
-    // two events, so an average contains one dependent-launch boundary per kernel (as in the real iteration) and no
-    // event-record bubble per launch (mode 2's intervals each include one: +3..6 us per kernel, by which the per-kernel
-    // figures used to add up to more than the step time they are part of).  Re-running a fused kernel on its own
-    // output is not an ADMM iteration (same bytes, same instructions, meaningless numbers), so the state v is parked
-    // in the w buffer, restored afterwards, and one plain iteration makes the handle consistent again.
+    // Back-to-back mode: a cross-check of mode 2 that records NO event between launches.  The two fused kernels are
+    // launched as `iters` consecutive (xfze, xbze) pairs with no scan in between -- same bytes, same instructions and
+    // the same sweep alternation (each kernel starts on the rows the previous one has just written, which is worth
+    // ~9 %: re-running ONE of them in a row measured 157 us against 136 us) -- and each scan form `iters` times in a
+    // row.  Without the scans the numbers are not ADMM iterates, so the state v is parked in the w buffer, restored
+    // afterwards, and one plain iteration makes the handle consistent again.
     int rc3 = ADMM_OK;
     const bool res3 = residuals != 0;
     if (!h->v_valid) {
@@ -1195,12 +1195,16 @@ int admm_profile(admm_handle* h, int32_t iters, int32_t residuals, int32_t fused
     h->alt_state = admm_handle::ALT_NONE;
     rc3 = launch_xb(h, true);
     if (!rc3) rc3 = launch_xscan_mfma(h, false, false);
-    HIP_TRY(hipEventRecord(e3[0], h->stream));
-    for (int it = 0; it < iters && !rc3; ++it) rc3 = launch_x(h, admm::XKernel::XFZE, false, res3);
-    HIP_TRY(hipEventRecord(e3[1], h->stream));
+    if (!rc3) rc3 = launch_x(h, admm::XKernel::XFZE, false, res3);     // valid db / m_in / x_end for the first xbze
     if (!rc3) rc3 = launch_xscan_mfma(h, true, false);
+    if (!rc3) rc3 = launch_x(h, admm::XKernel::XBZE, false, res3);
+    HIP_TRY(hipEventRecord(e3[0], h->stream));
+    for (int it = 0; it < iters && !rc3; ++it) {
+      rc3 = launch_x(h, admm::XKernel::XFZE, false, res3);
+      if (!rc3) rc3 = launch_x(h, admm::XKernel::XBZE, false, res3);
+    }
+    HIP_TRY(hipEventRecord(e3[1], h->stream));
     HIP_TRY(hipEventRecord(e3[2], h->stream));
-    for (int it = 0; it < iters && !rc3; ++it) rc3 = launch_x(h, admm::XKernel::XBZE, false, res3);
     HIP_TRY(hipEventRecord(e3[3], h->stream));
     HIP_TRY(hipEventRecord(e3[4], h->stream));
     for (int it = 0; it < iters && !rc3; ++it) rc3 = launch_xscan_mfma(h, false, res3);
@@ -1218,13 +1222,14 @@ int admm_profile(admm_handle* h, int32_t iters, int32_t residuals, int32_t fused
     HIP_TRY(hipStreamSynchronize(h->stream));
     for (int v = 0; v < 6; ++v) ms[v] = 0.0;
     if (!rc3) {
-      const int pairs[4][2] = {{4, 5}, {0, 1}, {6, 7}, {2, 3}};   // scan (W), xfze, scan (WB), xbze
-      for (int v = 0; v < 4; ++v) {
-        float t = 0.f;
-        HIP_TRY(hipEventElapsedTime(&t, e3[pairs[v][0]], e3[pairs[v][1]]));
-        ms[v] = t / iters;
-        ms[5] += ms[v];
-      }
+      float tp = 0.f, ta = 0.f, tb = 0.f;
+      HIP_TRY(hipEventElapsedTime(&tp, e3[0], e3[1]));          // iters (xfze, xbze) pairs
+      HIP_TRY(hipEventElapsedTime(&ta, e3[4], e3[5]));          // iters scans (W)
+      HIP_TRY(hipEventElapsedTime(&tb, e3[6], e3[7]));          // iters scans (WB)
+      ms[0] = ta / iters;
+      ms[1] = ms[3] = 0.5 * tp / iters;                          // mean of the two fused kernels
+      ms[2] = tb / iters;
+      ms[5] = ms[0] + ms[1] + ms[2] + ms[3];
     }
     for (auto& e : e3) (void)hipEventDestroy(e);
     return rc3;

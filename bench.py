@@ -241,11 +241,12 @@ def main():
     # per-kernel timing on the library's stream (HIP events)
     npf = max(1, min(a.profile_launches, 4096))     # launches of each kernel, regardless of --steps
     try:
-        # the timed path.  Back-to-back mode: each kernel npf times in a row between two events (no event-record bubble
-        # inside the averages: they add up to the step time); the per-launch-bracketed figures are kept beside them.
-        prof_alt = solver.profile(npf, residuals=True, alternating=True, back_to_back=True)
-        prof_alt_bracketed = solver.profile(npf, residuals=True, alternating=True)
-        prof_alt_plain = solver.profile(npf, residuals=False, alternating=True, back_to_back=True)
+        # the timed path: one HIP-event pair around every launch (the fused kernels' intervals agree with rocprofv3's
+        # kernel durations within 1 %, profiles/r02a_*; the event-record bubbles fall into the short scan intervals).
+        # prof_alt_b2b is the cross-check without events between launches (admm_profile mode 3).
+        prof_alt = solver.profile(npf, residuals=True, alternating=True)
+        prof_alt_bracketed = solver.profile(npf, residuals=True, alternating=True, back_to_back=True)
+        prof_alt_plain = solver.profile(npf, residuals=False, alternating=True)
     except pkg.AdmmError:                          # no alternating kernels for this shape: the plain kernels are timed
         prof_alt = prof_alt_plain = prof_alt_bracketed = None
     prof = solver.profile(npf, residuals=True, fused=True)           # plain fused path (the timed path without alternation)
@@ -378,11 +379,13 @@ def main():
             "roofline_zdual_standalone": standalone,
             "plain_path": plain_path,
             "kernels_ms": {"alternating_resid": None if prof_alt is None else {k: round(v, 5) for k, v in prof_alt.items()},
-                           "alternating_resid_event_per_launch": None if prof_alt_bracketed is None else
+                           "alternating_resid_back_to_back": None if prof_alt_bracketed is None else
                            {k: round(v, 5) for k, v in prof_alt_bracketed.items()},
-                           "measurement": (f"HIP events on the library's stream; alternating_*: {npf} consecutive launches of "
-                                           "each kernel between two events (admm_profile mode 3); *_event_per_launch: one "
-                                           "event pair per launch (each interval then includes an event-record bubble)"),
+                           "measurement": (f"HIP events on the library's stream, {npf} launches of each kernel; alternating_*: one "
+                                           "event pair per launch (the intervals of the two fused kernels match rocprofv3's kernel "
+                                           "durations; the event-record bubbles fall into the scan intervals); *_back_to_back: "
+                                           "no events between launches -- consecutive (xfze, xbze) pairs, and each scan form in a "
+                                           "row (admm_profile mode 3): xfze_ms = xbze_ms = the pair's mean"),
                            "alternating_plain": None if prof_alt_plain is None else {k: round(v, 5) for k, v in prof_alt_plain.items()},
                            "fused_resid": {k: round(v, 5) for k, v in prof.items()},
                            "fused_plain": {k: round(v, 5) for k, v in prof_plain.items()},

@@ -212,11 +212,10 @@ int admm_get_info(admm_handle* h, int32_t* iters, int32_t* status, double* r, do
  * fused_path == 2 (the default alternating-direction path; ADMM_ERR_UNSUPPORTED if the
  * handle does not run it): `iters` PAIRS of iterations,
  *   ms = {xscan, xfze, xscan (+ finalise role), xbze, 0, whole pair}
- * fused_path == 3 (the same path, BACK-TO-BACK mode): each of the pair's four kernels is launched `iters` times in a
- * row between two events, so an average holds one dependent-launch boundary per kernel and no event-record bubble,
- *   ms = {xscan (W), xfze, xscan (WB) (+ finalise role), xbze, 0, sum of the four}
- * (re-running a fused kernel on its own output moves the same bytes through the same instructions but is not an ADMM
- * iteration: the state is parked, restored, and ONE plain iteration is applied to leave the handle consistent).
+ * fused_path == 3 (the same path, BACK-TO-BACK cross-check: no event between launches): `iters` consecutive
+ * (xfze, xbze) pairs without the scans, then each scan form `iters` times in a row,
+ *   ms = {xscan (W), mean of xfze and xbze, xscan (WB) (+ finalise role), the same mean, 0, sum of the four}
+ * (not ADMM iterates: the state is parked, restored, and ONE plain iteration is applied to leave the handle consistent).
  * xb = x-update backward sweep, xscan = segment scan, xf = forward rollout,
  * zdual = standalone fused z/dual/residual kernel, xfz = forward rollout fused
  * with z/dual/residual.  `residuals` selects the residual-evaluating kernel
