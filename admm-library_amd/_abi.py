@@ -12,7 +12,7 @@ import numpy as np
 
 from .problems import Problem
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 ADMM_OK = 0
 STATUS_NAMES = {0: "ADMM_OK", 1: "ADMM_ERR_INVALID", 2: "ADMM_ERR_UNSUPPORTED",
@@ -25,6 +25,10 @@ FLAG_UNFUSED = 2
 FLAG_SCAN_CHAIN = 4
 FLAG_NO_ALTERNATE = 8
 FLAG_GRAPH = 16
+
+PRECISION_FP64 = 0
+PRECISION_MIXED = 1
+PRECISION_FP64_MFMA = 2
 
 c_double_p = C.POINTER(C.c_double)
 c_int32_p = C.POINTER(C.c_int32)
@@ -43,13 +47,14 @@ class COptions(C.Structure):
                 ("eps_rel", C.c_double), ("max_iter", C.c_int32), ("check_interval", C.c_int32),
                 ("segments", C.c_int32), ("device", C.c_int32), ("zrows", C.c_int32),
                 ("flags", C.c_int32), ("adapt_interval", C.c_int32), ("adapt_max", C.c_int32),
-                ("adapt_mu", C.c_double), ("adapt_tau", C.c_double)]
+                ("adapt_mu", C.c_double), ("adapt_tau", C.c_double),
+                ("precision_mode", C.c_int32), ("reserved", C.c_int32)]
 
 
 class CInfo(C.Structure):
     _fields_ = [("iters_run", C.c_int32), ("n_converged", C.c_int32),
                 ("max_r", C.c_double), ("max_s", C.c_double), ("solve_ms", C.c_double),
-                ("rho", C.c_double), ("rho_updates", C.c_int32), ("reserved", C.c_int32)]
+                ("rho", C.c_double), ("rho_updates", C.c_int32), ("mixed_iters", C.c_int32)]
 
 
 def dptr(a):
@@ -95,8 +100,9 @@ def marshal_problem(p: Problem):
 
 def make_options(rho=0.1, alpha=1.0, eps_abs=1e-6, eps_rel=1e-6, max_iter=4000,
                  check_interval=10, segments=0, device=-1, zrows=0, flags=0,
-                 adapt_interval=0, adapt_max=16, adapt_mu=10.0, adapt_tau=2.0) -> COptions:
+                 adapt_interval=0, adapt_max=16, adapt_mu=10.0, adapt_tau=2.0, precision_mode=0) -> COptions:
     return COptions(rho=rho, alpha=alpha, eps_abs=eps_abs, eps_rel=eps_rel,
                     max_iter=max_iter, check_interval=check_interval, segments=segments,
                     device=device, zrows=zrows, flags=flags, adapt_interval=adapt_interval,
-                    adapt_max=adapt_max, adapt_mu=adapt_mu, adapt_tau=adapt_tau)
+                    adapt_max=adapt_max, adapt_mu=adapt_mu, adapt_tau=adapt_tau,
+                    precision_mode=precision_mode, reserved=0)

@@ -65,6 +65,16 @@ struct admm_handle {
   // alternating-direction iteration
   double *recFE = nullptr, *recBE = nullptr, *mvec = nullptr, *scanWpB = nullptr;
   int* scan_rangeB = nullptr;
+  // MFMA form of the fused kernels: fragment records, element size (0 = not in use), and whether
+  // launch_x currently routes to it (the fp64 refinement phase of a MIXED solve turns it off)
+  unsigned char *recMF = nullptr, *recMB = nullptr;
+  int mfma_elem = 0;
+  bool mfma_on = false;
+  bool alt_allowed = false;      // alternation permitted by the options / compiled kernels (before the precision mode)
+  // MIXED solve: phase 1 (fp32) checks the stopping rule with raised tolerances on scratch status arrays
+  bool mixed_phase1 = false;
+  int mixed_iters = 0;
+  int *status1 = nullptr, *iters1 = nullptr;
   bool alt = false;              // the alternating kernels exist for this problem and are enabled
   // what the last kernel left behind for the next x-update:
   //   ALT_NONE  nothing (the next iteration starts with xb_kernel)
@@ -114,6 +124,8 @@ admm::XLaunch xlaunch_of(const admm_handle* h) {
   const bool chain = (h->opt.flags & ADMM_FLAG_SCAN_CHAIN) != 0;     // the chain scan writes slab 0 only
   l.nsplit = chain ? 1 : h->scan_split;
   l.split_stride = (size_t)h->fac.scanM * h->pitch;
+  l.recMF = h->recMF; l.recMB = h->recMB;
+  l.mfma_elem = h->mfma_on ? h->mfma_elem : 0;
   return l;
 }
 
@@ -133,7 +145,14 @@ std::string supported_list() {
 }
 
 int launch_x(admm_handle* h, admm::XKernel k, bool a, bool b) {
-  if (!dispatch_x(xlaunch_of(h), k, a, b, false)) return fail(ADMM_ERR_UNSUPPORTED, "no x-update kernel for this (n, m)");
+  const admm::XLaunch l = xlaunch_of(h);
+  // MFMA form: the alternating pair (fp64 records) or the plain path's v-form kernels (fp32 records); every other
+  // kernel form -- (z, y)-input first iterations, read-out -- stays on the one-lane fp64 kernels (same arrays)
+  if (l.mfma_elem) {
+    const bool vform_ok = (k == admm::XKernel::XFZE || k == admm::XKernel::XBZE) || a;
+    if (vform_ok && admm::launch_mfma(l, k, b, false)) return ADMM_OK;
+  }
+  if (!dispatch_x(l, k, a, b, false)) return fail(ADMM_ERR_UNSUPPORTED, "no x-update kernel for this (n, m)");
   return ADMM_OK;
 }
 
@@ -147,6 +166,12 @@ admm::FinArgs fin_args(const admm_handle* h, int it, int nchunks) {
   fa.part = h->part; fa.resid = h->resid; fa.status = h->status; fa.iters = h->iters; fa.nconv = h->nconv;
   fa.rho = h->opt.rho; fa.eps_abs = h->opt.eps_abs; fa.eps_rel = h->opt.eps_rel; fa.sqrtL = std::sqrt((double)h->L);
   fa.nchunks = nchunks; fa.batch = h->batch; fa.it = it;
+  if (h->mixed_phase1 && it > 0) {              // fp32 phase of a MIXED solve: raised tolerances, scratch status
+    fa.eps_abs = std::max(fa.eps_abs, 1e-4);
+    fa.eps_rel = std::max(fa.eps_rel, 1e-4);
+    fa.status = h->status1;
+    fa.iters = h->iters1;
+  }
   return fa;
 }
 
@@ -335,6 +360,8 @@ int validate_options(const admm_options* o) {
   if (o->check_interval < 1) return fail(ADMM_ERR_INVALID, "check_interval must be >= 1");
   if (o->segments < 0 || o->zrows < 0) return fail(ADMM_ERR_INVALID, "segments / zrows must be >= 0");
   if (o->adapt_interval < 0 || o->adapt_max < 0) return fail(ADMM_ERR_INVALID, "adapt_interval / adapt_max must be >= 0");
+  if (o->precision_mode < 0 || o->precision_mode > 2) return fail(ADMM_ERR_INVALID, "precision_mode must be ADMM_PRECISION_FP64, _MIXED or _FP64_MFMA");
+  if (o->reserved != 0) return fail(ADMM_ERR_INVALID, "options.reserved must be 0");
   if (o->adapt_interval > 0) {
     if (o->adapt_interval % o->check_interval != 0)
       return fail(ADMM_ERR_INVALID, "adapt_interval must be a multiple of check_interval");
@@ -374,6 +401,16 @@ int validate_problem(const admm_problem* p) {
   return ADMM_OK;
 }
 
+// MIXED precision: fp32 = the fp32-MFMA kernels on the plain path; otherwise (the fp64 refinement
+// phase of admm_solve) the default fp64 kernels, alternation included.  Both forms share every device array; what an
+// alternating iteration left pending is dropped at the switch.
+void set_mixed_form(admm_handle* h, bool fp32) {
+  if (h->opt.precision_mode != ADMM_PRECISION_MIXED) return;
+  h->mfma_on = fp32;
+  h->alt = fp32 ? false : h->alt_allowed;
+  h->alt_state = admm_handle::ALT_NONE;
+}
+
 // Conditioning guard of the parallel-in-time form (see admm_setup): largest entry of the dense scan matrices.
 constexpr double SCAN_GROWTH_MAX = 100.0;
 double scan_growth(const admm::Factor& f) {
@@ -398,7 +435,9 @@ void release(admm_handle* h) {
                      &h->recFE, &h->recBE, &h->mvec, &h->scanWpB};
   for (auto b : bufs)
     if (*b) { (void)hipFree(*b); *b = nullptr; }
-  int** ibufs[] = {&h->seg_start, &h->status, &h->iters, &h->nconv, &h->scan_range, &h->scan_rangeB};
+  if (h->recMF) { (void)hipFree(h->recMF); h->recMF = nullptr; }
+  if (h->recMB) { (void)hipFree(h->recMB); h->recMB = nullptr; }
+  int** ibufs[] = {&h->seg_start, &h->status, &h->iters, &h->nconv, &h->scan_range, &h->scan_rangeB, &h->status1, &h->iters1};
   for (auto b : ibufs)
     if (*b) { (void)hipFree(*b); *b = nullptr; }
   if (h->h_nconv) { (void)hipHostFree(h->h_nconv); h->h_nconv = nullptr; }
@@ -440,8 +479,12 @@ int upload_factor(admm_handle* h) {
   HIP_TRY(hipMemcpy(h->scanWp, h->fac.scanWp.data(), sizeof(double) * h->fac.scanWp.size(), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(h->scan_range, h->fac.scanRange.data(), sizeof(int32_t) * h->fac.scanRange.size(), hipMemcpyHostToDevice));
   h->alt_state = admm_handle::ALT_NONE;
-  if (h->alt && !h->fac.alt_ok) h->alt = false;            // the forward-elimination form did not survive the refactor
-  if (h->alt) {
+  if (!h->fac.alt_ok) { h->alt = false; h->alt_allowed = false; }   // the forward-elimination form did not survive the refactor
+  if (h->mfma_elem) {
+    HIP_TRY(hipMemcpy(h->recMF, h->fac.recMF.data(), h->fac.recMF.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->recMB, h->fac.recMB.data(), h->fac.recMB.size(), hipMemcpyHostToDevice));
+  }
+  if (h->alt_allowed) {
     HIP_TRY(hipMemcpy(h->recFE, h->fac.recFE.data(), sizeof(double) * h->fac.recFE.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->recBE, h->fac.recBE.data(), sizeof(double) * h->fac.recBE.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->scanWpB, h->fac.scanWpB.data(), sizeof(double) * h->fac.scanWpB.size(), hipMemcpyHostToDevice));
@@ -511,6 +554,8 @@ void admm_default_options(admm_options* o) {
   o->adapt_max = 16;
   o->adapt_mu = 10.0;
   o->adapt_tau = 2.0;
+  o->precision_mode = ADMM_PRECISION_FP64;
+  o->reserved = 0;
 }
 
 const char* admm_last_error(void) { return g_err.c_str(); }
@@ -579,6 +624,28 @@ int admm_host_factor_alt(const admm_problem* p, double rho, int32_t segments, do
   if (recFE) std::memcpy(recFE, f.recFE.data(), sizeof(double) * f.recFE.size());
   if (recBE) std::memcpy(recBE, f.recBE.data(), sizeof(double) * f.recBE.size());
   if (WB) std::memcpy(WB, f.scanWB.data(), sizeof(double) * f.scanWB.size());
+  return ADMM_OK;
+}
+
+int admm_mfma_record_bytes(int32_t n, int32_t m, int32_t elem_bytes, int32_t* fwd, int32_t* bwd) {
+  if (!admm::mfma_dims(n, m)) return fail(ADMM_ERR_UNSUPPORTED, "the MFMA form needs 1 <= n <= 12 and 1 <= m <= 8");
+  if (elem_bytes != 4 && elem_bytes != 8) return fail(ADMM_ERR_INVALID, "elem_bytes must be 4 or 8");
+  if (fwd) *fwd = admm::mfma_rec_bytes_fwd(n, m, elem_bytes);
+  if (bwd) *bwd = admm::mfma_rec_bytes_bwd(n, m, elem_bytes);
+  return ADMM_OK;
+}
+
+int admm_host_factor_mfma(const admm_problem* p, double rho, int32_t segments, int32_t elem_bytes, void* recMF,
+                          void* recMB, int32_t* alt_ok) {
+  if (!p) return fail(ADMM_ERR_INVALID, "NULL problem");
+  if (elem_bytes != 4 && elem_bytes != 8) return fail(ADMM_ERR_INVALID, "elem_bytes must be 4 or 8");
+  admm::Factor f;
+  std::string err;
+  int rc = admm::factorise(*p, rho, segments, f, err, elem_bytes);
+  if (rc) return fail(rc, err);
+  if (recMF) std::memcpy(recMF, f.recMF.data(), f.recMF.size());
+  if (recMB) std::memcpy(recMB, f.recMB.data(), f.recMB.size());
+  if (alt_ok) *alt_ok = f.alt_ok ? 1 : 0;
   return ADMM_OK;
 }
 
@@ -659,8 +726,23 @@ int admm_setup(admm_handle** out, const admm_problem* p, const admm_options* o_i
     h->zchunks = (h->L + zr - 1) / zr;
   }
 
+  // precision mode: the MFMA forms exist for a few (n, m), without q / thrust-magnitude bound
+  if (o.precision_mode != ADMM_PRECISION_FP64) {
+    admm::XLaunch lq{};
+    lq.n = p->n; lq.m = p->m;
+    lq.mfma_elem = o.precision_mode == ADMM_PRECISION_MIXED ? 4 : 8;
+    const bool compiled = admm::mfma_dims(p->n, p->m) &&
+                          admm::launch_mfma(lq, o.precision_mode == ADMM_PRECISION_MIXED ? admm::XKernel::XFZ : admm::XKernel::XFZE, false, true);
+    std::string why;
+    if (!compiled) why = "(n, m) has no MFMA instantiation; compiled: " + std::string(admm::dims_mfma());
+    else if (h->has_q) why = "a linear term q is not supported by the MFMA forms";
+    else if (h->has_soc) why = "a thrust-magnitude bound is not supported by the MFMA forms";
+    else if (o.flags & (ADMM_FLAG_UNFUSED | ADMM_FLAG_SCAN_CHAIN)) why = "ADMM_FLAG_UNFUSED / ADMM_FLAG_SCAN_CHAIN exclude the MFMA forms";
+    if (!why.empty()) { release(h); return fail(ADMM_ERR_UNSUPPORTED, "precision_mode " + std::to_string(o.precision_mode) + ": " + why); }
+    h->mfma_elem = lq.mfma_elem;
+  }
   std::string err;
-  rc = admm::factorise(*p, o.rho, h->S, h->fac, err);
+  rc = admm::factorise(*p, o.rho, h->S, h->fac, err, h->mfma_elem);
   if (rc) { release(h); return fail(rc, err); }
   // Conditioning guard of the parallel-in-time form: the segment coupling is exact in exact
   // arithmetic, but its transfer matrices are products of closed-loop matrices, and for a barely
@@ -672,7 +754,7 @@ int admm_setup(admm_handle** out, const admm_problem* p, const admm_options* o_i
   if (o.segments == 0) {
     while (h->fac.S > 1 && scan_growth(h->fac) > SCAN_GROWTH_MAX) {
       const int S2 = std::max(1, h->fac.S / 2);
-      rc = admm::factorise(*p, o.rho, S2, h->fac, err);
+      rc = admm::factorise(*p, o.rho, S2, h->fac, err, h->mfma_elem);
       if (rc) { release(h); return fail(rc, err); }
     }
   }
@@ -725,10 +807,26 @@ int admm_setup(admm_handle** out, const admm_problem* p, const admm_options* o_i
     TRY_RELEASE(dalloc(&h->scan_range, h->fac.scanRange.size()));
   }
   // alternating-direction iteration: compiled for this (n, m), buildable for this problem, not disabled
-  h->alt = h->fac.alt_ok && fused(h) &&
-           !(h->opt.flags & (ADMM_FLAG_SCAN_CHAIN | ADMM_FLAG_NO_ALTERNATE)) &&
-           dispatch_x(xlaunch_of(h), admm::XKernel::XFZE, false, false, /*query_only=*/true);
-  if (h->alt) {
+  h->alt_allowed = h->fac.alt_ok && fused(h) &&
+                   !(h->opt.flags & (ADMM_FLAG_SCAN_CHAIN | ADMM_FLAG_NO_ALTERNATE)) &&
+                   dispatch_x(xlaunch_of(h), admm::XKernel::XFZE, false, false, /*query_only=*/true);
+  // MIXED runs the plain (Riccati) path: the forward-elimination form's early-stage gains are not fp32-safe.
+  // Its fp64 refinement phase switches the alternation back on (set_mfma below).
+  h->alt = h->alt_allowed && o.precision_mode != ADMM_PRECISION_MIXED;
+  h->mfma_on = h->mfma_elem != 0 && (o.precision_mode == ADMM_PRECISION_MIXED || h->alt);
+  if (h->mfma_elem) {
+    // (+ 1 KiB: the LDS-DMA copy of a chunk moves whole KiB pieces, admm_mfma.hpp)
+    HIP_TRY_RELEASE(hipMalloc((void**)&h->recMF, h->fac.recMF.size() + 1024));
+    HIP_TRY_RELEASE(hipMalloc((void**)&h->recMB, h->fac.recMB.size() + 1024));
+    HIP_TRY_RELEASE(hipMemset(h->recMF, 0, h->fac.recMF.size() + 1024));
+    HIP_TRY_RELEASE(hipMemset(h->recMB, 0, h->fac.recMB.size() + 1024));
+    HIP_TRY_RELEASE(hipMemcpy(h->recMF, h->fac.recMF.data(), h->fac.recMF.size(), hipMemcpyHostToDevice));
+    HIP_TRY_RELEASE(hipMemcpy(h->recMB, h->fac.recMB.data(), h->fac.recMB.size(), hipMemcpyHostToDevice));
+    TRY_RELEASE(dalloc(&h->status1, (size_t)h->pitch));
+    TRY_RELEASE(dalloc(&h->iters1, (size_t)h->pitch));
+  }
+  const bool need_alt_buffers = h->alt_allowed;
+  if (need_alt_buffers) {
     TRY_RELEASE(dalloc(&h->recFE, h->fac.recFE.size()));
     TRY_RELEASE(dalloc(&h->recBE, h->fac.recBE.size()));
     TRY_RELEASE(dalloc(&h->scanWpB, h->fac.scanWpB.size()));
@@ -814,7 +912,7 @@ static int set_rho_internal(admm_handle* h, double rho_new) {
   p.unorm = h->pun.empty() ? nullptr : h->pun.data();
   admm::Factor f;
   std::string err;
-  int rc = admm::factorise(p, rho_new, h->S, f, err);
+  int rc = admm::factorise(p, rho_new, h->S, f, err, h->mfma_elem);
   if (rc) return fail(rc, err);
   if (f.recB.size() != h->fac.recB.size() || f.scanWp.size() != h->fac.scanWp.size())
     return fail(ADMM_ERR_NUMERIC, "internal: record sizes changed on refactor");
@@ -860,7 +958,7 @@ int admm_update_problem(admm_handle* h, const admm_problem* p) {
     return fail(ADMM_ERR_INVALID, "admm_update_problem: a thrust-magnitude bound cannot be added to or removed from a handle");
   admm::Factor f;
   std::string err;
-  if ((rc = admm::factorise(*p, h->opt.rho, h->S, f, err))) return fail(rc, err);
+  if ((rc = admm::factorise(*p, h->opt.rho, h->S, f, err, h->mfma_elem))) return fail(rc, err);
   if (f.recB.size() != h->fac.recB.size() || f.scanWp.size() != h->fac.scanWp.size())
     return fail(ADMM_ERR_NUMERIC, "internal: record sizes changed on refactor");
   if (h->auto_segments && h->S > 1 && scan_growth(f) > SCAN_GROWTH_MAX)
@@ -1021,6 +1119,13 @@ int admm_solve_begin(admm_handle* h, const double* z0, const double* y0) {
   h->rho_updates = 0;
   h->solve_it = 0;
   h->solve_nconv = 0;
+  h->mixed_iters = 0;
+  h->mixed_phase1 = h->opt.precision_mode == ADMM_PRECISION_MIXED;
+  if (h->mixed_phase1) {
+    if ((rc = flush_finalize(h))) return rc;
+    set_mixed_form(h, true);
+    HIP_TRY(hipMemsetAsync(h->status1, 0, sizeof(int) * P, h->stream));
+  }
   return ADMM_OK;
 }
 
@@ -1048,6 +1153,16 @@ int admm_solve_step(admm_handle* h, int32_t* iters_done, int32_t* n_converged, d
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->solve_nconv = *h->h_nconv;
     h->resid_valid = true;
+    if (h->mixed_phase1) {
+      // fp32 phase: the count is of the RAISED tolerances.  Once every QP meets them (or the budget is spent) the
+      // solve continues with the fp64 kernels, which check the rule as given; nothing has converged so far.
+      h->mixed_iters = h->solve_it;
+      if (h->solve_nconv >= h->batch) {
+        h->mixed_phase1 = false;
+        set_mixed_form(h, false);
+      }
+      h->solve_nconv = 0;
+    }
     break;
   }
   if (iters_done) *iters_done = h->solve_it;
@@ -1098,6 +1213,11 @@ int admm_solve_end(admm_handle* h, admm_info* info) {
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(h->stream));
   h->iters_run = h->solve_it;
+  if (h->opt.precision_mode == ADMM_PRECISION_MIXED) {
+    if (h->mixed_phase1) h->mixed_iters = h->solve_it;
+    h->mixed_phase1 = false;
+    set_mixed_form(h, true);                 // admm_run / admm_iterate after a solve run the fp32 form again
+  }
   const size_t P = h->pitch;
   if (info) {
     info->iters_run = h->solve_it;
@@ -1114,7 +1234,7 @@ int admm_solve_end(admm_handle* h, admm_info* info) {
     info->solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - h->solve_t0).count();
     info->rho = h->opt.rho;
     info->rho_updates = h->rho_updates;
-    info->reserved = 0;
+    info->mixed_iters = h->opt.precision_mode == ADMM_PRECISION_MIXED ? h->mixed_iters : 0;
   }
   return ADMM_OK;
 }

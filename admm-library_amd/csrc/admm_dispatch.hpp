@@ -23,6 +23,9 @@ struct XLaunch {
   const double* x0;
   int nsplit;                   // split-K slabs of the scan output (t_in / x_in), 1 = none
   size_t split_stride;          // elements between slabs
+  // MFMA form (admm_mfma.hpp): per-stage fragment records, element size 4 (fp32) / 8 (fp64), 0 = not in use
+  const unsigned char *recMF, *recMB;
+  int mfma_elem;
 };
 
 enum class XKernel { XB, XF, XFZ, XSCAN_CHAIN, XFZE, XBZE };
@@ -34,6 +37,10 @@ bool launch_group0(const XLaunch& l, XKernel k, bool a, bool b, bool query_only)
 bool launch_group1(const XLaunch& l, XKernel k, bool a, bool b, bool query_only);
 bool launch_group2(const XLaunch& l, XKernel k, bool a, bool b, bool query_only);
 bool launch_group3(const XLaunch& l, XKernel k, bool a, bool b, bool query_only);
+// MFMA form of XFZE / XBZE (fp64 records) or of XB / XFZ in v-form (fp32 records), by l.mfma_elem; false if the
+// (n, m) pair or the kernel has no MFMA instantiation.
+bool launch_mfma(const XLaunch& l, XKernel k, bool resid, bool query_only);
+const char* dims_mfma();
 // " (n,m) (n,m) ..." of a group, for error messages
 const char* dims_group0();
 const char* dims_group1();

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstring>
 
 namespace admm {
 namespace {
@@ -471,9 +472,160 @@ void build_alternating(Factor& f, const std::vector<Mat>& A, const std::vector<M
   f.alt_ok = true;
 }
 
+
+// ---- MFMA form of the fused stage operators (admm_mfma_layout.hpp) ----
+struct Frags {
+  std::vector<double> v;     // values in consumption order; cast to the element type when a record is written
+};
+
+// One product: M (R x C, row-major) -> ks * ot fragments of 64 values.  out_row(ot, r, g) / in_col(ks, g) give the
+// matrix row / column a slot stands for (-1 = padding).  hw_row(i) -> (r, g) is the accumulator-row map of the
+// element type.
+template <class OutRow, class InCol>
+void pack_product(Frags& fr, const Mat& M, int C, int ks_n, int ot_n, bool f32, OutRow out_row, InCol in_col) {
+  for (int ks = 0; ks < ks_n; ++ks)
+    for (int ot = 0; ot < ot_n; ++ot)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int i = lane & 15, kk = lane >> 4;
+        const int g = f32 ? (i >> 2) : (i & 3), r = f32 ? (i & 3) : (i >> 2);   // slot (r, g) of hardware row i
+        const int row = out_row(ot, r, g), col = in_col(ks, kk);
+        fr.v.push_back((row >= 0 && col >= 0) ? M[(size_t)row * C + col] : 0.0);
+      }
+}
+
+Mat block(const double* rec, int off, int r, int c) { return Mat(rec + off, rec + off + (size_t)r * c); }
+
+void put_block(Mat& M, int C, int r0, int c0, const Mat& B, int r, int c, double sgn) {
+  for (int i = 0; i < r; ++i)
+    for (int j = 0; j < c; ++j) M[(size_t)(r0 + i) * C + c0 + j] = sgn * B[(size_t)i * c + j];
+}
+
+void write_record(unsigned char* dst, const Frags& fr, const double* lohi, int elem) {
+  if (elem == 8) {
+    std::memcpy(dst, fr.v.data(), fr.v.size() * 8);
+  } else {
+    float* o = reinterpret_cast<float*>(dst);
+    for (size_t i = 0; i < fr.v.size(); ++i) o[i] = (float)fr.v[i];
+  }
+  std::memcpy(dst + fr.v.size() * elem, lohi, 40 * 8);
+}
+
+void build_mfma(Factor& f, int elem) {
+  const int N = f.N, n = f.n, m = f.m;
+  const MfmaLayout L = mfma_layout(n, m);
+  const bool f32 = elem == 4;
+  f.mfma_elem = elem;
+  f.RMF = mfma_rec_bytes_fwd(n, m, elem);
+  f.RMB = mfma_rec_bytes_bwd(n, m, elem);
+  f.recMF.assign((size_t)N * f.RMF, 0);
+  f.recMB.assign((size_t)N * f.RMB, 0);
+  const RecBLayout lb = rec_b_layout(n, m);
+  const RecFLayout lf = rec_f_layout(n, m);
+  const RecFELayout lfe = rec_fe_layout(n, m);
+  const RecBELayout lbe = rec_be_layout(n, m);
+  // slot -> row maps shared by the products
+  auto nvec = [&](int r, int g) { return (r < 3 && 4 * r + g < n) ? 4 * r + g : -1; };    // slots of an n-vector
+  auto sub_out = [&](int ot, int r, int g) -> int {          // rows: [x (n) ; u (m)]
+    if (ot == 0) return r < 3 ? nvec(r, g) : (g < m ? n + g : -1);
+    return (r == 0 && 4 + g < m) ? n + 4 + g : -1;
+  };
+  auto sub_in = [&](int ks, int kk) -> int {                 // cols: [x (n) ; second n-vector ; m-vector]
+    if (ks < 3) return nvec(ks, kk);
+    if (ks < 6) return nvec(ks - 3, kk) < 0 ? -1 : n + nvec(ks - 3, kk);
+    if (ks == 6) return kk < m ? 2 * n + kk : -1;
+    return 4 + kk < m ? 2 * n + 4 + kk : -1;
+  };
+  auto elim_out = [&](int ot, int r, int g) -> int {         // rows: [first n-vector ; second n-vector ; m-vector]
+    if (r < 3) return nvec(r, g) < 0 ? -1 : ot * n + nvec(r, g);
+    const int j = 4 * ot + g;
+    return j < m ? 2 * n + j : -1;
+  };
+  auto elimb_in = [&](int ks, int kk) -> int {               // cols: [p (n) ; g^u (m)]
+    if (ks < 3) return nvec(ks, kk);
+    const int j = 4 * (ks - 3) + kk;
+    return j < m ? n + j : -1;
+  };
+  const Mat Im = eye(m);
+  for (int k = 0; k < N; ++k) {
+    const double* rf = &f.recF[(size_t)k * f.RF];
+    const double* rb = &f.recB[(size_t)k * f.RB];
+    const Mat K = block(rf, lf.K, m, n), Psi = block(rf, lf.PSI, m, n), A = block(rf, lf.A, n, n), B = block(rf, lf.B, n, m);
+    const Mat AT = block(rb, lb.AT, n, n), BT = block(rb, lb.BT, m, n), SI = block(rb, lb.SI, m, m),
+              KT = block(rb, lb.KT, n, m), OM = block(rb, lb.OM, n, m);
+    // lo / hi in slot order (slot index r * 4 + g, r = 0..4)
+    double lohi[40];
+    for (int r = 0; r < 5; ++r)
+      for (int g = 0; g < 4; ++g) {
+        int row = -1;                                        // row of block k (u rows first)
+        if (r < 3) row = nvec(r, g) < 0 ? -1 : m + nvec(r, g);
+        else if (r == 3) row = g < m ? g : -1;
+        else row = 4 + g < m ? 4 + g : -1;
+        lohi[r * 4 + g] = row < 0 ? -INFINITY : rb[lb.LO + row];
+        lohi[20 + r * 4 + g] = row < 0 ? INFINITY : rb[lb.HI + row];
+      }
+    const int C3 = 2 * n + m;
+    {  // ---------------- forward record: SUB_F, ELIM_F ----------------
+      Frags fr;
+      Mat Ms((size_t)(n + m) * C3, 0.0);
+      const Mat BK = mul(B, K, n, m, n), BPsi = mul(B, Psi, n, m, n);
+      put_block(Ms, C3, 0, 0, sub(A, BK), n, n, 1.0);        // x+ = (A - B K) x - B Psi t - B d
+      put_block(Ms, C3, 0, n, BPsi, n, n, -1.0);
+      put_block(Ms, C3, 0, 2 * n, B, n, m, -1.0);
+      put_block(Ms, C3, n, 0, K, m, n, -1.0);                // u  = -K x - Psi t - d
+      put_block(Ms, C3, n, n, Psi, m, n, -1.0);
+      put_block(Ms, C3, n, 2 * n, Im, m, m, -1.0);
+      pack_product(fr, Ms, C3, L.ks_sub, L.ot_sub, f32, sub_out, sub_in);
+      Mat Me((size_t)(2 * n + m) * C3, 0.0);                 // rows [mu+ ; deps ; db], cols [mu ; g^x ; g^u]
+      if (f.alt_ok) {
+        const double* rfe = &f.recFE[(size_t)k * f.RFE];
+        const Mat FM = block(rfe, lfe.FM, n, n), GA = block(rfe, lfe.GA, n, m), PI = block(rfe, lfe.PI, n, n),
+                  DK = block(rfe, lfe.DK, m, n), DG = block(rfe, lfe.DG, m, m), OB = block(rfe, lfe.OB, n, m);
+        put_block(Me, C3, 0, 0, FM, n, n, 1.0);
+        put_block(Me, C3, 0, n, PI, n, n, 1.0);
+        put_block(Me, C3, 0, 2 * n, GA, n, m, 1.0);
+        put_block(Me, C3, n, 0, mul(OB, DK, n, m, n), n, n, 1.0);
+        put_block(Me, C3, n, 2 * n, mul(OB, DG, n, m, m), n, m, 1.0);
+        put_block(Me, C3, 2 * n, 0, DK, m, n, 1.0);
+        put_block(Me, C3, 2 * n, 2 * n, DG, m, m, 1.0);
+      }
+      pack_product(fr, Me, C3, L.ks_elim_f, 2, f32, elim_out, sub_in);
+      write_record(&f.recMF[(size_t)k * f.RMF], fr, lohi, elem);
+    }
+    {  // ---------------- backward record: SUB_B, ELIM_B ----------------
+      Frags fr;
+      Mat Ms((size_t)(n + m) * C3, 0.0);                     // rows [x_k ; u], cols [x_{k+1} ; m_in ; db]
+      if (f.alt_ok) {
+        const double* rbe = &f.recBE[(size_t)k * f.RBE];
+        const Mat PSB = block(rbe, lbe.PSB, m, n), KB = block(rbe, lbe.KB, m, n), AI = block(rbe, lbe.AI, n, n),
+                  AIB = block(rbe, lbe.AIB, n, m);           // AIB = -A^-1 B:  x_k = AI x_{k+1} + AIB u
+        put_block(Ms, C3, 0, 0, sub(AI, mul(AIB, KB, n, m, n)), n, n, 1.0);     // u = -KB x - PSB m_in - db
+        put_block(Ms, C3, 0, n, mul(AIB, PSB, n, m, n), n, n, -1.0);
+        put_block(Ms, C3, 0, 2 * n, AIB, n, m, -1.0);
+        put_block(Ms, C3, n, 0, KB, m, n, -1.0);
+        put_block(Ms, C3, n, n, PSB, m, n, -1.0);
+        put_block(Ms, C3, n, 2 * n, Im, m, m, -1.0);
+      }
+      pack_product(fr, Ms, C3, L.ks_sub, L.ot_sub, f32, sub_out, sub_in);
+      const int C2 = n + m;
+      Mat Me((size_t)(2 * n + m) * C2, 0.0);                 // rows [t+ ; de ; d0], cols [p ; g^u]
+      const Mat SIBT = mul(SI, BT, m, m, n);
+      put_block(Me, C2, 0, 0, sub(AT, mul(KT, BT, n, m, n)), n, n, 1.0);        // t+ = A' p - K' (B' p + g^u)
+      put_block(Me, C2, 0, n, KT, n, m, -1.0);
+      put_block(Me, C2, n, 0, mul(OM, SIBT, n, m, n), n, n, 1.0);               // de = Om d0
+      put_block(Me, C2, n, n, mul(OM, SI, n, m, m), n, m, 1.0);
+      put_block(Me, C2, 2 * n, 0, SIBT, m, n, 1.0);                             // d0 = Si (B' p + g^u)
+      put_block(Me, C2, 2 * n, n, SI, m, m, 1.0);
+      pack_product(fr, Me, C2, L.ks_elim_b, 2, f32, elim_out, elimb_in);
+      write_record(&f.recMB[(size_t)k * f.RMB], fr, lohi, elem);
+    }
+  }
+}
+
 }  // namespace
 
-int factorise(const admm_problem& p, double rho, int segments, Factor& f, std::string& err) {
+int factorise(const admm_problem& p, double rho, int segments, Factor& f, std::string& err, int mfma_elem) {
+  if (mfma_elem != 0 && !(mfma_elem == 4 || mfma_elem == 8)) { err = "mfma_elem must be 0, 4 or 8"; return ADMM_ERR_INVALID; }
+  if (mfma_elem != 0 && !mfma_dims(p.n, p.m)) { err = "the MFMA form needs n <= 12 and m <= 8"; return ADMM_ERR_UNSUPPORTED; }
   const int N = p.N, n = p.n, m = p.m;
   if (N < 1 || n < 1 || m < 1) { err = "N, n, m must be positive"; return ADMM_ERR_INVALID; }
   if (!(rho > 0.0) || !std::isfinite(rho)) { err = "rho must be positive and finite"; return ADMM_ERR_INVALID; }
@@ -631,6 +783,10 @@ int factorise(const admm_problem& p, double rho, int segments, Factor& f, std::s
   }
 
   build_alternating(f, A, B, Q, R, QN, rho);
+  f.mfma_elem = 0;
+  f.recMF.clear();
+  f.recMB.clear();
+  if (mfma_elem) build_mfma(f, mfma_elem);
   return ADMM_OK;
 }
 

@@ -1,0 +1,529 @@
+// admm_mfma.hpp -- MFMA form of the fused iteration kernels (BASELINE.json configs[4]:
+// "x-update with MFMA batched-GEMM reformulation").  No reference counterpart exists (README.md:1-2 only).
+//
+// Same iteration, same HBM arrays and the same segment scan as the one-lane-per-QP kernels of admm_kernels.hpp /
+// admm_kernels_alt.hpp; what changes is how a stage's operators reach the arithmetic.  There every lane owns a QP
+// and the stage matrices arrive as LDS broadcasts (2 LDS cycles per double per wave: 7200 cycles per stage and CU at
+// n = 12, m = 6 -- the bound of those kernels at that size).  Here 16 QPs x one stage is a chain of
+// v_mfma_{f64,f32}_16x16x4 products: the batch-minor panel is the B operand, the stage operators are pre-packed on
+// the host as A fragments (one element per lane per MFMA, admm_mfma_layout.hpp), and the accumulator tile of one
+// stage is, register for register, the B operand of the next.
+//
+//   xfzem_kernel<NX, NU, T, RESID, RELAX, ELIM>   forward:   SUB_F | z-update, dual, residual partials | ELIM_F
+//       ELIM = true : the alternating path's forward fused kernel (xfze_kernel)
+//       ELIM = false: the plain path's fused forward kernel (xfz_kernel, state in v-form)
+//   xbzem_kernel<NX, NU, T, RESID, RELAX, SUBST>  backward:  SUB_B | z-update, dual, residual partials | ELIM_B
+//       SUBST = true : the alternating path's backward fused kernel (xbze_kernel)
+//       SUBST = false: the plain path's backward sweep (xb_kernel, state in v-form; v is only read)
+//   T = double: exact -- iterates agree with the fp64 one-lane kernels to rounding (the operators are folded on the
+//       host, e.g. A - B K, so the rounding differs at the 1e-16 level).
+//   T = float : the x-update chains (x, t, mu, eps, d, db and the matrix operands) run in fp32 on the fp32 matrix
+//       pipe; v, the z-update, the dual and the residuals stay fp64.  Only on the plain path: the forward-elimination
+//       form's early-stage gains (2.5e4) are not fp32-safe.
+// Thrust-magnitude bound and linear term q: not in this form (admm_setup refuses the combination).
+//
+// Geometry: workgroup = 512 threads = 8 waves, 2 waves per SIMD (<= 256 registers each); a wave owns MF_NT = 2
+// tiles of 16 QPs, so a workgroup covers 256 QPs of one segment -- the same grid as the one-lane kernels,
+// (ceil(pitch / 256), S), one workgroup per CU at configs[2..4]'s batch.
+#pragma once
+
+#include "admm_kernels.hpp"
+#include "admm_kernels_alt.hpp"
+#include "admm_mfma_layout.hpp"
+
+namespace admm {
+
+constexpr int MF_THREADS = 512;
+constexpr int MF_NT = 2;                       // 16-QP tiles per wave
+constexpr int MF_COLS = (MF_THREADS / 64) * MF_NT * 16;   // 256 QPs per workgroup
+
+typedef float mfma_f4 __attribute__((ext_vector_type(4)));
+
+template <class T> struct MfmaOps;
+template <> struct MfmaOps<double> {
+  typedef mfma_d4 acc_t;
+  static __device__ __forceinline__ acc_t mfma(double a, double b, acc_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+};
+template <> struct MfmaOps<float> {
+  typedef mfma_f4 acc_t;
+  static __device__ __forceinline__ acc_t mfma(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+};
+
+// stages whose records sit in one LDS buffer (two buffers: <= ~80 KB of the CU's 160 KB)
+constexpr int mfma_chunk(int rec_bytes) {
+  int ch = 40000 / rec_bytes;
+  return ch < 1 ? 1 : (ch > 4 ? 4 : ch);
+}
+
+// Asynchronous global -> LDS copy of one chunk of records (LDS-DMA, global_load_lds_dwordx4: no staging registers,
+// no ds_write pass).  A wave-instruction moves 64 lanes x 16 B = one contiguous KiB to "wave-uniform LDS base +
+// lane x 16", so the chunk is copied in whole KiB pieces, wave w taking pieces w, w + 8, ...: the LDS buffers are
+// rounded up to a KiB and the device arrays carry a KiB of slack, so the last piece may run past the chunk.
+// Issued at the start of a chunk's arithmetic; the __syncthreads() that ends the chunk retires it (the barrier's
+// fence waits for vmcnt(0)).
+constexpr int mfma_lds_bytes(int chunk_bytes) { return ((chunk_bytes + 1023) / 1024) * 1024; }
+
+__device__ __forceinline__ void glds_chunk(const unsigned char* src, unsigned char* lds_dst, int bytes, int wave, int lane) {
+  const int pieces = (bytes + 1023) >> 10;
+  for (int p = wave; p < pieces; p += MF_THREADS / 64) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)p * 1024 + lane * 16),
+                                     (__attribute__((address_space(3))) void*)(lds_dst + p * 1024), 16, 0, 0);
+  }
+}
+
+// One register (4 rows x 16 QPs) of the z-update, dual ascent and residual partials; returns v+ and the linear
+// term g = -rho (z+ - y+) of the next x-update.  Padding slots carry c0 = w = 0 and the box (-inf, inf): every
+// result is then (+-) 0 and the sums are untouched.
+template <bool RESID, bool RELAX>
+__device__ __forceinline__ void mf_zupdate(double c0, double w, double lo, double hi, double alpha, double rho,
+                                           double& vn, double& gg, double (&acc)[5]) {
+  const double zo = fmin(fmax(c0, lo), hi);
+  const double yo = c0 - zo;
+  double wh = w;
+  if (RELAX) wh = fma(alpha, w, (1.0 - alpha) * zo);
+  vn = wh + yo;
+  const double zn = fmin(fmax(vn, lo), hi);
+  const double yn = vn - zn;
+  gg = -rho * (zn - yn);
+  if (RESID) {
+    const double dr = w - zn, ds = zn - zo;
+    acc[0] = fma(dr, dr, acc[0]);
+    acc[1] = fma(ds, ds, acc[1]);
+    acc[2] = fma(w, w, acc[2]);
+    acc[3] = fma(zn, zn, acc[3]);
+    acc[4] = fma(yn, yn, acc[4]);
+  }
+}
+
+// per-QP residual partials: a QP's rows live in the four lane groups of its column -> two cross-lane adds
+__device__ __forceinline__ double mf_colsum(double x) {
+  x += __shfl_xor(x, 16, 64);
+  x += __shfl_xor(x, 32, 64);
+  return x;
+}
+
+// ---------------------------------------------------------------------------
+// Forward kernel.  Per 16-QP tile and stage k = a .. b-1 (block k = (u_k, x_{k+1})):
+//     SUB_F :  [x+ ; u] = M [x ; t_in ; d_k]                       (d_k from dbuf; w block k = (u, x+))
+//     z-update on block k with v (in place) -> v+, g
+//     ELIM_F:  [mu+ ; deps ; db_k] = M [mu ; g^x ; g^u],  eps += deps,  db_k -> dbb          (ELIM only)
+// and on exit mu -> mseg[s], eps -> epsseg[s] (ELIM), residual partials -> part (RESID).
+// ---------------------------------------------------------------------------
+template <int NX, int NU, class T, bool RESID, bool RELAX, bool ELIM>
+__global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void xfzem_kernel(
+    const double* __restrict__ dbuf, const double* __restrict__ tin, const double* __restrict__ xin,
+    const unsigned char* __restrict__ recMF, const int* __restrict__ seg_start_, double* __restrict__ v,
+    double* __restrict__ dbb, double* __restrict__ mseg, double* __restrict__ epsseg, double* __restrict__ part,
+    double alpha, double rho, int pitch, int nsplit, size_t split_stride) {
+  typedef MfmaOps<T> Ops;
+  typedef typename Ops::acc_t acc_t;
+  static_assert(mfma_dims(NX, NU), "MFMA form: n <= 12, m <= 8");
+  constexpr int NB = NX + NU;
+  constexpr MfmaLayout ML = mfma_layout(NX, NU);
+  constexpr int XT = ML.xt, OT = ML.ot_sub, KS = ML.ks_sub, KE = ML.ks_elim_f;
+  constexpr int RM = mfma_rec_bytes_fwd(NX, NU, (int)sizeof(T));
+  constexpr int O_ELIM = ML.nf_sub * 64;                       // element offset of the ELIM fragments
+  constexpr int O_LOHI = (ML.nf_sub + ML.nf_elim_f) * 64 * (int)sizeof(T);   // byte offset of lo / hi
+  constexpr int CH = mfma_chunk(RM);
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2][mfma_lds_bytes(CH * RM)];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, c = lane & 15;
+  const int s = blockIdx.y;
+  cint_p seg_start = as_const(seg_start_);
+  const int k0 = seg_start[s], k1 = seg_start[s + 1];
+  const size_t P = (size_t)pitch;
+  const unsigned PB = (unsigned)pitch * 8u;
+  const RowView vv(v, (size_t)k0 * NB * P, (size_t)(k1 - k0) * NB * P * 8);
+  const RowView vd(dbuf, (size_t)k0 * NU * P, (size_t)(k1 - k0) * NU * P * 8);
+  const RowView vm(dbb, (size_t)k0 * NU * P, (size_t)(k1 - k0) * NU * P * 8);
+
+  // slot validity of this lane group (compile-time in r, run-time in g)
+  bool okx[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) okx[r] = 4 * r + g < NX;
+  const bool oku0 = g < NU, oku1 = 4 + g < NU;
+
+  int col[MF_NT];
+  unsigned lbl[MF_NT], lbs[MF_NT];             // lane byte offsets for loads (clamped column) / stores (dropped if clamped)
+#pragma unroll
+  for (int nt = 0; nt < MF_NT; ++nt) {
+    const int col_raw = blockIdx.x * MF_COLS + (wave * MF_NT + nt) * 16 + c;
+    col[nt] = col_raw < pitch ? col_raw : pitch - 1;
+    lbl[nt] = ((unsigned)g * (unsigned)pitch + (unsigned)col[nt]) * 8u;
+    lbs[nt] = col_raw < pitch ? lbl[nt] : ROWVIEW_OOB;
+  }
+
+  T X[MF_NT][3], Tin[MF_NT][3], Mu[MF_NT][3], Eps[MF_NT][3];
+#pragma unroll
+  for (int nt = 0; nt < MF_NT; ++nt)
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const size_t o = ((size_t)s * NX + (okx[r] ? 4 * r + g : 0)) * P + col[nt];
+      const double tv = scan_row(tin, o, nsplit, split_stride), xv = scan_row(xin, o, nsplit, split_stride);
+      Tin[nt][r] = okx[r] ? (T)tv : (T)0;
+      X[nt][r] = okx[r] ? (T)xv : (T)0;
+      Mu[nt][r] = (T)0;
+      Eps[nt][r] = (T)0;
+    }
+  double racc[MF_NT][5];
+#pragma unroll
+  for (int nt = 0; nt < MF_NT; ++nt)
+#pragma unroll
+    for (int q = 0; q < 5; ++q) racc[nt][q] = 0.0;
+
+  // operand prefetch, one stage deep: v rows (5 registers) and d rows (2) of the next stage
+  double pv[MF_NT][5], pd[MF_NT][2];
+  auto load_stage = [&](int k, int nt) {
+    const int kk = k < k1 ? k : k1 - 1;
+    const unsigned r0 = (unsigned)(kk - k0) * NB * PB;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) pv[nt][r] = vv.load(lbl[nt], r0 + (unsigned)(NU + 4 * r) * PB);
+    pv[nt][3] = vv.load(lbl[nt], r0);
+    pv[nt][4] = XT ? vv.load(lbl[nt], r0 + 4u * PB) : 0.0;
+    const unsigned d0 = (unsigned)(kk - k0) * NU * PB;
+    pd[nt][0] = vd.load(lbl[nt], d0);
+    pd[nt][1] = XT ? vd.load(lbl[nt], d0 + 4u * PB) : 0.0;
+  };
+#pragma unroll
+  for (int nt = 0; nt < MF_NT; ++nt) load_stage(k0, nt);
+
+  glds_chunk(recMF + (size_t)k0 * RM, lds[0], ((k1 - k0 < CH) ? k1 - k0 : CH) * RM, wave, lane);
+  __syncthreads();
+  int buf = 0;
+  for (int kc = k0; kc < k1; kc += CH) {
+    const int khi = (kc + CH < k1) ? kc + CH : k1;               // this chunk: stages kc .. khi-1
+    const int nnext = (khi < k1) ? ((khi + CH < k1 ? CH : k1 - khi) * RM) : 0;
+    if (nnext) glds_chunk(recMF + (size_t)khi * RM, lds[buf ^ 1], nnext, wave, lane);   // next chunk, in flight during this one
+    for (int k = kc; k < khi; ++k) {
+      const unsigned char* rec = lds[buf] + (k - kc) * RM;
+      const T* af = reinterpret_cast<const T*>(rec);
+      const double* lohi = reinterpret_cast<const double*>(rec + O_LOHI);
+      double c0[MF_NT][5], dk[MF_NT][2];
+#pragma unroll
+      for (int nt = 0; nt < MF_NT; ++nt) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) c0[nt][r] = okx[r] ? pv[nt][r] : 0.0;
+        c0[nt][3] = oku0 ? pv[nt][3] : 0.0;
+        c0[nt][4] = (XT && oku1) ? pv[nt][4] : 0.0;
+        dk[nt][0] = oku0 ? pd[nt][0] : 0.0;
+        dk[nt][1] = (XT && oku1) ? pd[nt][1] : 0.0;
+        load_stage(k + 1, nt);
+      }
+      // ---- SUB_F ----
+      acc_t a0[MF_NT], a1[MF_NT];
+#pragma unroll
+      for (int nt = 0; nt < MF_NT; ++nt) { a0[nt] = acc_t{0, 0, 0, 0}; a1[nt] = acc_t{0, 0, 0, 0}; }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const T fa0 = af[(ks * OT + 0) * 64 + lane];
+        const T fa1 = XT ? af[(ks * OT + XT) * 64 + lane] : (T)0;
+#pragma unroll
+        for (int nt = 0; nt < MF_NT; ++nt) {
+          const T b = ks < 3 ? X[nt][ks < 3 ? ks : 0] : (ks < 6 ? Tin[nt][ks < 6 ? (ks >= 3 ? ks - 3 : 0) : 0] : (T)dk[nt][ks == 6 ? 0 : 1]);
+          a0[nt] = Ops::mfma(fa0, b, a0[nt]);
+          if (XT) a1[nt] = Ops::mfma(fa1, b, a1[nt]);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- z-update, dual ascent, residual partials; v+ stored in place ----
+      double gg[MF_NT][5];
+      const unsigned r0 = (unsigned)(k - k0) * NB * PB;
+#pragma unroll
+      for (int nt = 0; nt < MF_NT; ++nt) {
+        double vn;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          mf_zupdate<RESID, RELAX>(c0[nt][r], (double)a0[nt][r], lohi[r * 4 + g], lohi[20 + r * 4 + g], alpha, rho, vn, gg[nt][r], racc[nt]);
+          vv.store(vn, okx[r] ? lbs[nt] : ROWVIEW_OOB, r0 + (unsigned)(NU + 4 * r) * PB);
+          X[nt][r] = a0[nt][r];
+        }
+        mf_zupdate<RESID, RELAX>(c0[nt][3], (double)a0[nt][3], lohi[12 + g], lohi[32 + g], alpha, rho, vn, gg[nt][3], racc[nt]);
+        vv.store(vn, oku0 ? lbs[nt] : ROWVIEW_OOB, r0);
+        if (XT) {
+          mf_zupdate<RESID, RELAX>(c0[nt][4], (double)a1[nt][0], lohi[16 + g], lohi[36 + g], alpha, rho, vn, gg[nt][4], racc[nt]);
+          vv.store(vn, oku1 ? lbs[nt] : ROWVIEW_OOB, r0 + 4u * PB);
+        } else {
+          gg[nt][4] = 0.0;
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- ELIM_F ----
+      if (ELIM) {
+        const T* ae = af + O_ELIM;
+        acc_t e0[MF_NT], e1[MF_NT];
+#pragma unroll
+        for (int nt = 0; nt < MF_NT; ++nt) {
+          e0[nt] = acc_t{0, 0, 0, 0};
+          e1[nt] = acc_t{Eps[nt][0], Eps[nt][1], Eps[nt][2], 0};
+        }
+#pragma unroll
+        for (int ks = 0; ks < KE; ++ks) {
+          const T fa0 = ae[(ks * 2 + 0) * 64 + lane], fa1 = ae[(ks * 2 + 1) * 64 + lane];
+#pragma unroll
+          for (int nt = 0; nt < MF_NT; ++nt) {
+            const T b = ks < 3 ? Mu[nt][ks < 3 ? ks : 0] : (T)gg[nt][ks < 6 ? (ks >= 3 ? ks - 3 : 0) : (ks == 6 ? 3 : 4)];
+            e0[nt] = Ops::mfma(fa0, b, e0[nt]);
+            e1[nt] = Ops::mfma(fa1, b, e1[nt]);
+          }
+        }
+        const unsigned m0 = (unsigned)(k - k0) * NU * PB;
+#pragma unroll
+        for (int nt = 0; nt < MF_NT; ++nt) {
+#pragma unroll
+          for (int r = 0; r < 3; ++r) { Mu[nt][r] = e0[nt][r]; Eps[nt][r] = e1[nt][r]; }
+          vm.store((double)e0[nt][3], oku0 ? lbs[nt] : ROWVIEW_OOB, m0);
+          if (XT) vm.store((double)e1[nt][3], oku1 ? lbs[nt] : ROWVIEW_OOB, m0 + 4u * PB);
+        }
+      }
+    }
+    __syncthreads();
+    buf ^= 1;
+  }
+#pragma unroll
+  for (int nt = 0; nt < MF_NT; ++nt) {
+    const bool st = lbs[nt] != ROWVIEW_OOB;
+    if (ELIM) {
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+        if (st && okx[r]) {
+          const size_t o = ((size_t)s * NX + 4 * r + g) * P + col[nt];
+          mseg[o] = (double)Mu[nt][r];
+          epsseg[o] = (double)Eps[nt][r];
+        }
+    }
+    if (RESID) {
+#pragma unroll
+      for (int q = 0; q < 5; ++q) {
+        const double t = mf_colsum(racc[nt][q]);
+        if (st && g == 0) part[((size_t)s * 5 + q) * P + col[nt]] = t;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Backward kernel.  Per 16-QP tile and stage k = b-1 .. a (x = x_{k+1} on entry of a stage):
+//     SUB_B :  [x_k ; u] = M [x ; m_in ; db_k]      (db_k from dbb; w block k = (u, x_{k+1}))          (SUBST only)
+//     z-update on block k -> v+, g                   (SUBST = false: g = -rho (z - y) of the CURRENT state, v only read)
+//     ELIM_B:  [t+ ; de ; d0_k] = M [g^x + t ; g^u],  e += de,  d0_k -> dbuf
+// and on exit t -> tseg[s], e -> eseg[s]: what xb_kernel / xbze_kernel leave for the plain scan.
+// ---------------------------------------------------------------------------
+template <int NX, int NU, class T, bool RESID, bool RELAX, bool SUBST>
+__global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void xbzem_kernel(
+    const double* __restrict__ dbb, const double* __restrict__ min_, const double* __restrict__ xend,
+    const unsigned char* __restrict__ recMB, const int* __restrict__ seg_start_, double* __restrict__ v,
+    double* __restrict__ dbuf, double* __restrict__ tseg, double* __restrict__ eseg, double* __restrict__ part,
+    double alpha, double rho, int pitch, int nsplit, size_t split_stride) {
+  typedef MfmaOps<T> Ops;
+  typedef typename Ops::acc_t acc_t;
+  static_assert(mfma_dims(NX, NU), "MFMA form: n <= 12, m <= 8");
+  constexpr int NB = NX + NU;
+  constexpr MfmaLayout ML = mfma_layout(NX, NU);
+  constexpr int XT = ML.xt, OT = ML.ot_sub, KS = ML.ks_sub, KE = ML.ks_elim_b;
+  constexpr int RM = mfma_rec_bytes_bwd(NX, NU, (int)sizeof(T));
+  constexpr int O_ELIM = ML.nf_sub * 64;
+  constexpr int O_LOHI = (ML.nf_sub + ML.nf_elim_b) * 64 * (int)sizeof(T);
+  constexpr int CH = mfma_chunk(RM);
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2][mfma_lds_bytes(CH * RM)];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, c = lane & 15;
+  const int s = blockIdx.y;
+  cint_p seg_start = as_const(seg_start_);
+  const int k0 = seg_start[s], k1 = seg_start[s + 1];
+  const size_t P = (size_t)pitch;
+  const unsigned PB = (unsigned)pitch * 8u;
+  const RowView vv(v, (size_t)k0 * NB * P, (size_t)(k1 - k0) * NB * P * 8);
+  const RowView vd(dbuf, (size_t)k0 * NU * P, (size_t)(k1 - k0) * NU * P * 8);
+  const RowView vm(dbb, (size_t)k0 * NU * P, (size_t)(k1 - k0) * NU * P * 8);
+
+  bool okx[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) okx[r] = 4 * r + g < NX;
+  const bool oku0 = g < NU, oku1 = 4 + g < NU;
+
+  int col[MF_NT];
+  unsigned lbl[MF_NT], lbs[MF_NT];
+#pragma unroll
+  for (int nt = 0; nt < MF_NT; ++nt) {
+    const int col_raw = blockIdx.x * MF_COLS + (wave * MF_NT + nt) * 16 + c;
+    col[nt] = col_raw < pitch ? col_raw : pitch - 1;
+    lbl[nt] = ((unsigned)g * (unsigned)pitch + (unsigned)col[nt]) * 8u;
+    lbs[nt] = col_raw < pitch ? lbl[nt] : ROWVIEW_OOB;
+  }
+
+  T X[MF_NT][3], Min[MF_NT][3], Tt[MF_NT][3], Ee[MF_NT][3];
+#pragma unroll
+  for (int nt = 0; nt < MF_NT; ++nt)
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      if (SUBST) {
+        const size_t o = ((size_t)s * NX + (okx[r] ? 4 * r + g : 0)) * P + col[nt];
+        const double mv = scan_row(min_, o, nsplit, split_stride), xv = scan_row(xend, o, nsplit, split_stride);
+        Min[nt][r] = okx[r] ? (T)mv : (T)0;
+        X[nt][r] = okx[r] ? (T)xv : (T)0;
+      } else {
+        Min[nt][r] = (T)0;
+        X[nt][r] = (T)0;
+      }
+      Tt[nt][r] = (T)0;
+      Ee[nt][r] = (T)0;
+    }
+  double racc[MF_NT][5];
+#pragma unroll
+  for (int nt = 0; nt < MF_NT; ++nt)
+#pragma unroll
+    for (int q = 0; q < 5; ++q) racc[nt][q] = 0.0;
+
+  double pv[MF_NT][5], pd[MF_NT][2];
+  auto load_stage = [&](int k, int nt) {
+    const int kk = k > k0 ? k : k0;
+    const unsigned r0 = (unsigned)(kk - k0) * NB * PB;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) pv[nt][r] = vv.load(lbl[nt], r0 + (unsigned)(NU + 4 * r) * PB);
+    pv[nt][3] = vv.load(lbl[nt], r0);
+    pv[nt][4] = XT ? vv.load(lbl[nt], r0 + 4u * PB) : 0.0;
+    if (SUBST) {
+      const unsigned d0 = (unsigned)(kk - k0) * NU * PB;
+      pd[nt][0] = vm.load(lbl[nt], d0);
+      pd[nt][1] = XT ? vm.load(lbl[nt], d0 + 4u * PB) : 0.0;
+    } else {
+      pd[nt][0] = pd[nt][1] = 0.0;
+    }
+  };
+#pragma unroll
+  for (int nt = 0; nt < MF_NT; ++nt) load_stage(k1 - 1, nt);
+
+  {  // first chunk: stages k1-CH .. k1-1 (clipped at k0); LDS slot j = k - klo
+    const int klo = (k1 - CH > k0) ? k1 - CH : k0;
+    glds_chunk(recMB + (size_t)klo * RM, lds[0], (k1 - klo) * RM, wave, lane);
+  }
+  __syncthreads();
+  int buf = 0;
+  for (int kc = k1; kc > k0; kc -= CH) {                       // this chunk: stages klo .. kc-1, descending
+    const int klo = (kc - CH > k0) ? kc - CH : k0;
+    const int nlo = (klo - CH > k0) ? klo - CH : k0;           // next chunk: stages nlo .. klo-1
+    const int nnext = (klo > k0) ? (klo - nlo) * RM : 0;
+    if (nnext) glds_chunk(recMB + (size_t)nlo * RM, lds[buf ^ 1], nnext, wave, lane);
+    for (int k = kc - 1; k >= klo; --k) {
+      const unsigned char* rec = lds[buf] + (k - klo) * RM;
+      const T* af = reinterpret_cast<const T*>(rec);
+      const double* lohi = reinterpret_cast<const double*>(rec + O_LOHI);
+      double c0[MF_NT][5], dk[MF_NT][2];
+#pragma unroll
+      for (int nt = 0; nt < MF_NT; ++nt) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) c0[nt][r] = okx[r] ? pv[nt][r] : 0.0;
+        c0[nt][3] = oku0 ? pv[nt][3] : 0.0;
+        c0[nt][4] = (XT && oku1) ? pv[nt][4] : 0.0;
+        dk[nt][0] = oku0 ? pd[nt][0] : 0.0;
+        dk[nt][1] = (XT && oku1) ? pd[nt][1] : 0.0;
+        load_stage(k - 1, nt);
+      }
+      double gg[MF_NT][5];
+      if (SUBST) {
+        // ---- SUB_B ----
+        acc_t a0[MF_NT], a1[MF_NT];
+#pragma unroll
+        for (int nt = 0; nt < MF_NT; ++nt) { a0[nt] = acc_t{0, 0, 0, 0}; a1[nt] = acc_t{0, 0, 0, 0}; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const T fa0 = af[(ks * OT + 0) * 64 + lane];
+          const T fa1 = XT ? af[(ks * OT + XT) * 64 + lane] : (T)0;
+#pragma unroll
+          for (int nt = 0; nt < MF_NT; ++nt) {
+            const T b = ks < 3 ? X[nt][ks < 3 ? ks : 0] : (ks < 6 ? Min[nt][ks < 6 ? (ks >= 3 ? ks - 3 : 0) : 0] : (T)dk[nt][ks == 6 ? 0 : 1]);
+            a0[nt] = Ops::mfma(fa0, b, a0[nt]);
+            if (XT) a1[nt] = Ops::mfma(fa1, b, a1[nt]);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- z-update: w block k = (u_k, x_{k+1}) ----
+        const unsigned r0 = (unsigned)(k - k0) * NB * PB;
+#pragma unroll
+        for (int nt = 0; nt < MF_NT; ++nt) {
+          double vn;
+#pragma unroll
+          for (int r = 0; r < 3; ++r) {
+            mf_zupdate<RESID, RELAX>(c0[nt][r], (double)X[nt][r], lohi[r * 4 + g], lohi[20 + r * 4 + g], alpha, rho, vn, gg[nt][r], racc[nt]);
+            vv.store(vn, okx[r] ? lbs[nt] : ROWVIEW_OOB, r0 + (unsigned)(NU + 4 * r) * PB);
+            X[nt][r] = a0[nt][r];                                 // x_k
+          }
+          mf_zupdate<RESID, RELAX>(c0[nt][3], (double)a0[nt][3], lohi[12 + g], lohi[32 + g], alpha, rho, vn, gg[nt][3], racc[nt]);
+          vv.store(vn, oku0 ? lbs[nt] : ROWVIEW_OOB, r0);
+          if (XT) {
+            mf_zupdate<RESID, RELAX>(c0[nt][4], (double)a1[nt][0], lohi[16 + g], lohi[36 + g], alpha, rho, vn, gg[nt][4], racc[nt]);
+            vv.store(vn, oku1 ? lbs[nt] : ROWVIEW_OOB, r0 + 4u * PB);
+          } else {
+            gg[nt][4] = 0.0;
+          }
+        }
+      } else {
+        // the plain path's backward sweep: linear term of the CURRENT state, z = clip(v), y = v - z
+#pragma unroll
+        for (int nt = 0; nt < MF_NT; ++nt)
+#pragma unroll
+          for (int q = 0; q < 5; ++q) {
+            const int slot = q * 4 + g;
+            const double zz = fmin(fmax(c0[nt][q], lohi[slot]), lohi[20 + slot]);
+            gg[nt][q] = (q < 4 || XT) ? -rho * (zz - (c0[nt][q] - zz)) : 0.0;
+          }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- ELIM_B ----
+      {
+        const T* ae = af + O_ELIM;
+        acc_t e0[MF_NT], e1[MF_NT];
+        T pp[MF_NT][3];
+#pragma unroll
+        for (int nt = 0; nt < MF_NT; ++nt) {
+          e0[nt] = acc_t{0, 0, 0, 0};
+          e1[nt] = acc_t{Ee[nt][0], Ee[nt][1], Ee[nt][2], 0};
+#pragma unroll
+          for (int r = 0; r < 3; ++r) pp[nt][r] = (T)gg[nt][r] + Tt[nt][r];
+        }
+#pragma unroll
+        for (int ks = 0; ks < KE; ++ks) {
+          const T fa0 = ae[(ks * 2 + 0) * 64 + lane], fa1 = ae[(ks * 2 + 1) * 64 + lane];
+#pragma unroll
+          for (int nt = 0; nt < MF_NT; ++nt) {
+            const T b = ks < 3 ? pp[nt][ks < 3 ? ks : 0] : (T)gg[nt][ks == 3 ? 3 : 4];
+            e0[nt] = Ops::mfma(fa0, b, e0[nt]);
+            e1[nt] = Ops::mfma(fa1, b, e1[nt]);
+          }
+        }
+        const unsigned d0 = (unsigned)(k - k0) * NU * PB;
+#pragma unroll
+        for (int nt = 0; nt < MF_NT; ++nt) {
+#pragma unroll
+          for (int r = 0; r < 3; ++r) { Tt[nt][r] = e0[nt][r]; Ee[nt][r] = e1[nt][r]; }
+          vd.store((double)e0[nt][3], oku0 ? lbs[nt] : ROWVIEW_OOB, d0);
+          if (XT) vd.store((double)e1[nt][3], oku1 ? lbs[nt] : ROWVIEW_OOB, d0 + 4u * PB);
+        }
+      }
+    }
+    __syncthreads();
+    buf ^= 1;
+  }
+#pragma unroll
+  for (int nt = 0; nt < MF_NT; ++nt) {
+    const bool st = lbs[nt] != ROWVIEW_OOB;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+      if (st && okx[r]) {
+        const size_t o = ((size_t)s * NX + 4 * r + g) * P + col[nt];
+        tseg[o] = (double)Tt[nt][r];
+        eseg[o] = (double)Ee[nt][r];
+      }
+    if (RESID && SUBST) {
+#pragma unroll
+      for (int q = 0; q < 5; ++q) {
+        const double t = mf_colsum(racc[nt][q]);
+        if (st && g == 0) part[((size_t)s * 5 + q) * P + col[nt]] = t;
+      }
+    }
+  }
+}
+
+}  // namespace admm

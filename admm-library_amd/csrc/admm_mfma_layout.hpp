@@ -1,0 +1,74 @@
+// admm_mfma_layout.hpp -- layout of the MFMA form of the fused stage operators, shared by the
+// host packing (admm_factor.cpp, runtime n, m) and the kernels (admm_mfma.hpp, compile-time NX, NU).
+// No reference counterpart exists (README.md:1-2 only).
+//
+// Why: with one lane per QP the per-stage matrices reach the lanes as LDS BROADCASTS, 2 LDS cycles per double
+// per wave.  At n = 12, m = 6 a stage of the fused forward kernel reads 900 doubles = 1800 LDS cycles per wave,
+// 7200 per CU with four waves, against 3600 cycles of fp64 FMA issue per wave: the kernel is bound by operand
+// delivery, not by arithmetic or HBM.  An MFMA takes its matrix operand DISTRIBUTED over the lanes (one element
+// per lane per instruction), so the same operators cost 32 ds_read_b64 per wave per stage.
+//
+// Form: per stage the block-banded solve is a chain of small dense products
+//     [outputs](rows) x 16 QPs  =  M_k (rows x cols)  x  [inputs](cols) x 16 QPs
+// with the batch-minor panel of 16 QPs as the B operand and the accumulator tile of one stage used, register for
+// register, as the B operand of the next (no lane movement: see `slot` below).
+//
+// Vector tile ("slot" addressing).  A 16-row x 16-QP accumulator tile is 4 registers per lane; lane l serves
+// QP column c = l & 15 and lane group g = l >> 4.  Register r of lane group g is called slot (r, g).  A block
+// vector (u (m), x (n)), n <= 12, m <= 8, is held as
+//     main tile:   slots (r, g), r = 0..2  ->  x row 4 r + g        slot (3, g)  ->  u row g
+//     extra reg:   slot  (4, g)            ->  u row 4 + g           (only when m > 4)
+// As the B operand of v_mfma_*_16x16x4 a register IS one k-step: lane group g supplies k = g, so k-step "register r"
+// multiplies matrix columns {slot (r, 0..3)}.  As a D result the hardware row of slot (r, g) is
+//     fp64 (v_mfma_f64_16x16x4_f64):  row = g + 4 r        fp32 (v_mfma_f32_16x16x4_f32):  row = 4 g + r
+// (cdna_hip_programming.md §3); the host writes each A fragment with the matrix row the hardware row stands for,
+// so the kernels never convert between the two.
+//
+// Products (matrices folded on the host in fp64 from the blocks of admm_layout.hpp):
+//   forward kernel   SUB_F : [x+ ; u]          = [A-BK, -B Psi, -B ; -K, -Psi, -I]        [x ; t_in ; d]
+//                    ELIM_F: [mu+ ; deps ; db] = [FM, PI, GA ; OB DK, 0, OB DG ; DK, 0, DG] [mu ; g^x ; g^u]
+//   backward kernel  SUB_B : [x_k ; u]         = [AI-AIB' KB, -AIB' PSB, -AIB' ; -KB, -PSB, -I] [x_{k+1} ; m_in ; db]   (AIB' = A^-1 B)
+//                    ELIM_B: [t+ ; de ; d0]    = [AT-KT BT, -KT ; OM SI BT, OM SI ; SI BT, SI]  [p ; g^u]
+// k-steps: each input n-vector is 3 registers, the m-vector 1 (+1 when m > 4).  Output tiles: tile 0 = first
+// n-vector + rows 0..3 of the m-vector (slot (3, g)), tile 1 = second n-vector + rows 4..7 of the m-vector (ELIM), or
+// just rows 4..7 of u in its register 0 (SUB, only when m > 4).
+//
+// Per-stage record (element type T = double or float), in the order the kernel consumes it:
+//     SUB  fragments  [ks][ot][64 lanes]      ELIM fragments [ks][ot][64 lanes]      lo [20], hi [20] as fp64
+// lo / hi are indexed by slot (r * 4 + g, r = 0..4); slots that stand for no row carry (-inf, +inf).
+#pragma once
+
+namespace admm {
+
+struct MfmaLayout {
+  int xt;                    // 1 when m > 4 (extra u register / second SUB output tile)
+  int ks_sub, ot_sub;        // k-steps and output tiles of SUB_F / SUB_B
+  int ks_elim_f, ks_elim_b;  // k-steps of ELIM_F / ELIM_B (two output tiles each)
+  int nf_sub, nf_elim_f, nf_elim_b;   // fragments (of 64 elements) per stage
+  int lohi_doubles;          // 40
+};
+constexpr MfmaLayout mfma_layout(int n, int m) {
+  MfmaLayout l{};
+  (void)n;
+  l.xt = m > 4 ? 1 : 0;
+  l.ks_sub = 3 + 3 + 1 + l.xt;
+  l.ot_sub = 1 + l.xt;
+  l.ks_elim_f = 3 + 3 + 1 + l.xt;
+  l.ks_elim_b = 3 + 1 + l.xt;
+  l.nf_sub = l.ks_sub * l.ot_sub;
+  l.nf_elim_f = l.ks_elim_f * 2;
+  l.nf_elim_b = l.ks_elim_b * 2;
+  l.lohi_doubles = 40;
+  return l;
+}
+constexpr bool mfma_dims(int n, int m) { return n >= 1 && n <= 12 && m >= 1 && m <= 8; }
+
+// bytes of one stage's record (multiples of 16)
+constexpr int mfma_rec_bytes_fwd(int n, int m, int elem_bytes) {
+  return (mfma_layout(n, m).nf_sub + mfma_layout(n, m).nf_elim_f) * 64 * elem_bytes + 40 * 8;
+}
+constexpr int mfma_rec_bytes_bwd(int n, int m, int elem_bytes) {
+  return (mfma_layout(n, m).nf_sub + mfma_layout(n, m).nf_elim_b) * 64 * elem_bytes + 40 * 8;
+}
+
+}  // namespace admm

@@ -73,6 +73,9 @@ _SIGNATURES = {
     "admm_record_sizes_alt": (C.c_int, [C.c_int32, C.c_int32, c_int32_p, c_int32_p]),
     "admm_host_factor_alt": (C.c_int, [C.POINTER(CProblem), C.c_double, C.c_int32, c_double_p, c_double_p,
                                        c_double_p, c_int32_p]),
+    "admm_mfma_record_bytes": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, c_int32_p, c_int32_p]),
+    "admm_host_factor_mfma": (C.c_int, [C.POINTER(CProblem), C.c_double, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                        c_int32_p]),
 }
 
 
@@ -123,6 +126,7 @@ class Options:
     adapt_max: int = 16
     adapt_mu: float = 10.0
     adapt_tau: float = 2.0
+    precision_mode: int = 0       # _abi.PRECISION_FP64 / _MIXED / _FP64_MFMA
 
     def to_c(self) -> COptions:
         return _abi.make_options(**dataclasses.asdict(self))
@@ -137,6 +141,7 @@ class SolveInfo:
     solve_ms: float
     rho: float
     rho_updates: int
+    mixed_iters: int
     iters: np.ndarray
     status: np.ndarray
     r: np.ndarray
@@ -212,7 +217,7 @@ class Solver:
         s = np.empty(self.batch)
         _check(self._lib, self._lib.admm_get_info(self._h, iptr(iters), iptr(status), dptr(r), dptr(s)))
         return SolveInfo(ci.iters_run, ci.n_converged, ci.max_r, ci.max_s, ci.solve_ms, ci.rho, ci.rho_updates,
-                         iters, status, r, s)
+                         ci.mixed_iters, iters, status, r, s)
 
     def solve(self, z0=None, y0=None) -> SolveInfo:
         z0, y0 = self._vec(z0), self._vec(y0)
@@ -345,3 +350,18 @@ def host_factor(problem: Problem, rho: float, segments: int):
         out.update(alt_ok=True, recFE=recFE, recBE=recBE, scanWB=WB)
     del keep
     return out
+
+
+def host_factor_mfma(problem: Problem, rho: float, segments: int, elem_bytes: int):
+    """Host-only: the MFMA fragment records exactly as admm_setup uploads them, as
+    (N, bytes) uint8 arrays (forward, backward), plus whether the forward-elimination products are present."""
+    lib = load_library()
+    cp, keep = _abi.marshal_problem(problem)
+    fb, bb, ok = C.c_int32(), C.c_int32(), C.c_int32()
+    _check(lib, lib.admm_mfma_record_bytes(problem.n, problem.m, int(elem_bytes), C.byref(fb), C.byref(bb)))
+    recMF = np.zeros((problem.N, fb.value), np.uint8)
+    recMB = np.zeros((problem.N, bb.value), np.uint8)
+    _check(lib, lib.admm_host_factor_mfma(C.byref(cp), float(rho), int(segments), int(elem_bytes),
+                                          recMF.ctypes.data_as(C.c_void_p), recMB.ctypes.data_as(C.c_void_p), C.byref(ok)))
+    del keep
+    return recMF, recMB, bool(ok.value)

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ADMM_HIP_ABI_VERSION 3
+#define ADMM_HIP_ABI_VERSION 4
 
 typedef enum admm_status {
   ADMM_OK = 0,
@@ -91,7 +91,24 @@ typedef struct admm_options {
   int32_t adapt_max;      /* at most this many rho changes per admm_solve */
   double adapt_mu;        /* > 1 */
   double adapt_tau;       /* > 1 */
+  /* Arithmetic of the x-update (ABI v4; BASELINE.json configs[4]).  ADMM_PRECISION_*:
+   *   FP64       one lane per QP, fp64 vector FMAs (every compiled (n, m), q, thrust-magnitude bound).
+   *   FP64_MFMA  the fused stage operators as chains of v_mfma_f64_16x16x4_f64 over 16-QP panels: the same fp64
+   *              iteration (iterates equal to FP64's to rounding), faster where operand delivery binds (n = 12).
+   *   MIXED      the x-update's sweeps in fp32 on v_mfma_f32_16x16x4_f32 (plain Riccati path); the state v, the
+   *              z-update, the dual and the residuals stay fp64.  admm_solve refines in fp64: it iterates in fp32
+   *              until the stopping rule holds with eps_abs, eps_rel raised to at least 1e-4, then continues with
+   *              the FP64 kernels until it holds as given (admm_info.mixed_iters = length of the first phase).
+   *              admm_run / admm_iterate always run the fp32 form.
+   * The two MFMA forms exist for the (n, m) pairs of csrc/admm_mfma.hip, without q and without a thrust-magnitude
+   * bound: ADMM_ERR_UNSUPPORTED otherwise. */
+  int32_t precision_mode;
+  int32_t reserved;       /* must be 0 */
 } admm_options;
+
+#define ADMM_PRECISION_FP64 0
+#define ADMM_PRECISION_MIXED 1
+#define ADMM_PRECISION_FP64_MFMA 2
 
 #define ADMM_FLAG_NONE 0
 #define ADMM_FLAG_NO_GRAPH 1   /* accepted, no effect: direct launches are the default (see ADMM_FLAG_GRAPH) */
@@ -117,7 +134,7 @@ typedef struct admm_info {
   double  solve_ms;       /* wall time of the last admm_solve (host clock) */
   double  rho;            /* rho in force at the end of the solve */
   int32_t rho_updates;    /* rho changes made by the adaptive rule during the solve */
-  int32_t reserved;
+  int32_t mixed_iters;    /* ADMM_PRECISION_MIXED: iterations run in fp32 before the fp64 refinement phase (else 0) */
 } admm_info;
 
 typedef struct admm_handle admm_handle;
@@ -253,6 +270,13 @@ int admm_host_scan_matrix(const admm_problem* p, double rho, int32_t segments, d
 int admm_record_sizes_alt(int32_t n, int32_t m, int32_t* rfe, int32_t* rbe);
 int admm_host_factor_alt(const admm_problem* p, double rho, int32_t segments, double* recFE, double* recBE,
                          double* WB, int32_t* ok);
+
+/* MFMA form (csrc/admm_mfma_layout.hpp): bytes per stage of the forward / backward fragment
+ * records for element size elem_bytes (4 = fp32, 8 = fp64), and the records themselves (N * bytes each; either
+ * pointer may be NULL).  *alt_ok = 0: the ELIM_F / SUB_B fragments are zero (no forward-elimination form). */
+int admm_mfma_record_bytes(int32_t n, int32_t m, int32_t elem_bytes, int32_t* fwd, int32_t* bwd);
+int admm_host_factor_mfma(const admm_problem* p, double rho, int32_t segments, int32_t elem_bytes, void* recMF,
+                          void* recMB, int32_t* alt_ok);
 
 const char* admm_last_error(void);
 int admm_abi_version(void);
