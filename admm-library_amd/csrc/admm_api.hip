@@ -65,10 +65,10 @@ struct admm_handle {
   // alternating-direction iteration
   double *recFE = nullptr, *recBE = nullptr, *mvec = nullptr, *scanWpB = nullptr;
   int* scan_rangeB = nullptr;
-  // MFMA form of the fused kernels: fragment records, element size (0 = not in use), and whether
+  // MFMA form of the fused kernels: fragment records, mode (0 = not in use, 1 mixed, 2 fp64), and whether
   // launch_x currently routes to it (the fp64 refinement phase of a MIXED solve turns it off)
   unsigned char *recMF = nullptr, *recMB = nullptr;
-  int mfma_elem = 0;
+  int mfma_mode = 0;
   bool mfma_on = false;
   bool alt_allowed = false;      // alternation permitted by the options / compiled kernels (before the precision mode)
   // MIXED solve: phase 1 (fp32) checks the stopping rule with raised tolerances on scratch status arrays
@@ -125,7 +125,7 @@ admm::XLaunch xlaunch_of(const admm_handle* h) {
   l.nsplit = chain ? 1 : h->scan_split;
   l.split_stride = (size_t)h->fac.scanM * h->pitch;
   l.recMF = h->recMF; l.recMB = h->recMB;
-  l.mfma_elem = h->mfma_on ? h->mfma_elem : 0;
+  l.mfma_mode = h->mfma_on ? h->mfma_mode : 0;
   return l;
 }
 
@@ -148,7 +148,7 @@ int launch_x(admm_handle* h, admm::XKernel k, bool a, bool b) {
   const admm::XLaunch l = xlaunch_of(h);
   // MFMA form: the alternating pair (fp64 records) or the plain path's v-form kernels (fp32 records); every other
   // kernel form -- (z, y)-input first iterations, read-out -- stays on the one-lane fp64 kernels (same arrays)
-  if (l.mfma_elem) {
+  if (l.mfma_mode) {
     const bool vform_ok = (k == admm::XKernel::XFZE || k == admm::XKernel::XBZE) || a;
     if (vform_ok && admm::launch_mfma(l, k, b, false)) return ADMM_OK;
   }
@@ -401,13 +401,12 @@ int validate_problem(const admm_problem* p) {
   return ADMM_OK;
 }
 
-// MIXED precision: fp32 = the fp32-MFMA kernels on the plain path; otherwise (the fp64 refinement
-// phase of admm_solve) the default fp64 kernels, alternation included.  Both forms share every device array; what an
-// alternating iteration left pending is dropped at the switch.
+// MIXED precision: fp32 = the mixed MFMA kernels; otherwise (the fp64 refinement phase of
+// admm_solve) the one-lane fp64 kernels.  Both forms share every device array and the alternation schedule; what an
+// alternating iteration left pending is dropped at the switch (the next iteration starts with a backward sweep).
 void set_mixed_form(admm_handle* h, bool fp32) {
   if (h->opt.precision_mode != ADMM_PRECISION_MIXED) return;
   h->mfma_on = fp32;
-  h->alt = fp32 ? false : h->alt_allowed;
   h->alt_state = admm_handle::ALT_NONE;
 }
 
@@ -480,7 +479,7 @@ int upload_factor(admm_handle* h) {
   HIP_TRY(hipMemcpy(h->scan_range, h->fac.scanRange.data(), sizeof(int32_t) * h->fac.scanRange.size(), hipMemcpyHostToDevice));
   h->alt_state = admm_handle::ALT_NONE;
   if (!h->fac.alt_ok) { h->alt = false; h->alt_allowed = false; }   // the forward-elimination form did not survive the refactor
-  if (h->mfma_elem) {
+  if (h->mfma_mode) {
     HIP_TRY(hipMemcpy(h->recMF, h->fac.recMF.data(), h->fac.recMF.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->recMB, h->fac.recMB.data(), h->fac.recMB.size(), hipMemcpyHostToDevice));
   }
@@ -627,21 +626,21 @@ int admm_host_factor_alt(const admm_problem* p, double rho, int32_t segments, do
   return ADMM_OK;
 }
 
-int admm_mfma_record_bytes(int32_t n, int32_t m, int32_t elem_bytes, int32_t* fwd, int32_t* bwd) {
+int admm_mfma_record_bytes(int32_t n, int32_t m, int32_t mode, int32_t* fwd, int32_t* bwd) {
   if (!admm::mfma_dims(n, m)) return fail(ADMM_ERR_UNSUPPORTED, "the MFMA form needs 1 <= n <= 12 and 1 <= m <= 8");
-  if (elem_bytes != 4 && elem_bytes != 8) return fail(ADMM_ERR_INVALID, "elem_bytes must be 4 or 8");
-  if (fwd) *fwd = admm::mfma_rec_bytes_fwd(n, m, elem_bytes);
-  if (bwd) *bwd = admm::mfma_rec_bytes_bwd(n, m, elem_bytes);
+  if (mode != 1 && mode != 2) return fail(ADMM_ERR_INVALID, "mode must be ADMM_PRECISION_MIXED or ADMM_PRECISION_FP64_MFMA");
+  if (fwd) *fwd = admm::mfma_rec_bytes_fwd(n, m, mode);
+  if (bwd) *bwd = admm::mfma_rec_bytes_bwd(n, m, mode);
   return ADMM_OK;
 }
 
-int admm_host_factor_mfma(const admm_problem* p, double rho, int32_t segments, int32_t elem_bytes, void* recMF,
+int admm_host_factor_mfma(const admm_problem* p, double rho, int32_t segments, int32_t mode, void* recMF,
                           void* recMB, int32_t* alt_ok) {
   if (!p) return fail(ADMM_ERR_INVALID, "NULL problem");
-  if (elem_bytes != 4 && elem_bytes != 8) return fail(ADMM_ERR_INVALID, "elem_bytes must be 4 or 8");
+  if (mode != 1 && mode != 2) return fail(ADMM_ERR_INVALID, "mode must be ADMM_PRECISION_MIXED or ADMM_PRECISION_FP64_MFMA");
   admm::Factor f;
   std::string err;
-  int rc = admm::factorise(*p, rho, segments, f, err, elem_bytes);
+  int rc = admm::factorise(*p, rho, segments, f, err, mode);
   if (rc) return fail(rc, err);
   if (recMF) std::memcpy(recMF, f.recMF.data(), f.recMF.size());
   if (recMB) std::memcpy(recMB, f.recMB.data(), f.recMB.size());
@@ -730,19 +729,19 @@ int admm_setup(admm_handle** out, const admm_problem* p, const admm_options* o_i
   if (o.precision_mode != ADMM_PRECISION_FP64) {
     admm::XLaunch lq{};
     lq.n = p->n; lq.m = p->m;
-    lq.mfma_elem = o.precision_mode == ADMM_PRECISION_MIXED ? 4 : 8;
+    lq.mfma_mode = o.precision_mode == ADMM_PRECISION_MIXED ? 1 : 2;
     const bool compiled = admm::mfma_dims(p->n, p->m) &&
-                          admm::launch_mfma(lq, o.precision_mode == ADMM_PRECISION_MIXED ? admm::XKernel::XFZ : admm::XKernel::XFZE, false, true);
+                          admm::launch_mfma(lq, admm::XKernel::XFZE, false, true);
     std::string why;
     if (!compiled) why = "(n, m) has no MFMA instantiation; compiled: " + std::string(admm::dims_mfma());
     else if (h->has_q) why = "a linear term q is not supported by the MFMA forms";
     else if (h->has_soc) why = "a thrust-magnitude bound is not supported by the MFMA forms";
     else if (o.flags & (ADMM_FLAG_UNFUSED | ADMM_FLAG_SCAN_CHAIN)) why = "ADMM_FLAG_UNFUSED / ADMM_FLAG_SCAN_CHAIN exclude the MFMA forms";
     if (!why.empty()) { release(h); return fail(ADMM_ERR_UNSUPPORTED, "precision_mode " + std::to_string(o.precision_mode) + ": " + why); }
-    h->mfma_elem = lq.mfma_elem;
+    h->mfma_mode = lq.mfma_mode;
   }
   std::string err;
-  rc = admm::factorise(*p, o.rho, h->S, h->fac, err, h->mfma_elem);
+  rc = admm::factorise(*p, o.rho, h->S, h->fac, err, h->mfma_mode);
   if (rc) { release(h); return fail(rc, err); }
   // Conditioning guard of the parallel-in-time form: the segment coupling is exact in exact
   // arithmetic, but its transfer matrices are products of closed-loop matrices, and for a barely
@@ -754,7 +753,7 @@ int admm_setup(admm_handle** out, const admm_problem* p, const admm_options* o_i
   if (o.segments == 0) {
     while (h->fac.S > 1 && scan_growth(h->fac) > SCAN_GROWTH_MAX) {
       const int S2 = std::max(1, h->fac.S / 2);
-      rc = admm::factorise(*p, o.rho, S2, h->fac, err, h->mfma_elem);
+      rc = admm::factorise(*p, o.rho, S2, h->fac, err, h->mfma_mode);
       if (rc) { release(h); return fail(rc, err); }
     }
   }
@@ -810,11 +809,9 @@ int admm_setup(admm_handle** out, const admm_problem* p, const admm_options* o_i
   h->alt_allowed = h->fac.alt_ok && fused(h) &&
                    !(h->opt.flags & (ADMM_FLAG_SCAN_CHAIN | ADMM_FLAG_NO_ALTERNATE)) &&
                    dispatch_x(xlaunch_of(h), admm::XKernel::XFZE, false, false, /*query_only=*/true);
-  // MIXED runs the plain (Riccati) path: the forward-elimination form's early-stage gains are not fp32-safe.
-  // Its fp64 refinement phase switches the alternation back on (set_mfma below).
-  h->alt = h->alt_allowed && o.precision_mode != ADMM_PRECISION_MIXED;
-  h->mfma_on = h->mfma_elem != 0 && (o.precision_mode == ADMM_PRECISION_MIXED || h->alt);
-  if (h->mfma_elem) {
+  h->alt = h->alt_allowed;
+  h->mfma_on = h->mfma_mode != 0 && (o.precision_mode == ADMM_PRECISION_MIXED || h->alt);
+  if (h->mfma_mode) {
     // (+ 1 KiB: the LDS-DMA copy of a chunk moves whole KiB pieces, admm_mfma.hpp)
     HIP_TRY_RELEASE(hipMalloc((void**)&h->recMF, h->fac.recMF.size() + 1024));
     HIP_TRY_RELEASE(hipMalloc((void**)&h->recMB, h->fac.recMB.size() + 1024));
@@ -912,7 +909,7 @@ static int set_rho_internal(admm_handle* h, double rho_new) {
   p.unorm = h->pun.empty() ? nullptr : h->pun.data();
   admm::Factor f;
   std::string err;
-  int rc = admm::factorise(p, rho_new, h->S, f, err, h->mfma_elem);
+  int rc = admm::factorise(p, rho_new, h->S, f, err, h->mfma_mode);
   if (rc) return fail(rc, err);
   if (f.recB.size() != h->fac.recB.size() || f.scanWp.size() != h->fac.scanWp.size())
     return fail(ADMM_ERR_NUMERIC, "internal: record sizes changed on refactor");
@@ -958,7 +955,7 @@ int admm_update_problem(admm_handle* h, const admm_problem* p) {
     return fail(ADMM_ERR_INVALID, "admm_update_problem: a thrust-magnitude bound cannot be added to or removed from a handle");
   admm::Factor f;
   std::string err;
-  if ((rc = admm::factorise(*p, h->opt.rho, h->S, f, err, h->mfma_elem))) return fail(rc, err);
+  if ((rc = admm::factorise(*p, h->opt.rho, h->S, f, err, h->mfma_mode))) return fail(rc, err);
   if (f.recB.size() != h->fac.recB.size() || f.scanWp.size() != h->fac.scanWp.size())
     return fail(ADMM_ERR_NUMERIC, "internal: record sizes changed on refactor");
   if (h->auto_segments && h->S > 1 && scan_growth(f) > SCAN_GROWTH_MAX)

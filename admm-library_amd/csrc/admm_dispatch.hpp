@@ -23,9 +23,9 @@ struct XLaunch {
   const double* x0;
   int nsplit;                   // split-K slabs of the scan output (t_in / x_in), 1 = none
   size_t split_stride;          // elements between slabs
-  // MFMA form (admm_mfma.hpp): per-stage fragment records, element size 4 (fp32) / 8 (fp64), 0 = not in use
+  // MFMA form (admm_mfma.hpp): per-stage fragment records; mode 1 = mixed, 2 = fp64, 0 = not in use
   const unsigned char *recMF, *recMB;
-  int mfma_elem;
+  int mfma_mode;
 };
 
 enum class XKernel { XB, XF, XFZ, XSCAN_CHAIN, XFZE, XBZE };
@@ -37,7 +37,7 @@ bool launch_group0(const XLaunch& l, XKernel k, bool a, bool b, bool query_only)
 bool launch_group1(const XLaunch& l, XKernel k, bool a, bool b, bool query_only);
 bool launch_group2(const XLaunch& l, XKernel k, bool a, bool b, bool query_only);
 bool launch_group3(const XLaunch& l, XKernel k, bool a, bool b, bool query_only);
-// MFMA form of XFZE / XBZE (fp64 records) or of XB / XFZ in v-form (fp32 records), by l.mfma_elem; false if the
+// MFMA form of XFZE / XBZE (modes 1, 2) and of XB / XFZ in v-form (mode 1), by l.mfma_mode; false if the
 // (n, m) pair or the kernel has no MFMA instantiation.
 bool launch_mfma(const XLaunch& l, XKernel k, bool resid, bool query_only);
 const char* dims_mfma();

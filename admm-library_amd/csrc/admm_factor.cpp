@@ -500,23 +500,22 @@ void put_block(Mat& M, int C, int r0, int c0, const Mat& B, int r, int c, double
     for (int j = 0; j < c; ++j) M[(size_t)(r0 + i) * C + c0 + j] = sgn * B[(size_t)i * c + j];
 }
 
-void write_record(unsigned char* dst, const Frags& fr, const double* lohi, int elem) {
+unsigned char* write_frags(unsigned char* dst, const Frags& fr, int elem) {
   if (elem == 8) {
     std::memcpy(dst, fr.v.data(), fr.v.size() * 8);
   } else {
     float* o = reinterpret_cast<float*>(dst);
     for (size_t i = 0; i < fr.v.size(); ++i) o[i] = (float)fr.v[i];
   }
-  std::memcpy(dst + fr.v.size() * elem, lohi, 40 * 8);
+  return dst + fr.v.size() * elem;
 }
 
-void build_mfma(Factor& f, int elem) {
+void build_mfma(Factor& f, int mode) {
   const int N = f.N, n = f.n, m = f.m;
   const MfmaLayout L = mfma_layout(n, m);
-  const bool f32 = elem == 4;
-  f.mfma_elem = elem;
-  f.RMF = mfma_rec_bytes_fwd(n, m, elem);
-  f.RMB = mfma_rec_bytes_bwd(n, m, elem);
+  f.mfma_mode = mode;
+  f.RMF = mfma_rec_bytes_fwd(n, m, mode);
+  f.RMB = mfma_rec_bytes_bwd(n, m, mode);
   f.recMF.assign((size_t)N * f.RMF, 0);
   f.recMB.assign((size_t)N * f.RMB, 0);
   const RecBLayout lb = rec_b_layout(n, m);
@@ -565,7 +564,7 @@ void build_mfma(Factor& f, int elem) {
       }
     const int C3 = 2 * n + m;
     {  // ---------------- forward record: SUB_F, ELIM_F ----------------
-      Frags fr;
+      Frags fr, fe;
       Mat Ms((size_t)(n + m) * C3, 0.0);
       const Mat BK = mul(B, K, n, m, n), BPsi = mul(B, Psi, n, m, n);
       put_block(Ms, C3, 0, 0, sub(A, BK), n, n, 1.0);        // x+ = (A - B K) x - B Psi t - B d
@@ -574,7 +573,7 @@ void build_mfma(Factor& f, int elem) {
       put_block(Ms, C3, n, 0, K, m, n, -1.0);                // u  = -K x - Psi t - d
       put_block(Ms, C3, n, n, Psi, m, n, -1.0);
       put_block(Ms, C3, n, 2 * n, Im, m, m, -1.0);
-      pack_product(fr, Ms, C3, L.ks_sub, L.ot_sub, f32, sub_out, sub_in);
+      pack_product(fr, Ms, C3, L.ks_sub, L.ot_sub, mfma_es_sub_f(mode) == 4, sub_out, sub_in);
       Mat Me((size_t)(2 * n + m) * C3, 0.0);                 // rows [mu+ ; deps ; db], cols [mu ; g^x ; g^u]
       if (f.alt_ok) {
         const double* rfe = &f.recFE[(size_t)k * f.RFE];
@@ -588,11 +587,13 @@ void build_mfma(Factor& f, int elem) {
         put_block(Me, C3, 2 * n, 0, DK, m, n, 1.0);
         put_block(Me, C3, 2 * n, 2 * n, DG, m, m, 1.0);
       }
-      pack_product(fr, Me, C3, L.ks_elim_f, 2, f32, elim_out, sub_in);
-      write_record(&f.recMF[(size_t)k * f.RMF], fr, lohi, elem);
+      pack_product(fe, Me, C3, L.ks_elim_f, 2, mfma_es_elim_f(mode) == 4, elim_out, sub_in);
+      unsigned char* o = write_frags(&f.recMF[(size_t)k * f.RMF], fr, mfma_es_sub_f(mode));
+      o = write_frags(o, fe, mfma_es_elim_f(mode));
+      std::memcpy(o, lohi, 40 * 8);
     }
     {  // ---------------- backward record: SUB_B, ELIM_B ----------------
-      Frags fr;
+      Frags fr, fe;
       Mat Ms((size_t)(n + m) * C3, 0.0);                     // rows [x_k ; u], cols [x_{k+1} ; m_in ; db]
       if (f.alt_ok) {
         const double* rbe = &f.recBE[(size_t)k * f.RBE];
@@ -605,7 +606,7 @@ void build_mfma(Factor& f, int elem) {
         put_block(Ms, C3, n, n, PSB, m, n, -1.0);
         put_block(Ms, C3, n, 2 * n, Im, m, m, -1.0);
       }
-      pack_product(fr, Ms, C3, L.ks_sub, L.ot_sub, f32, sub_out, sub_in);
+      pack_product(fr, Ms, C3, L.ks_sub, L.ot_sub, mfma_es_sub_b(mode) == 4, sub_out, sub_in);
       const int C2 = n + m;
       Mat Me((size_t)(2 * n + m) * C2, 0.0);                 // rows [t+ ; de ; d0], cols [p ; g^u]
       const Mat SIBT = mul(SI, BT, m, m, n);
@@ -615,17 +616,19 @@ void build_mfma(Factor& f, int elem) {
       put_block(Me, C2, n, n, mul(OM, SI, n, m, m), n, m, 1.0);
       put_block(Me, C2, 2 * n, 0, SIBT, m, n, 1.0);                             // d0 = Si (B' p + g^u)
       put_block(Me, C2, 2 * n, n, SI, m, m, 1.0);
-      pack_product(fr, Me, C2, L.ks_elim_b, 2, f32, elim_out, elimb_in);
-      write_record(&f.recMB[(size_t)k * f.RMB], fr, lohi, elem);
+      pack_product(fe, Me, C2, L.ks_elim_b, 2, mfma_es_elim_b(mode) == 4, elim_out, elimb_in);
+      unsigned char* o = write_frags(&f.recMB[(size_t)k * f.RMB], fr, mfma_es_sub_b(mode));
+      o = write_frags(o, fe, mfma_es_elim_b(mode));
+      std::memcpy(o, lohi, 40 * 8);
     }
   }
 }
 
 }  // namespace
 
-int factorise(const admm_problem& p, double rho, int segments, Factor& f, std::string& err, int mfma_elem) {
-  if (mfma_elem != 0 && !(mfma_elem == 4 || mfma_elem == 8)) { err = "mfma_elem must be 0, 4 or 8"; return ADMM_ERR_INVALID; }
-  if (mfma_elem != 0 && !mfma_dims(p.n, p.m)) { err = "the MFMA form needs n <= 12 and m <= 8"; return ADMM_ERR_UNSUPPORTED; }
+int factorise(const admm_problem& p, double rho, int segments, Factor& f, std::string& err, int mfma_mode) {
+  if (mfma_mode < 0 || mfma_mode > 2) { err = "mfma_mode must be 0, 1 or 2"; return ADMM_ERR_INVALID; }
+  if (mfma_mode != 0 && !mfma_dims(p.n, p.m)) { err = "the MFMA form needs n <= 12 and m <= 8"; return ADMM_ERR_UNSUPPORTED; }
   const int N = p.N, n = p.n, m = p.m;
   if (N < 1 || n < 1 || m < 1) { err = "N, n, m must be positive"; return ADMM_ERR_INVALID; }
   if (!(rho > 0.0) || !std::isfinite(rho)) { err = "rho must be positive and finite"; return ADMM_ERR_INVALID; }
@@ -783,10 +786,10 @@ int factorise(const admm_problem& p, double rho, int segments, Factor& f, std::s
   }
 
   build_alternating(f, A, B, Q, R, QN, rho);
-  f.mfma_elem = 0;
+  f.mfma_mode = 0;
   f.recMF.clear();
   f.recMB.clear();
-  if (mfma_elem) build_mfma(f, mfma_elem);
+  if (mfma_mode) build_mfma(f, mfma_mode);
   return ADMM_OK;
 }
 

@@ -73,10 +73,11 @@ struct Factor {
   std::vector<int32_t> scanRangeB;
 
   // MFMA form of the fused stage operators (admm_mfma_layout.hpp): per-stage records of
-  // pre-packed A fragments + the box in slot order, as raw bytes (element type fp32 or fp64).
-  // mfma_elem = 0: not built.  recMF = forward kernel (SUB_F, ELIM_F), recMB = backward kernel (SUB_B, ELIM_B);
+  // pre-packed A fragments + the box in slot order, as raw bytes (element type per product: mfma_es_*(mode)).
+  // mfma_mode = 0: not built; 1 = mixed (SUB_F, ELIM_B fp32; ELIM_F, SUB_B fp64); 2 = all fp64.
+  // recMF = forward kernel (SUB_F, ELIM_F), recMB = backward kernel (SUB_B, ELIM_B);
   // the ELIM_F / SUB_B fragments are zero when alt_ok is false (only the plain path may then use the records).
-  int mfma_elem = 0;                // bytes per element: 0, 4 or 8
+  int mfma_mode = 0;
   int RMF = 0, RMB = 0;             // bytes per stage
   std::vector<unsigned char> recMF; // N * RMF
   std::vector<unsigned char> recMB; // N * RMB
@@ -99,7 +100,7 @@ inline int rec_be_size(int n, int m) { return rec_be_layout(n, m).SIZE; }
 
 // Validates nothing about the batch; only dynamics/weights.  Returns an
 // admm_status; err receives a message on failure.
-// mfma_elem: 0 = no MFMA records; 4 / 8 = also pack the MFMA form in fp32 / fp64 (needs mfma_dims(n, m)).
-int factorise(const admm_problem& p, double rho, int segments, Factor& out, std::string& err, int mfma_elem = 0);
+// mfma_mode: 0 = no MFMA records; 1 / 2 = also pack the MFMA form, mixed / fp64 (needs mfma_dims(n, m)).
+int factorise(const admm_problem& p, double rho, int segments, Factor& out, std::string& err, int mfma_mode = 0);
 
 }  // namespace admm

@@ -19,29 +19,29 @@ namespace {
 
 template <int NX, int NU>
 bool launch_dim(const XLaunch& l, XKernel k, bool resid, bool query_only) {
-  const bool f32 = l.mfma_elem == 4;
-  // fp32: the plain path only (xb / xfz roles); fp64: the alternating pair
-  const bool ok = f32 ? (k == XKernel::XB || k == XKernel::XFZ) : (k == XKernel::XFZE || k == XKernel::XBZE);
+  const bool mixed = l.mfma_mode == 1;
+  // mode 2 (fp64): the alternating pair; mode 1 (mixed): the pair, and the plain path's v-form kernels (xb / xfz roles)
+  const bool ok = (k == XKernel::XFZE || k == XKernel::XBZE) || (mixed && (k == XKernel::XB || k == XKernel::XFZ));
   if (!ok) return false;
   if (query_only) return true;
   const dim3 grid((l.pitch + MF_COLS - 1) / MF_COLS, l.S), block(MF_THREADS);
   const bool relax = l.alpha != 1.0;
-#define FWD(T, RS, RX, EL)                                                                                          \
-  hipLaunchKernelGGL((xfzem_kernel<NX, NU, T, RS, RX, EL>), grid, block, 0, l.stream, l.dbuf, l.tin, l.xin, l.recMF, \
+#define FWD(TS, TE, RS, RX, EL)                                                                                      \
+  hipLaunchKernelGGL((xfzem_kernel<NX, NU, TS, TE, RS, RX, EL>), grid, block, 0, l.stream, l.dbuf, l.tin, l.xin, l.recMF, \
                      l.seg_start, l.v, l.mvec, l.tseg, l.eseg, l.part, l.alpha, l.rho, l.pitch, l.nsplit, l.split_stride)
-#define BWD(T, RS, RX, SB)                                                                                          \
-  hipLaunchKernelGGL((xbzem_kernel<NX, NU, T, RS, RX, SB>), grid, block, 0, l.stream, l.mvec, l.tin, l.xin, l.recMB, \
+#define BWD(TS, TE, RS, RX, SB)                                                                                      \
+  hipLaunchKernelGGL((xbzem_kernel<NX, NU, TS, TE, RS, RX, SB>), grid, block, 0, l.stream, l.mvec, l.tin, l.xin, l.recMB, \
                      l.seg_start, l.v, l.dbuf, l.tseg, l.eseg, l.part, l.alpha, l.rho, l.pitch, l.nsplit, l.split_stride)
-#define BY_FLAGS(CALL, T, LAST)                                                   \
-  do {                                                                            \
-    if (resid) { if (relax) CALL(T, true, true, LAST); else CALL(T, true, false, LAST); }   \
-    else       { if (relax) CALL(T, false, true, LAST); else CALL(T, false, false, LAST); } \
+#define BY_FLAGS(CALL, TS, TE, LAST)                                                      \
+  do {                                                                                    \
+    if (resid) { if (relax) CALL(TS, TE, true, true, LAST); else CALL(TS, TE, true, false, LAST); }   \
+    else       { if (relax) CALL(TS, TE, false, true, LAST); else CALL(TS, TE, false, false, LAST); } \
   } while (0)
   switch (k) {
-    case XKernel::XFZE: BY_FLAGS(FWD, double, true); break;
-    case XKernel::XBZE: BY_FLAGS(BWD, double, true); break;
-    case XKernel::XFZ:  BY_FLAGS(FWD, float, false); break;
-    case XKernel::XB:   BWD(float, false, false, false); break;
+    case XKernel::XFZE: if (mixed) BY_FLAGS(FWD, float, double, true); else BY_FLAGS(FWD, double, double, true); break;
+    case XKernel::XBZE: if (mixed) BY_FLAGS(BWD, double, float, true); else BY_FLAGS(BWD, double, double, true); break;
+    case XKernel::XFZ:  BY_FLAGS(FWD, float, double, false); break;
+    case XKernel::XB:   BWD(double, float, false, false, false); break;
     default: return false;
   }
 #undef BY_FLAGS

@@ -9,17 +9,19 @@
 // the host as A fragments (one element per lane per MFMA, admm_mfma_layout.hpp), and the accumulator tile of one
 // stage is, register for register, the B operand of the next.
 //
-//   xfzem_kernel<NX, NU, T, RESID, RELAX, ELIM>   forward:   SUB_F | z-update, dual, residual partials | ELIM_F
+//   xfzem_kernel<NX, NU, TS, TE, RESID, RELAX, ELIM>   forward:   SUB_F | z-update, dual, residual partials | ELIM_F
 //       ELIM = true : the alternating path's forward fused kernel (xfze_kernel)
 //       ELIM = false: the plain path's fused forward kernel (xfz_kernel, state in v-form)
-//   xbzem_kernel<NX, NU, T, RESID, RELAX, SUBST>  backward:  SUB_B | z-update, dual, residual partials | ELIM_B
+//   xbzem_kernel<NX, NU, TS, TE, RESID, RELAX, SUBST>  backward:  SUB_B | z-update, dual, residual partials | ELIM_B
 //       SUBST = true : the alternating path's backward fused kernel (xbze_kernel)
 //       SUBST = false: the plain path's backward sweep (xb_kernel, state in v-form; v is only read)
-//   T = double: exact -- iterates agree with the fp64 one-lane kernels to rounding (the operators are folded on the
-//       host, e.g. A - B K, so the rounding differs at the 1e-16 level).
-//   T = float : the x-update chains (x, t, mu, eps, d, db and the matrix operands) run in fp32 on the fp32 matrix
-//       pipe; v, the z-update, the dual and the residuals stay fp64.  Only on the plain path: the forward-elimination
-//       form's early-stage gains (2.5e4) are not fp32-safe.
+//   TS / TE = element type of the SUB / ELIM product (operands, chains and accumulators):
+//   all double (ADMM_PRECISION_FP64_MFMA): exact -- iterates agree with the fp64 one-lane kernels to rounding (the
+//       operators are folded on the host, e.g. A - B K, so the rounding differs at the 1e-16 level).
+//   mixed (ADMM_PRECISION_MIXED): the Riccati form's two products, SUB_F and ELIM_B (operators O(1)), in fp32 on the
+//       fp32 matrix pipe (half the cycles per MFMA); the forward-elimination form's ELIM_F and SUB_B, whose
+//       early-stage gains reach 2.5e4, in fp64.  So xfzem<float, double> / xbzem<double, float> on the alternating
+//       path; v, the z-update, the dual and the residuals are fp64 in every mode.
 // Thrust-magnitude bound and linear term q: not in this form (admm_setup refuses the combination).
 //
 // Geometry: workgroup = 512 threads = 8 waves, 2 waves per SIMD (<= 256 registers each); a wave owns MF_NT = 2
@@ -35,6 +37,14 @@ namespace admm {
 
 constexpr int MF_THREADS = 512;
 constexpr int MF_NT = 2;                       // 16-QP tiles per wave
+#ifndef ADMM_MF_PF
+#define ADMM_MF_PF 2
+#endif
+#ifndef ADMM_MF_PF_B
+#define ADMM_MF_PF_B 1
+#endif
+constexpr int MF_PF_F = ADMM_MF_PF;            // stages of operand prefetch (register ring) of the forward kernel ...
+constexpr int MF_PF_B = ADMM_MF_PF_B;          // ... and of the backward one (2 spilled ~100 registers there); both divide the LDS chunk
 constexpr int MF_COLS = (MF_THREADS / 64) * MF_NT * 16;   // 256 QPs per workgroup
 
 typedef float mfma_f4 __attribute__((ext_vector_type(4)));
@@ -50,26 +60,39 @@ template <> struct MfmaOps<float> {
 };
 
 // stages whose records sit in one LDS buffer (two buffers: <= ~80 KB of the CU's 160 KB)
-constexpr int mfma_chunk(int rec_bytes) {
+constexpr int mfma_chunk(int rec_bytes, int pf) {
   int ch = 40000 / rec_bytes;
-  return ch < 1 ? 1 : (ch > 4 ? 4 : ch);
+  ch = ch < 1 ? 1 : (ch > 4 ? 4 : ch);
+  ch = (ch / pf) * pf;                         // ring slots stay aligned across chunks
+  return ch < pf ? pf : ch;
 }
 
 // Asynchronous global -> LDS copy of one chunk of records (LDS-DMA, global_load_lds_dwordx4: no staging registers,
-// no ds_write pass).  A wave-instruction moves 64 lanes x 16 B = one contiguous KiB to "wave-uniform LDS base +
-// lane x 16", so the chunk is copied in whole KiB pieces, wave w taking pieces w, w + 8, ...: the LDS buffers are
-// rounded up to a KiB and the device arrays carry a KiB of slack, so the last piece may run past the chunk.
-// Issued at the start of a chunk's arithmetic; the __syncthreads() that ends the chunk retires it (the barrier's
-// fence waits for vmcnt(0)).
+// no ds_write pass).  A wave-instruction moves 64 lanes x 16 B = one contiguous KiB to "M0 (wave-uniform LDS
+// address) + lane x 16", so the chunk is copied in whole KiB pieces, wave w taking pieces w, w + 8, ...: the LDS
+// buffers are rounded up to a KiB and the device arrays carry a KiB of slack, so the last piece may run past the
+// chunk.
+// Issued through inline asm ON PURPOSE: with an LDS-DMA it knows of in flight, hipcc (ROCm 7.2) turns every counted
+// `s_waitcnt vmcnt(N)` into vmcnt(0) (cdna_hip_programming.md §5, "Pipelining across barriers") -- in the stage loop
+// that made each stage wait for the previous stage's v+ STORES before touching its prefetched operands (measured:
+// 371 us per launch instead of ~300 at n = 12).  Hidden from the compiler, the DMA is still counted by the hardware:
+// a counted wait can only over-wait (the DMA is younger than the loads it is waiting for), never under-wait, and the
+// chunk that is being filled is not read before glds_retire() + the barrier that ends the current chunk.
 constexpr int mfma_lds_bytes(int chunk_bytes) { return ((chunk_bytes + 1023) / 1024) * 1024; }
 
 __device__ __forceinline__ void glds_chunk(const unsigned char* src, unsigned char* lds_dst, int bytes, int wave, int lane) {
   const int pieces = (bytes + 1023) >> 10;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds_dst;
   for (int p = wave; p < pieces; p += MF_THREADS / 64) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)p * 1024 + lane * 16),
-                                     (__attribute__((address_space(3))) void*)(lds_dst + p * 1024), 16, 0, 0);
+    const unsigned char* gsrc = src + (size_t)p * 1024 + lane * 16;
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)p * 1024u);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
   }
 }
+// every LDS-DMA of this wave has landed (then a barrier makes the other waves' pieces visible too)
+__device__ __forceinline__ void glds_retire() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // One register (4 rows x 16 QPs) of the z-update, dual ascent and residual partials; returns v+ and the linear
 // term g = -rho (z+ - y+) of the next x-update.  Padding slots carry c0 = w = 0 and the box (-inf, inf): every
@@ -95,6 +118,13 @@ __device__ __forceinline__ void mf_zupdate(double c0, double w, double lo, doubl
   }
 }
 
+// One row of the scan output; the common case of one slab (every batch that fills the chip) takes ONE load instead of
+// scan_row's eight (its unrolled form serialised the prologue here: 48 rows x 8 loads per lane).
+__device__ __forceinline__ double mf_scan_row(const double* base, size_t o, int nsplit, size_t split_stride) {
+  if (nsplit == 1) return base[o];          // wave-uniform branch
+  return scan_row(base, o, nsplit, split_stride);
+}
+
 // per-QP residual partials: a QP's rows live in the four lane groups of its column -> two cross-lane adds
 __device__ __forceinline__ double mf_colsum(double x) {
   x += __shfl_xor(x, 16, 64);
@@ -109,25 +139,30 @@ __device__ __forceinline__ double mf_colsum(double x) {
 //     ELIM_F:  [mu+ ; deps ; db_k] = M [mu ; g^x ; g^u],  eps += deps,  db_k -> dbb          (ELIM only)
 // and on exit mu -> mseg[s], eps -> epsseg[s] (ELIM), residual partials -> part (RESID).
 // ---------------------------------------------------------------------------
-template <int NX, int NU, class T, bool RESID, bool RELAX, bool ELIM>
+template <int NX, int NU, class TS, class TE, bool RESID, bool RELAX, bool ELIM>
 __global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void xfzem_kernel(
     const double* __restrict__ dbuf, const double* __restrict__ tin, const double* __restrict__ xin,
     const unsigned char* __restrict__ recMF, const int* __restrict__ seg_start_, double* __restrict__ v,
     double* __restrict__ dbb, double* __restrict__ mseg, double* __restrict__ epsseg, double* __restrict__ part,
     double alpha, double rho, int pitch, int nsplit, size_t split_stride) {
-  typedef MfmaOps<T> Ops;
-  typedef typename Ops::acc_t acc_t;
+  typedef MfmaOps<TS> OpsS;
+  typedef MfmaOps<TE> OpsE;
+  typedef typename OpsS::acc_t accs_t;
+  typedef typename OpsE::acc_t acce_t;
+  constexpr int MODE = sizeof(TS) == 4 ? 1 : 2;
   static_assert(mfma_dims(NX, NU), "MFMA form: n <= 12, m <= 8");
   constexpr int NB = NX + NU;
   constexpr MfmaLayout ML = mfma_layout(NX, NU);
   constexpr int XT = ML.xt, OT = ML.ot_sub, KS = ML.ks_sub, KE = ML.ks_elim_f;
-  constexpr int RM = mfma_rec_bytes_fwd(NX, NU, (int)sizeof(T));
-  constexpr int O_ELIM = ML.nf_sub * 64;                       // element offset of the ELIM fragments
-  constexpr int O_LOHI = (ML.nf_sub + ML.nf_elim_f) * 64 * (int)sizeof(T);   // byte offset of lo / hi
-  constexpr int CH = mfma_chunk(RM);
+  constexpr int RM = mfma_rec_bytes_fwd(NX, NU, MODE);
+  static_assert(sizeof(TS) == mfma_es_sub_f(MODE) && (!ELIM || sizeof(TE) == mfma_es_elim_f(MODE)), "element types vs record layout");
+  constexpr int O_ELIM = ML.nf_sub * 64 * mfma_es_sub_f(MODE);     // byte offset of the ELIM fragments
+  constexpr int O_LOHI = O_ELIM + ML.nf_elim_f * 64 * mfma_es_elim_f(MODE);   // byte offset of lo / hi
+  constexpr int MF_PF = MF_PF_F;
+  constexpr int CH = mfma_chunk(RM, MF_PF);
   __shared__ __attribute__((aligned(16))) unsigned char lds[2][mfma_lds_bytes(CH * RM)];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, c = lane & 15;
   const int s = blockIdx.y;
   cint_p seg_start = as_const(seg_start_);
@@ -154,17 +189,18 @@ __global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     lbs[nt] = col_raw < pitch ? lbl[nt] : ROWVIEW_OOB;
   }
 
-  T X[MF_NT][3], Tin[MF_NT][3], Mu[MF_NT][3], Eps[MF_NT][3];
+  TS X[MF_NT][3], Tin[MF_NT][3];
+  TE Mu[MF_NT][3], Eps[MF_NT][3];
 #pragma unroll
   for (int nt = 0; nt < MF_NT; ++nt)
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
       const size_t o = ((size_t)s * NX + (okx[r] ? 4 * r + g : 0)) * P + col[nt];
-      const double tv = scan_row(tin, o, nsplit, split_stride), xv = scan_row(xin, o, nsplit, split_stride);
-      Tin[nt][r] = okx[r] ? (T)tv : (T)0;
-      X[nt][r] = okx[r] ? (T)xv : (T)0;
-      Mu[nt][r] = (T)0;
-      Eps[nt][r] = (T)0;
+      const double tv = mf_scan_row(tin, o, nsplit, split_stride), xv = mf_scan_row(xin, o, nsplit, split_stride);
+      Tin[nt][r] = okx[r] ? (TS)tv : (TS)0;
+      X[nt][r] = okx[r] ? (TS)xv : (TS)0;
+      Mu[nt][r] = (TE)0;
+      Eps[nt][r] = (TE)0;
     }
   double racc[MF_NT][5];
 #pragma unroll
@@ -172,57 +208,66 @@ __global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
     for (int q = 0; q < 5; ++q) racc[nt][q] = 0.0;
 
-  // operand prefetch, one stage deep: v rows (5 registers) and d rows (2) of the next stage
-  double pv[MF_NT][5], pd[MF_NT][2];
-  auto load_stage = [&](int k, int nt) {
+  // operand prefetch ring, MF_PF stages deep: v rows (5 registers) and d rows (2) per tile and slot
+  double pv[MF_PF][MF_NT][5], pd[MF_PF][MF_NT][2];
+  auto load_stage = [&](int k, int j, int nt) {
     const int kk = k < k1 ? k : k1 - 1;
     const unsigned r0 = (unsigned)(kk - k0) * NB * PB;
 #pragma unroll
-    for (int r = 0; r < 3; ++r) pv[nt][r] = vv.load(lbl[nt], r0 + (unsigned)(NU + 4 * r) * PB);
-    pv[nt][3] = vv.load(lbl[nt], r0);
-    pv[nt][4] = XT ? vv.load(lbl[nt], r0 + 4u * PB) : 0.0;
+    for (int r = 0; r < 3; ++r) pv[j][nt][r] = vv.load(lbl[nt], r0 + (unsigned)(NU + 4 * r) * PB);
+    pv[j][nt][3] = vv.load(lbl[nt], r0);
+    pv[j][nt][4] = XT ? vv.load(lbl[nt], r0 + 4u * PB) : 0.0;
     const unsigned d0 = (unsigned)(kk - k0) * NU * PB;
-    pd[nt][0] = vd.load(lbl[nt], d0);
-    pd[nt][1] = XT ? vd.load(lbl[nt], d0 + 4u * PB) : 0.0;
+    pd[j][nt][0] = vd.load(lbl[nt], d0);
+    pd[j][nt][1] = XT ? vd.load(lbl[nt], d0 + 4u * PB) : 0.0;
   };
 #pragma unroll
-  for (int nt = 0; nt < MF_NT; ++nt) load_stage(k0, nt);
+  for (int j = 0; j < MF_PF; ++j)
+#pragma unroll
+    for (int nt = 0; nt < MF_NT; ++nt) load_stage(k0 + j, j, nt);
 
   glds_chunk(recMF + (size_t)k0 * RM, lds[0], ((k1 - k0 < CH) ? k1 - k0 : CH) * RM, wave, lane);
+  glds_retire();
   __syncthreads();
   int buf = 0;
   for (int kc = k0; kc < k1; kc += CH) {
     const int khi = (kc + CH < k1) ? kc + CH : k1;               // this chunk: stages kc .. khi-1
     const int nnext = (khi < k1) ? ((khi + CH < k1 ? CH : k1 - khi) * RM) : 0;
     if (nnext) glds_chunk(recMF + (size_t)khi * RM, lds[buf ^ 1], nnext, wave, lane);   // next chunk, in flight during this one
-    for (int k = kc; k < khi; ++k) {
+    for (int kb = kc; kb < khi; kb += MF_PF) {
+#pragma unroll
+     for (int j = 0; j < MF_PF; ++j) {
+      const int k = kb + j;
+      if (k >= khi) break;
       const unsigned char* rec = lds[buf] + (k - kc) * RM;
-      const T* af = reinterpret_cast<const T*>(rec);
+      const TS* af = reinterpret_cast<const TS*>(rec);
       const double* lohi = reinterpret_cast<const double*>(rec + O_LOHI);
       double c0[MF_NT][5], dk[MF_NT][2];
 #pragma unroll
       for (int nt = 0; nt < MF_NT; ++nt) {
 #pragma unroll
-        for (int r = 0; r < 3; ++r) c0[nt][r] = okx[r] ? pv[nt][r] : 0.0;
-        c0[nt][3] = oku0 ? pv[nt][3] : 0.0;
-        c0[nt][4] = (XT && oku1) ? pv[nt][4] : 0.0;
-        dk[nt][0] = oku0 ? pd[nt][0] : 0.0;
-        dk[nt][1] = (XT && oku1) ? pd[nt][1] : 0.0;
-        load_stage(k + 1, nt);
+        for (int r = 0; r < 3; ++r) c0[nt][r] = okx[r] ? pv[j][nt][r] : 0.0;
+        c0[nt][3] = oku0 ? pv[j][nt][3] : 0.0;
+        c0[nt][4] = (XT && oku1) ? pv[j][nt][4] : 0.0;
+        dk[nt][0] = oku0 ? pd[j][nt][0] : 0.0;
+        dk[nt][1] = (XT && oku1) ? pd[j][nt][1] : 0.0;
+        load_stage(k + MF_PF, j, nt);
       }
       // ---- SUB_F ----
-      acc_t a0[MF_NT], a1[MF_NT];
+      accs_t a0[MF_NT], a1[MF_NT];
 #pragma unroll
-      for (int nt = 0; nt < MF_NT; ++nt) { a0[nt] = acc_t{0, 0, 0, 0}; a1[nt] = acc_t{0, 0, 0, 0}; }
+      for (int nt = 0; nt < MF_NT; ++nt) { a0[nt] = accs_t{0, 0, 0, 0}; a1[nt] = accs_t{0, 0, 0, 0}; }
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        const T fa0 = af[(ks * OT + 0) * 64 + lane];
-        const T fa1 = XT ? af[(ks * OT + XT) * 64 + lane] : (T)0;
+        const TS fa0 = af[(ks * OT + 0) * 64 + lane];
+        const TS fa1 = XT ? af[(ks * OT + XT) * 64 + lane] : (TS)0;
 #pragma unroll
         for (int nt = 0; nt < MF_NT; ++nt) {
-          const T b = ks < 3 ? X[nt][ks < 3 ? ks : 0] : (ks < 6 ? Tin[nt][ks < 6 ? (ks >= 3 ? ks - 3 : 0) : 0] : (T)dk[nt][ks == 6 ? 0 : 1]);
-          a0[nt] = Ops::mfma(fa0, b, a0[nt]);
-          if (XT) a1[nt] = Ops::mfma(fa1, b, a1[nt]);
+          const TS b = ks < 3 ? X[nt][ks < 3 ? ks : 0] : (ks < 6 ? Tin[nt][ks < 6 ? (ks >= 3 ? ks - 3 : 0) : 0] : (TS)dk[nt][ks == 6 ? 0 : 1]);
+          a0[nt] = OpsS::mfma(fa0, b, a0[nt]);
+#ifndef ADMM_MF_ABLATE_SUB1     // timing-only diagnostic: no MFMAs for the second SUB output tile (wrong results)
+          if (XT) a1[nt] = OpsS::mfma(fa1, b, a1[nt]);
+#endif
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -250,21 +295,25 @@ __global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
       __builtin_amdgcn_sched_barrier(0);
       // ---- ELIM_F ----
       if (ELIM) {
-        const T* ae = af + O_ELIM;
-        acc_t e0[MF_NT], e1[MF_NT];
+        const TE* ae = reinterpret_cast<const TE*>(rec + O_ELIM);
+        acce_t e0[MF_NT], e1[MF_NT];
 #pragma unroll
         for (int nt = 0; nt < MF_NT; ++nt) {
-          e0[nt] = acc_t{0, 0, 0, 0};
-          e1[nt] = acc_t{Eps[nt][0], Eps[nt][1], Eps[nt][2], 0};
+          e0[nt] = acce_t{0, 0, 0, 0};
+          e1[nt] = acce_t{Eps[nt][0], Eps[nt][1], Eps[nt][2], 0};
         }
 #pragma unroll
         for (int ks = 0; ks < KE; ++ks) {
-          const T fa0 = ae[(ks * 2 + 0) * 64 + lane], fa1 = ae[(ks * 2 + 1) * 64 + lane];
+          const TE fa0 = ae[(ks * 2 + 0) * 64 + lane], fa1 = ae[(ks * 2 + 1) * 64 + lane];
 #pragma unroll
           for (int nt = 0; nt < MF_NT; ++nt) {
-            const T b = ks < 3 ? Mu[nt][ks < 3 ? ks : 0] : (T)gg[nt][ks < 6 ? (ks >= 3 ? ks - 3 : 0) : (ks == 6 ? 3 : 4)];
-            e0[nt] = Ops::mfma(fa0, b, e0[nt]);
-            e1[nt] = Ops::mfma(fa1, b, e1[nt]);
+            const TE b = ks < 3 ? Mu[nt][ks < 3 ? ks : 0] : (TE)gg[nt][ks < 6 ? (ks >= 3 ? ks - 3 : 0) : (ks == 6 ? 3 : 4)];
+#ifndef ADMM_MF_ABLATE_ELIM     // timing-only diagnostic: no ELIM MFMAs (wrong results)
+            e0[nt] = OpsE::mfma(fa0, b, e0[nt]);
+            e1[nt] = OpsE::mfma(fa1, b, e1[nt]);
+#else
+            e0[nt][0] += fa0 * b; e1[nt][0] += fa1 * b;
+#endif
           }
         }
         const unsigned m0 = (unsigned)(k - k0) * NU * PB;
@@ -276,7 +325,10 @@ __global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
           if (XT) vm.store((double)e1[nt][3], oku1 ? lbs[nt] : ROWVIEW_OOB, m0 + 4u * PB);
         }
       }
+      __builtin_amdgcn_sched_barrier(0);
+     }
     }
+    if (nnext) glds_retire();
     __syncthreads();
     buf ^= 1;
   }
@@ -309,25 +361,30 @@ __global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 //     ELIM_B:  [t+ ; de ; d0_k] = M [g^x + t ; g^u],  e += de,  d0_k -> dbuf
 // and on exit t -> tseg[s], e -> eseg[s]: what xb_kernel / xbze_kernel leave for the plain scan.
 // ---------------------------------------------------------------------------
-template <int NX, int NU, class T, bool RESID, bool RELAX, bool SUBST>
+template <int NX, int NU, class TS, class TE, bool RESID, bool RELAX, bool SUBST>
 __global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void xbzem_kernel(
     const double* __restrict__ dbb, const double* __restrict__ min_, const double* __restrict__ xend,
     const unsigned char* __restrict__ recMB, const int* __restrict__ seg_start_, double* __restrict__ v,
     double* __restrict__ dbuf, double* __restrict__ tseg, double* __restrict__ eseg, double* __restrict__ part,
     double alpha, double rho, int pitch, int nsplit, size_t split_stride) {
-  typedef MfmaOps<T> Ops;
-  typedef typename Ops::acc_t acc_t;
+  typedef MfmaOps<TS> OpsS;
+  typedef MfmaOps<TE> OpsE;
+  typedef typename OpsS::acc_t accs_t;
+  typedef typename OpsE::acc_t acce_t;
+  constexpr int MODE = sizeof(TE) == 4 ? 1 : 2;
   static_assert(mfma_dims(NX, NU), "MFMA form: n <= 12, m <= 8");
   constexpr int NB = NX + NU;
   constexpr MfmaLayout ML = mfma_layout(NX, NU);
   constexpr int XT = ML.xt, OT = ML.ot_sub, KS = ML.ks_sub, KE = ML.ks_elim_b;
-  constexpr int RM = mfma_rec_bytes_bwd(NX, NU, (int)sizeof(T));
-  constexpr int O_ELIM = ML.nf_sub * 64;
-  constexpr int O_LOHI = (ML.nf_sub + ML.nf_elim_b) * 64 * (int)sizeof(T);
-  constexpr int CH = mfma_chunk(RM);
+  constexpr int RM = mfma_rec_bytes_bwd(NX, NU, MODE);
+  static_assert(sizeof(TE) == mfma_es_elim_b(MODE) && (!SUBST || sizeof(TS) == mfma_es_sub_b(MODE)), "element types vs record layout");
+  constexpr int O_ELIM = ML.nf_sub * 64 * mfma_es_sub_b(MODE);
+  constexpr int O_LOHI = O_ELIM + ML.nf_elim_b * 64 * mfma_es_elim_b(MODE);
+  constexpr int MF_PF = MF_PF_B;
+  constexpr int CH = mfma_chunk(RM, MF_PF);
   __shared__ __attribute__((aligned(16))) unsigned char lds[2][mfma_lds_bytes(CH * RM)];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, c = lane & 15;
   const int s = blockIdx.y;
   cint_p seg_start = as_const(seg_start_);
@@ -353,22 +410,23 @@ __global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     lbs[nt] = col_raw < pitch ? lbl[nt] : ROWVIEW_OOB;
   }
 
-  T X[MF_NT][3], Min[MF_NT][3], Tt[MF_NT][3], Ee[MF_NT][3];
+  TS X[MF_NT][3], Min[MF_NT][3];
+  TE Tt[MF_NT][3], Ee[MF_NT][3];
 #pragma unroll
   for (int nt = 0; nt < MF_NT; ++nt)
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
       if (SUBST) {
         const size_t o = ((size_t)s * NX + (okx[r] ? 4 * r + g : 0)) * P + col[nt];
-        const double mv = scan_row(min_, o, nsplit, split_stride), xv = scan_row(xend, o, nsplit, split_stride);
-        Min[nt][r] = okx[r] ? (T)mv : (T)0;
-        X[nt][r] = okx[r] ? (T)xv : (T)0;
+        const double mv = mf_scan_row(min_, o, nsplit, split_stride), xv = mf_scan_row(xend, o, nsplit, split_stride);
+        Min[nt][r] = okx[r] ? (TS)mv : (TS)0;
+        X[nt][r] = okx[r] ? (TS)xv : (TS)0;
       } else {
-        Min[nt][r] = (T)0;
-        X[nt][r] = (T)0;
+        Min[nt][r] = (TS)0;
+        X[nt][r] = (TS)0;
       }
-      Tt[nt][r] = (T)0;
-      Ee[nt][r] = (T)0;
+      Tt[nt][r] = (TE)0;
+      Ee[nt][r] = (TE)0;
     }
   double racc[MF_NT][5];
 #pragma unroll
@@ -376,29 +434,32 @@ __global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
     for (int q = 0; q < 5; ++q) racc[nt][q] = 0.0;
 
-  double pv[MF_NT][5], pd[MF_NT][2];
-  auto load_stage = [&](int k, int nt) {
+  double pv[MF_PF][MF_NT][5], pd[MF_PF][MF_NT][2];
+  auto load_stage = [&](int k, int j, int nt) {
     const int kk = k > k0 ? k : k0;
     const unsigned r0 = (unsigned)(kk - k0) * NB * PB;
 #pragma unroll
-    for (int r = 0; r < 3; ++r) pv[nt][r] = vv.load(lbl[nt], r0 + (unsigned)(NU + 4 * r) * PB);
-    pv[nt][3] = vv.load(lbl[nt], r0);
-    pv[nt][4] = XT ? vv.load(lbl[nt], r0 + 4u * PB) : 0.0;
+    for (int r = 0; r < 3; ++r) pv[j][nt][r] = vv.load(lbl[nt], r0 + (unsigned)(NU + 4 * r) * PB);
+    pv[j][nt][3] = vv.load(lbl[nt], r0);
+    pv[j][nt][4] = XT ? vv.load(lbl[nt], r0 + 4u * PB) : 0.0;
     if (SUBST) {
       const unsigned d0 = (unsigned)(kk - k0) * NU * PB;
-      pd[nt][0] = vm.load(lbl[nt], d0);
-      pd[nt][1] = XT ? vm.load(lbl[nt], d0 + 4u * PB) : 0.0;
+      pd[j][nt][0] = vm.load(lbl[nt], d0);
+      pd[j][nt][1] = XT ? vm.load(lbl[nt], d0 + 4u * PB) : 0.0;
     } else {
-      pd[nt][0] = pd[nt][1] = 0.0;
+      pd[j][nt][0] = pd[j][nt][1] = 0.0;
     }
   };
 #pragma unroll
-  for (int nt = 0; nt < MF_NT; ++nt) load_stage(k1 - 1, nt);
+  for (int j = 0; j < MF_PF; ++j)
+#pragma unroll
+    for (int nt = 0; nt < MF_NT; ++nt) load_stage(k1 - 1 - j, j, nt);
 
   {  // first chunk: stages k1-CH .. k1-1 (clipped at k0); LDS slot j = k - klo
     const int klo = (k1 - CH > k0) ? k1 - CH : k0;
     glds_chunk(recMB + (size_t)klo * RM, lds[0], (k1 - klo) * RM, wave, lane);
   }
+  glds_retire();
   __syncthreads();
   int buf = 0;
   for (int kc = k1; kc > k0; kc -= CH) {                       // this chunk: stages klo .. kc-1, descending
@@ -406,36 +467,42 @@ __global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     const int nlo = (klo - CH > k0) ? klo - CH : k0;           // next chunk: stages nlo .. klo-1
     const int nnext = (klo > k0) ? (klo - nlo) * RM : 0;
     if (nnext) glds_chunk(recMB + (size_t)nlo * RM, lds[buf ^ 1], nnext, wave, lane);
-    for (int k = kc - 1; k >= klo; --k) {
+    for (int kb = kc - 1; kb >= klo; kb -= MF_PF) {
+#pragma unroll
+     for (int j = 0; j < MF_PF; ++j) {
+      const int k = kb - j;
+      if (k < klo) break;
       const unsigned char* rec = lds[buf] + (k - klo) * RM;
-      const T* af = reinterpret_cast<const T*>(rec);
+      const TS* af = reinterpret_cast<const TS*>(rec);
       const double* lohi = reinterpret_cast<const double*>(rec + O_LOHI);
       double c0[MF_NT][5], dk[MF_NT][2];
 #pragma unroll
       for (int nt = 0; nt < MF_NT; ++nt) {
 #pragma unroll
-        for (int r = 0; r < 3; ++r) c0[nt][r] = okx[r] ? pv[nt][r] : 0.0;
-        c0[nt][3] = oku0 ? pv[nt][3] : 0.0;
-        c0[nt][4] = (XT && oku1) ? pv[nt][4] : 0.0;
-        dk[nt][0] = oku0 ? pd[nt][0] : 0.0;
-        dk[nt][1] = (XT && oku1) ? pd[nt][1] : 0.0;
-        load_stage(k - 1, nt);
+        for (int r = 0; r < 3; ++r) c0[nt][r] = okx[r] ? pv[j][nt][r] : 0.0;
+        c0[nt][3] = oku0 ? pv[j][nt][3] : 0.0;
+        c0[nt][4] = (XT && oku1) ? pv[j][nt][4] : 0.0;
+        dk[nt][0] = oku0 ? pd[j][nt][0] : 0.0;
+        dk[nt][1] = (XT && oku1) ? pd[j][nt][1] : 0.0;
+        load_stage(k - MF_PF, j, nt);
       }
       double gg[MF_NT][5];
       if (SUBST) {
         // ---- SUB_B ----
-        acc_t a0[MF_NT], a1[MF_NT];
+        accs_t a0[MF_NT], a1[MF_NT];
 #pragma unroll
-        for (int nt = 0; nt < MF_NT; ++nt) { a0[nt] = acc_t{0, 0, 0, 0}; a1[nt] = acc_t{0, 0, 0, 0}; }
+        for (int nt = 0; nt < MF_NT; ++nt) { a0[nt] = accs_t{0, 0, 0, 0}; a1[nt] = accs_t{0, 0, 0, 0}; }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-          const T fa0 = af[(ks * OT + 0) * 64 + lane];
-          const T fa1 = XT ? af[(ks * OT + XT) * 64 + lane] : (T)0;
+          const TS fa0 = af[(ks * OT + 0) * 64 + lane];
+          const TS fa1 = XT ? af[(ks * OT + XT) * 64 + lane] : (TS)0;
 #pragma unroll
           for (int nt = 0; nt < MF_NT; ++nt) {
-            const T b = ks < 3 ? X[nt][ks < 3 ? ks : 0] : (ks < 6 ? Min[nt][ks < 6 ? (ks >= 3 ? ks - 3 : 0) : 0] : (T)dk[nt][ks == 6 ? 0 : 1]);
-            a0[nt] = Ops::mfma(fa0, b, a0[nt]);
-            if (XT) a1[nt] = Ops::mfma(fa1, b, a1[nt]);
+            const TS b = ks < 3 ? X[nt][ks < 3 ? ks : 0] : (ks < 6 ? Min[nt][ks < 6 ? (ks >= 3 ? ks - 3 : 0) : 0] : (TS)dk[nt][ks == 6 ? 0 : 1]);
+            a0[nt] = OpsS::mfma(fa0, b, a0[nt]);
+  #ifndef ADMM_MF_ABLATE_SUB1     // timing-only diagnostic: no MFMAs for the second SUB output tile (wrong results)
+          if (XT) a1[nt] = OpsS::mfma(fa1, b, a1[nt]);
+#endif
           }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -473,24 +540,28 @@ __global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
       __builtin_amdgcn_sched_barrier(0);
       // ---- ELIM_B ----
       {
-        const T* ae = af + O_ELIM;
-        acc_t e0[MF_NT], e1[MF_NT];
-        T pp[MF_NT][3];
+        const TE* ae = reinterpret_cast<const TE*>(rec + O_ELIM);
+        acce_t e0[MF_NT], e1[MF_NT];
+        TE pp[MF_NT][3];
 #pragma unroll
         for (int nt = 0; nt < MF_NT; ++nt) {
-          e0[nt] = acc_t{0, 0, 0, 0};
-          e1[nt] = acc_t{Ee[nt][0], Ee[nt][1], Ee[nt][2], 0};
+          e0[nt] = acce_t{0, 0, 0, 0};
+          e1[nt] = acce_t{Ee[nt][0], Ee[nt][1], Ee[nt][2], 0};
 #pragma unroll
-          for (int r = 0; r < 3; ++r) pp[nt][r] = (T)gg[nt][r] + Tt[nt][r];
+          for (int r = 0; r < 3; ++r) pp[nt][r] = (TE)gg[nt][r] + Tt[nt][r];
         }
 #pragma unroll
         for (int ks = 0; ks < KE; ++ks) {
-          const T fa0 = ae[(ks * 2 + 0) * 64 + lane], fa1 = ae[(ks * 2 + 1) * 64 + lane];
+          const TE fa0 = ae[(ks * 2 + 0) * 64 + lane], fa1 = ae[(ks * 2 + 1) * 64 + lane];
 #pragma unroll
           for (int nt = 0; nt < MF_NT; ++nt) {
-            const T b = ks < 3 ? pp[nt][ks < 3 ? ks : 0] : (T)gg[nt][ks == 3 ? 3 : 4];
-            e0[nt] = Ops::mfma(fa0, b, e0[nt]);
-            e1[nt] = Ops::mfma(fa1, b, e1[nt]);
+            const TE b = ks < 3 ? pp[nt][ks < 3 ? ks : 0] : (TE)gg[nt][ks == 3 ? 3 : 4];
+#ifndef ADMM_MF_ABLATE_ELIM     // timing-only diagnostic: no ELIM MFMAs (wrong results)
+            e0[nt] = OpsE::mfma(fa0, b, e0[nt]);
+            e1[nt] = OpsE::mfma(fa1, b, e1[nt]);
+#else
+            e0[nt][0] += fa0 * b; e1[nt][0] += fa1 * b;
+#endif
           }
         }
         const unsigned d0 = (unsigned)(k - k0) * NU * PB;
@@ -502,7 +573,10 @@ __global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
           if (XT) vd.store((double)e1[nt][3], oku1 ? lbs[nt] : ROWVIEW_OOB, d0 + 4u * PB);
         }
       }
+      __builtin_amdgcn_sched_barrier(0);
+     }
     }
+    if (nnext) glds_retire();
     __syncthreads();
     buf ^= 1;
   }

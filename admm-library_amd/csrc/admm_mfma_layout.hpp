@@ -33,7 +33,7 @@
 // n-vector + rows 0..3 of the m-vector (slot (3, g)), tile 1 = second n-vector + rows 4..7 of the m-vector (ELIM), or
 // just rows 4..7 of u in its register 0 (SUB, only when m > 4).
 //
-// Per-stage record (element type T = double or float), in the order the kernel consumes it:
+// Per-stage record, in the order the kernel consumes it (element type per product: mfma_es_* below):
 //     SUB  fragments  [ks][ot][64 lanes]      ELIM fragments [ks][ot][64 lanes]      lo [20], hi [20] as fp64
 // lo / hi are indexed by slot (r * 4 + g, r = 0..4); slots that stand for no row carry (-inf, +inf).
 #pragma once
@@ -63,12 +63,21 @@ constexpr MfmaLayout mfma_layout(int n, int m) {
 }
 constexpr bool mfma_dims(int n, int m) { return n >= 1 && n <= 12 && m >= 1 && m <= 8; }
 
+// Element sizes by mode.  mode 2 (ADMM_PRECISION_FP64_MFMA): every product fp64.  mode 1 (ADMM_PRECISION_MIXED): the
+// two products of the Riccati form -- SUB_F (forward rollout) and ELIM_B (backward elimination), whose operators are
+// O(1) -- in fp32; the two of the forward-elimination form -- ELIM_F and SUB_B, whose early-stage gains reach 2.5e4
+//  -- stay fp64.
+constexpr int mfma_es_sub_f(int mode) { return mode == 1 ? 4 : 8; }
+constexpr int mfma_es_elim_f(int) { return 8; }
+constexpr int mfma_es_sub_b(int) { return 8; }
+constexpr int mfma_es_elim_b(int mode) { return mode == 1 ? 4 : 8; }
+
 // bytes of one stage's record (multiples of 16)
-constexpr int mfma_rec_bytes_fwd(int n, int m, int elem_bytes) {
-  return (mfma_layout(n, m).nf_sub + mfma_layout(n, m).nf_elim_f) * 64 * elem_bytes + 40 * 8;
+constexpr int mfma_rec_bytes_fwd(int n, int m, int mode) {
+  return mfma_layout(n, m).nf_sub * 64 * mfma_es_sub_f(mode) + mfma_layout(n, m).nf_elim_f * 64 * mfma_es_elim_f(mode) + 40 * 8;
 }
-constexpr int mfma_rec_bytes_bwd(int n, int m, int elem_bytes) {
-  return (mfma_layout(n, m).nf_sub + mfma_layout(n, m).nf_elim_b) * 64 * elem_bytes + 40 * 8;
+constexpr int mfma_rec_bytes_bwd(int n, int m, int mode) {
+  return mfma_layout(n, m).nf_sub * 64 * mfma_es_sub_b(mode) + mfma_layout(n, m).nf_elim_b * 64 * mfma_es_elim_b(mode) + 40 * 8;
 }
 
 }  // namespace admm

@@ -352,16 +352,16 @@ def host_factor(problem: Problem, rho: float, segments: int):
     return out
 
 
-def host_factor_mfma(problem: Problem, rho: float, segments: int, elem_bytes: int):
+def host_factor_mfma(problem: Problem, rho: float, segments: int, mode: int):
     """Host-only: the MFMA fragment records exactly as admm_setup uploads them, as
     (N, bytes) uint8 arrays (forward, backward), plus whether the forward-elimination products are present."""
     lib = load_library()
     cp, keep = _abi.marshal_problem(problem)
     fb, bb, ok = C.c_int32(), C.c_int32(), C.c_int32()
-    _check(lib, lib.admm_mfma_record_bytes(problem.n, problem.m, int(elem_bytes), C.byref(fb), C.byref(bb)))
+    _check(lib, lib.admm_mfma_record_bytes(problem.n, problem.m, int(mode), C.byref(fb), C.byref(bb)))
     recMF = np.zeros((problem.N, fb.value), np.uint8)
     recMB = np.zeros((problem.N, bb.value), np.uint8)
-    _check(lib, lib.admm_host_factor_mfma(C.byref(cp), float(rho), int(segments), int(elem_bytes),
+    _check(lib, lib.admm_host_factor_mfma(C.byref(cp), float(rho), int(segments), int(mode),
                                           recMF.ctypes.data_as(C.c_void_p), recMB.ctypes.data_as(C.c_void_p), C.byref(ok)))
     del keep
     return recMF, recMB, bool(ok.value)

@@ -95,11 +95,13 @@ typedef struct admm_options {
    *   FP64       one lane per QP, fp64 vector FMAs (every compiled (n, m), q, thrust-magnitude bound).
    *   FP64_MFMA  the fused stage operators as chains of v_mfma_f64_16x16x4_f64 over 16-QP panels: the same fp64
    *              iteration (iterates equal to FP64's to rounding), faster where operand delivery binds (n = 12).
-   *   MIXED      the x-update's sweeps in fp32 on v_mfma_f32_16x16x4_f32 (plain Riccati path); the state v, the
-   *              z-update, the dual and the residuals stay fp64.  admm_solve refines in fp64: it iterates in fp32
-   *              until the stopping rule holds with eps_abs, eps_rel raised to at least 1e-4, then continues with
-   *              the FP64 kernels until it holds as given (admm_info.mixed_iters = length of the first phase).
-   *              admm_run / admm_iterate always run the fp32 form.
+   *   MIXED      as FP64_MFMA, but the two products of the Riccati form (forward rollout, backward elimination:
+   *              operators O(1)) run in fp32 on v_mfma_f32_16x16x4_f32, at half the matrix-pipe cycles; the two of
+   *              the forward-elimination form (gains up to 2.5e4) stay fp64, as do the state v, the z-update, the
+   *              dual and the residuals.  Iterates then carry ~1e-6 relative error.  admm_solve refines in fp64: it
+   *              iterates in this form until the stopping rule holds with eps_abs, eps_rel raised to at least 1e-4,
+   *              then continues with the FP64 kernels until it holds as given (admm_info.mixed_iters = length of
+   *              the first phase).  admm_run / admm_iterate always run the mixed form.
    * The two MFMA forms exist for the (n, m) pairs of csrc/admm_mfma.hip, without q and without a thrust-magnitude
    * bound: ADMM_ERR_UNSUPPORTED otherwise. */
   int32_t precision_mode;
@@ -272,10 +274,10 @@ int admm_host_factor_alt(const admm_problem* p, double rho, int32_t segments, do
                          double* WB, int32_t* ok);
 
 /* MFMA form (csrc/admm_mfma_layout.hpp): bytes per stage of the forward / backward fragment
- * records for element size elem_bytes (4 = fp32, 8 = fp64), and the records themselves (N * bytes each; either
- * pointer may be NULL).  *alt_ok = 0: the ELIM_F / SUB_B fragments are zero (no forward-elimination form). */
-int admm_mfma_record_bytes(int32_t n, int32_t m, int32_t elem_bytes, int32_t* fwd, int32_t* bwd);
-int admm_host_factor_mfma(const admm_problem* p, double rho, int32_t segments, int32_t elem_bytes, void* recMF,
+ * records of mode ADMM_PRECISION_MIXED or ADMM_PRECISION_FP64_MFMA, and the records themselves (N * bytes each;
+ * either pointer may be NULL).  *alt_ok = 0: the ELIM_F / SUB_B fragments are zero (no forward-elimination form). */
+int admm_mfma_record_bytes(int32_t n, int32_t m, int32_t mode, int32_t* fwd, int32_t* bwd);
+int admm_host_factor_mfma(const admm_problem* p, double rho, int32_t segments, int32_t mode, void* recMF,
                           void* recMB, int32_t* alt_ok);
 
 const char* admm_last_error(void);

@@ -86,18 +86,19 @@ def _mfma(frags, b_regs, ot_n, f32, acc=None):
     return tiles
 
 
-@pytest.mark.parametrize("elem", [8, 4], ids=["fp64", "fp32"])
+@pytest.mark.parametrize("mode", [2, 1], ids=["fp64", "mixed"])
 @pytest.mark.parametrize("n,m", [(12, 6), (6, 3), (10, 4), (9, 8), (3, 1)])
-def test_mfma_records_reproduce_the_stage_operators(built, n, m, elem):
-    f32 = elem == 4
-    tol = 2e-5 if f32 else 1e-12
+def test_mfma_records_reproduce_the_stage_operators(built, n, m, mode):
+    # element size per product (admm_mfma_layout.hpp): mixed = SUB_F and ELIM_B in fp32, ELIM_F and SUB_B in fp64
+    es = {"sub_f": 4 if mode == 1 else 8, "elim_f": 8, "sub_b": 8, "elim_b": 4 if mode == 1 else 8}
+    tol_of = lambda e: 2e-5 if e == 4 else 1e-12
+    dt_of = lambda e: np.float32 if e == 4 else np.float64
     p = pkg.random_ltv(N=6, n=n, m=m, batch=2, seed=100 + n + m, with_q=False)
     rho, S = 0.4, 2
     hf = host_factor(p, rho, S)
-    recMF, recMB, alt_ok = host_factor_mfma(p, rho, S, elem)
+    recMF, recMB, alt_ok = host_factor_mfma(p, rho, S, mode)
     assert alt_ok and hf["alt_ok"]
     L = _layout(n, m)
-    dt = np.float32 if f32 else np.float64
     rng = np.random.default_rng(5)
     for k in (0, 3, 5):
         F = _blocks(hf["recF"][k], _rec_f(n, m)); B_ = _blocks(hf["recB"][k], _rec_b(n, m))
@@ -106,9 +107,11 @@ def test_mfma_records_reproduce_the_stage_operators(built, n, m, elem):
         d, gu = (rng.standard_normal((m, 16)) for _ in range(2))
         nf_sub = L["ks_sub"] * L["ot_sub"]
         # ---------------- forward record ----------------
-        fr = recMF[k][: (nf_sub + 2 * L["ks_ef"]) * 64 * elem].view(dt)
-        sub = fr[: nf_sub * 64].reshape(L["ks_sub"], L["ot_sub"], 64)
-        eli = fr[nf_sub * 64:].reshape(L["ks_ef"], 2, 64)
+        o_el = nf_sub * 64 * es["sub_f"]
+        o_lh = o_el + 2 * L["ks_ef"] * 64 * es["elim_f"]
+        sub = recMF[k][:o_el].view(dt_of(es["sub_f"])).reshape(L["ks_sub"], L["ot_sub"], 64)
+        eli = recMF[k][o_el:o_lh].view(dt_of(es["elim_f"])).reshape(L["ks_ef"], 2, 64)
+        f32, tol = es["sub_f"] == 4, tol_of(es["sub_f"])
         X, T, D = _to_slots(x, None, n, m), _to_slots(t, None, n, m), _to_slots(None, d, n, m)
         regs = [X[0], X[1], X[2], T[0], T[1], T[2], D[3]] + ([D[4]] if L["xt"] else [])
         o = _mfma(sub, regs, L["ot_sub"], f32)
@@ -122,6 +125,7 @@ def test_mfma_records_reproduce_the_stage_operators(built, n, m, elem):
             assert all(np.all(o[0, r, g] == 0) for r in range(3) for g in range(4) if 4 * r + g >= n)
         M, G = _to_slots(mu, None, n, m), _to_slots(gx, gu, n, m)
         regs = [M[0], M[1], M[2], G[0], G[1], G[2], G[3]] + ([G[4]] if L["xt"] else [])
+        f32, tol = es["elim_f"] == 4, tol_of(es["elim_f"])
         eps0 = rng.standard_normal((n, 16))
         acc = np.zeros((2, 16, 16))
         E = _to_slots(eps0, None, n, m)
@@ -138,7 +142,7 @@ def test_mfma_records_reproduce_the_stage_operators(built, n, m, elem):
         for got, ref in ((got_mu, mu_ref), (got_eps, eps_ref), (got_db, db_ref)):
             assert np.abs(got - ref).max() <= tol * max(1, np.abs(ref).max(), np.abs(FE["DK"]).max())
         # lo / hi in slot order
-        lohi = recMF[k][(nf_sub + 2 * L["ks_ef"]) * 64 * elem:].view(np.float64)
+        lohi = recMF[k][o_lh:].view(np.float64)
         lo_b, hi_b = B_["LO"][0], B_["HI"][0]
         for r in range(5):
             for g in range(4):
@@ -148,9 +152,11 @@ def test_mfma_records_reproduce_the_stage_operators(built, n, m, elem):
                 assert lohi[r * 4 + g] == (lo_b[row] if row >= 0 else -np.inf)
                 assert lohi[20 + r * 4 + g] == (hi_b[row] if row >= 0 else np.inf)
         # ---------------- backward record ----------------
-        fr = recMB[k][: (nf_sub + 2 * L["ks_eb"]) * 64 * elem].view(dt)
-        sub = fr[: nf_sub * 64].reshape(L["ks_sub"], L["ot_sub"], 64)
-        eli = fr[nf_sub * 64:].reshape(L["ks_eb"], 2, 64)
+        o_el = nf_sub * 64 * es["sub_b"]
+        o_lh = o_el + 2 * L["ks_eb"] * 64 * es["elim_b"]
+        sub = recMB[k][:o_el].view(dt_of(es["sub_b"])).reshape(L["ks_sub"], L["ot_sub"], 64)
+        eli = recMB[k][o_el:o_lh].view(dt_of(es["elim_b"])).reshape(L["ks_eb"], 2, 64)
+        f32, tol = es["sub_b"] == 4, tol_of(es["sub_b"])
         regs = [X[0], X[1], X[2], T[0], T[1], T[2], D[3]] + ([D[4]] if L["xt"] else [])     # x_{k+1}, m_in, db
         o = _mfma(sub, regs, L["ot_sub"], f32)
         u_ref = -(BE["KB"] @ x + BE["PSB"] @ t + d)
@@ -160,6 +166,7 @@ def test_mfma_records_reproduce_the_stage_operators(built, n, m, elem):
         scale = max(1, np.abs(BE["KB"]).max())
         assert np.abs(got_x - xk_ref).max() <= tol * scale * max(1, np.abs(xk_ref).max())
         assert np.abs(got_u - u_ref).max() <= tol * scale * max(1, np.abs(u_ref).max())
+        f32, tol = es["elim_b"] == 4, tol_of(es["elim_b"])
         Pp, Gu = _to_slots(p_, None, n, m), _to_slots(None, gu, n, m)
         regs = [Pp[0], Pp[1], Pp[2], Gu[3]] + ([Gu[4]] if L["xt"] else [])
         o = _mfma(eli, regs, 2, f32)
@@ -178,10 +185,10 @@ def test_mfma_record_sizes_and_unsupported_dims(built):
     import ctypes as C
     lib = pkg.load_library()
     f, b = C.c_int32(), C.c_int32()
-    assert lib.admm_mfma_record_bytes(12, 6, 8, C.byref(f), C.byref(b)) == 0
+    assert lib.admm_mfma_record_bytes(12, 6, 2, C.byref(f), C.byref(b)) == 0      # fp64: every fragment 512 B
     assert (f.value, b.value) == ((16 + 16) * 512 + 320, (16 + 10) * 512 + 320)
-    assert lib.admm_mfma_record_bytes(6, 3, 4, C.byref(f), C.byref(b)) == 0
-    assert (f.value, b.value) == ((7 + 14) * 256 + 320, (7 + 8) * 256 + 320)
-    assert lib.admm_mfma_record_bytes(13, 3, 8, C.byref(f), C.byref(b)) != 0      # n > 12
-    assert lib.admm_mfma_record_bytes(6, 9, 8, C.byref(f), C.byref(b)) != 0       # m > 8
-    assert lib.admm_mfma_record_bytes(6, 3, 2, C.byref(f), C.byref(b)) != 0
+    assert lib.admm_mfma_record_bytes(6, 3, 1, C.byref(f), C.byref(b)) == 0       # mixed: SUB_F, ELIM_B fragments 256 B
+    assert (f.value, b.value) == (7 * 256 + 14 * 512 + 320, 7 * 512 + 8 * 256 + 320)
+    assert lib.admm_mfma_record_bytes(13, 3, 2, C.byref(f), C.byref(b)) != 0      # n > 12
+    assert lib.admm_mfma_record_bytes(6, 9, 2, C.byref(f), C.byref(b)) != 0       # m > 8
+    assert lib.admm_mfma_record_bytes(6, 3, 0, C.byref(f), C.byref(b)) != 0
