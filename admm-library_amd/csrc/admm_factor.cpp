@@ -524,15 +524,23 @@ void build_mfma(Factor& f, int mode) {
   const RecBELayout lbe = rec_be_layout(n, m);
   // slot -> row maps shared by the products
   auto nvec = [&](int r, int g) { return (r < 3 && 4 * r + g < n) ? 4 * r + g : -1; };    // slots of an n-vector
-  auto sub_out = [&](int ot, int r, int g) -> int {          // rows: [x (n) ; u (m)]
-    if (ot == 0) return r < 3 ? nvec(r, g) : (g < m ? n + g : -1);
-    return (r == 0 && 4 + g < m) ? n + 4 + g : -1;
+  auto sub_out = [&](int, int r, int g) -> int {             // rows: [x (n) ; u (m)]; one tile: x + u rows 0..3
+    return r < 3 ? nvec(r, g) : (g < m ? n + g : -1);
   };
   auto sub_in = [&](int ks, int kk) -> int {                 // cols: [x (n) ; second n-vector ; m-vector]
     if (ks < 3) return nvec(ks, kk);
     if (ks < 6) return nvec(ks - 3, kk) < 0 ? -1 : n + nvec(ks - 3, kk);
     if (ks == 6) return kk < m ? 2 * n + kk : -1;
     return 4 + kk < m ? 2 * n + 4 + kk : -1;
+  };
+  // rows 4.. of u: coefficient of the lane's own slot, [row - 4][ks][g] (admm_mfma_layout.hpp)
+  auto urow_table = [&](const Mat& Ms, int C, double* out) {
+    for (int j = 0; j < L.urows; ++j)
+      for (int ks = 0; ks < L.ks_sub; ++ks)
+        for (int g = 0; g < 4; ++g) {
+          const int col = sub_in(ks, g);
+          out[(j * L.ks_sub + ks) * 4 + g] = col >= 0 ? Ms[(size_t)(n + 4 + j) * C + col] : 0.0;
+        }
   };
   auto elim_out = [&](int ot, int r, int g) -> int {         // rows: [first n-vector ; second n-vector ; m-vector]
     if (r < 3) return nvec(r, g) < 0 ? -1 : ot * n + nvec(r, g);
@@ -573,7 +581,9 @@ void build_mfma(Factor& f, int mode) {
       put_block(Ms, C3, n, 0, K, m, n, -1.0);                // u  = -K x - Psi t - d
       put_block(Ms, C3, n, n, Psi, m, n, -1.0);
       put_block(Ms, C3, n, 2 * n, Im, m, m, -1.0);
-      pack_product(fr, Ms, C3, L.ks_sub, L.ot_sub, mfma_es_sub_f(mode) == 4, sub_out, sub_in);
+      pack_product(fr, Ms, C3, L.ks_sub, 1, mfma_es_sub_f(mode) == 4, sub_out, sub_in);
+      std::vector<double> urow((size_t)L.urows * L.ks_sub * 4 + 1, 0.0);
+      urow_table(Ms, C3, urow.data());
       Mat Me((size_t)(2 * n + m) * C3, 0.0);                 // rows [mu+ ; deps ; db], cols [mu ; g^x ; g^u]
       if (f.alt_ok) {
         const double* rfe = &f.recFE[(size_t)k * f.RFE];
@@ -591,6 +601,7 @@ void build_mfma(Factor& f, int mode) {
       unsigned char* o = write_frags(&f.recMF[(size_t)k * f.RMF], fr, mfma_es_sub_f(mode));
       o = write_frags(o, fe, mfma_es_elim_f(mode));
       std::memcpy(o, lohi, 40 * 8);
+      std::memcpy(o + 40 * 8, urow.data(), (size_t)L.urows * L.ks_sub * 4 * 8);
     }
     {  // ---------------- backward record: SUB_B, ELIM_B ----------------
       Frags fr, fe;
@@ -606,7 +617,9 @@ void build_mfma(Factor& f, int mode) {
         put_block(Ms, C3, n, n, PSB, m, n, -1.0);
         put_block(Ms, C3, n, 2 * n, Im, m, m, -1.0);
       }
-      pack_product(fr, Ms, C3, L.ks_sub, L.ot_sub, mfma_es_sub_b(mode) == 4, sub_out, sub_in);
+      pack_product(fr, Ms, C3, L.ks_sub, 1, mfma_es_sub_b(mode) == 4, sub_out, sub_in);
+      std::vector<double> urow((size_t)L.urows * L.ks_sub * 4 + 1, 0.0);
+      urow_table(Ms, C3, urow.data());
       const int C2 = n + m;
       Mat Me((size_t)(2 * n + m) * C2, 0.0);                 // rows [t+ ; de ; d0], cols [p ; g^u]
       const Mat SIBT = mul(SI, BT, m, m, n);
@@ -620,6 +633,7 @@ void build_mfma(Factor& f, int mode) {
       unsigned char* o = write_frags(&f.recMB[(size_t)k * f.RMB], fr, mfma_es_sub_b(mode));
       o = write_frags(o, fe, mfma_es_elim_b(mode));
       std::memcpy(o, lohi, 40 * 8);
+      std::memcpy(o + 40 * 8, urow.data(), (size_t)L.urows * L.ks_sub * 4 * 8);
     }
   }
 }

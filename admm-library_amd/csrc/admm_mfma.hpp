@@ -125,6 +125,21 @@ __device__ __forceinline__ double mf_scan_row(const double* base, size_t o, int 
   return scan_row(base, o, nsplit, split_stride);
 }
 
+// Rows 4.. of u (admm_mfma_layout.hpp): ur[j] holds this lane's partial sum of row 4 + j; the four lane groups of a
+// column are added, and lane group g keeps row 4 + g (slot (4, g)).
+template <int UR>
+__device__ __forceinline__ double mf_urow_place(const double (&ur)[UR > 0 ? UR : 1], int g) {
+  double out = 0.0;
+#pragma unroll
+  for (int j = 0; j < UR; ++j) {
+    double t = ur[j];
+    t += __shfl_xor(t, 16, 64);
+    t += __shfl_xor(t, 32, 64);
+    out = (g == j) ? t : out;
+  }
+  return out;
+}
+
 // per-QP residual partials: a QP's rows live in the four lane groups of its column -> two cross-lane adds
 __device__ __forceinline__ double mf_colsum(double x) {
   x += __shfl_xor(x, 16, 64);
@@ -153,7 +168,7 @@ __global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
   static_assert(mfma_dims(NX, NU), "MFMA form: n <= 12, m <= 8");
   constexpr int NB = NX + NU;
   constexpr MfmaLayout ML = mfma_layout(NX, NU);
-  constexpr int XT = ML.xt, OT = ML.ot_sub, KS = ML.ks_sub, KE = ML.ks_elim_f;
+  constexpr int XT = ML.xt, UR = ML.urows, KS = ML.ks_sub, KE = ML.ks_elim_f;
   constexpr int RM = mfma_rec_bytes_fwd(NX, NU, MODE);
   static_assert(sizeof(TS) == mfma_es_sub_f(MODE) && (!ELIM || sizeof(TE) == mfma_es_elim_f(MODE)), "element types vs record layout");
   constexpr int O_ELIM = ML.nf_sub * 64 * mfma_es_sub_f(MODE);     // byte offset of the ELIM fragments
@@ -254,22 +269,32 @@ __global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         load_stage(k + MF_PF, j, nt);
       }
       // ---- SUB_F ----
-      accs_t a0[MF_NT], a1[MF_NT];
+      accs_t a0[MF_NT];
+      double ur[MF_NT][UR > 0 ? UR : 1];
+      const double* urow = lohi + 40;                          // [row - 4][ks][g]
 #pragma unroll
-      for (int nt = 0; nt < MF_NT; ++nt) { a0[nt] = accs_t{0, 0, 0, 0}; a1[nt] = accs_t{0, 0, 0, 0}; }
+      for (int nt = 0; nt < MF_NT; ++nt) {
+        a0[nt] = accs_t{0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < (UR > 0 ? UR : 1); ++j) ur[nt][j] = 0.0;
+      }
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        const TS fa0 = af[(ks * OT + 0) * 64 + lane];
-        const TS fa1 = XT ? af[(ks * OT + XT) * 64 + lane] : (TS)0;
+        const TS fa0 = af[ks * 64 + lane];
+        double uc[UR > 0 ? UR : 1];
+#pragma unroll
+        for (int j = 0; j < UR; ++j) uc[j] = urow[(j * KS + ks) * 4 + g];
 #pragma unroll
         for (int nt = 0; nt < MF_NT; ++nt) {
           const TS b = ks < 3 ? X[nt][ks < 3 ? ks : 0] : (ks < 6 ? Tin[nt][ks < 6 ? (ks >= 3 ? ks - 3 : 0) : 0] : (TS)dk[nt][ks == 6 ? 0 : 1]);
           a0[nt] = OpsS::mfma(fa0, b, a0[nt]);
-#ifndef ADMM_MF_ABLATE_SUB1     // timing-only diagnostic: no MFMAs for the second SUB output tile (wrong results)
-          if (XT) a1[nt] = OpsS::mfma(fa1, b, a1[nt]);
-#endif
+#pragma unroll
+          for (int j = 0; j < UR; ++j) ur[nt][j] = fma(uc[j], (double)b, ur[nt][j]);
         }
       }
+      double u1[MF_NT];
+#pragma unroll
+      for (int nt = 0; nt < MF_NT; ++nt) u1[nt] = XT ? mf_urow_place<UR>(ur[nt], g) : 0.0;
       __builtin_amdgcn_sched_barrier(0);
       // ---- z-update, dual ascent, residual partials; v+ stored in place ----
       double gg[MF_NT][5];
@@ -286,7 +311,7 @@ __global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         mf_zupdate<RESID, RELAX>(c0[nt][3], (double)a0[nt][3], lohi[12 + g], lohi[32 + g], alpha, rho, vn, gg[nt][3], racc[nt]);
         vv.store(vn, oku0 ? lbs[nt] : ROWVIEW_OOB, r0);
         if (XT) {
-          mf_zupdate<RESID, RELAX>(c0[nt][4], (double)a1[nt][0], lohi[16 + g], lohi[36 + g], alpha, rho, vn, gg[nt][4], racc[nt]);
+          mf_zupdate<RESID, RELAX>(c0[nt][4], u1[nt], lohi[16 + g], lohi[36 + g], alpha, rho, vn, gg[nt][4], racc[nt]);
           vv.store(vn, oku1 ? lbs[nt] : ROWVIEW_OOB, r0 + 4u * PB);
         } else {
           gg[nt][4] = 0.0;
@@ -375,7 +400,7 @@ __global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
   static_assert(mfma_dims(NX, NU), "MFMA form: n <= 12, m <= 8");
   constexpr int NB = NX + NU;
   constexpr MfmaLayout ML = mfma_layout(NX, NU);
-  constexpr int XT = ML.xt, OT = ML.ot_sub, KS = ML.ks_sub, KE = ML.ks_elim_b;
+  constexpr int XT = ML.xt, UR = ML.urows, KS = ML.ks_sub, KE = ML.ks_elim_b;
   constexpr int RM = mfma_rec_bytes_bwd(NX, NU, MODE);
   static_assert(sizeof(TE) == mfma_es_elim_b(MODE) && (!SUBST || sizeof(TS) == mfma_es_sub_b(MODE)), "element types vs record layout");
   constexpr int O_ELIM = ML.nf_sub * 64 * mfma_es_sub_b(MODE);
@@ -489,22 +514,32 @@ __global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
       double gg[MF_NT][5];
       if (SUBST) {
         // ---- SUB_B ----
-        accs_t a0[MF_NT], a1[MF_NT];
+        accs_t a0[MF_NT];
+        double ur[MF_NT][UR > 0 ? UR : 1];
+        const double* urow = lohi + 40;
 #pragma unroll
-        for (int nt = 0; nt < MF_NT; ++nt) { a0[nt] = accs_t{0, 0, 0, 0}; a1[nt] = accs_t{0, 0, 0, 0}; }
+        for (int nt = 0; nt < MF_NT; ++nt) {
+          a0[nt] = accs_t{0, 0, 0, 0};
+#pragma unroll
+          for (int j = 0; j < (UR > 0 ? UR : 1); ++j) ur[nt][j] = 0.0;
+        }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-          const TS fa0 = af[(ks * OT + 0) * 64 + lane];
-          const TS fa1 = XT ? af[(ks * OT + XT) * 64 + lane] : (TS)0;
+          const TS fa0 = af[ks * 64 + lane];
+          double uc[UR > 0 ? UR : 1];
+#pragma unroll
+          for (int j = 0; j < UR; ++j) uc[j] = urow[(j * KS + ks) * 4 + g];
 #pragma unroll
           for (int nt = 0; nt < MF_NT; ++nt) {
             const TS b = ks < 3 ? X[nt][ks < 3 ? ks : 0] : (ks < 6 ? Min[nt][ks < 6 ? (ks >= 3 ? ks - 3 : 0) : 0] : (TS)dk[nt][ks == 6 ? 0 : 1]);
             a0[nt] = OpsS::mfma(fa0, b, a0[nt]);
-  #ifndef ADMM_MF_ABLATE_SUB1     // timing-only diagnostic: no MFMAs for the second SUB output tile (wrong results)
-          if (XT) a1[nt] = OpsS::mfma(fa1, b, a1[nt]);
-#endif
+#pragma unroll
+            for (int j = 0; j < UR; ++j) ur[nt][j] = fma(uc[j], (double)b, ur[nt][j]);
           }
         }
+        double u1[MF_NT];
+#pragma unroll
+        for (int nt = 0; nt < MF_NT; ++nt) u1[nt] = XT ? mf_urow_place<UR>(ur[nt], g) : 0.0;
         __builtin_amdgcn_sched_barrier(0);
         // ---- z-update: w block k = (u_k, x_{k+1}) ----
         const unsigned r0 = (unsigned)(k - k0) * NB * PB;
@@ -520,7 +555,7 @@ __global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
           mf_zupdate<RESID, RELAX>(c0[nt][3], (double)a0[nt][3], lohi[12 + g], lohi[32 + g], alpha, rho, vn, gg[nt][3], racc[nt]);
           vv.store(vn, oku0 ? lbs[nt] : ROWVIEW_OOB, r0);
           if (XT) {
-            mf_zupdate<RESID, RELAX>(c0[nt][4], (double)a1[nt][0], lohi[16 + g], lohi[36 + g], alpha, rho, vn, gg[nt][4], racc[nt]);
+            mf_zupdate<RESID, RELAX>(c0[nt][4], u1[nt], lohi[16 + g], lohi[36 + g], alpha, rho, vn, gg[nt][4], racc[nt]);
             vv.store(vn, oku1 ? lbs[nt] : ROWVIEW_OOB, r0 + 4u * PB);
           } else {
             gg[nt][4] = 0.0;

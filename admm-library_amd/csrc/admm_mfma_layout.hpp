@@ -30,19 +30,24 @@
 //   backward kernel  SUB_B : [x_k ; u]         = [AI-AIB' KB, -AIB' PSB, -AIB' ; -KB, -PSB, -I] [x_{k+1} ; m_in ; db]   (AIB' = A^-1 B)
 //                    ELIM_B: [t+ ; de ; d0]    = [AT-KT BT, -KT ; OM SI BT, OM SI ; SI BT, SI]  [p ; g^u]
 // k-steps: each input n-vector is 3 registers, the m-vector 1 (+1 when m > 4).  Output tiles: tile 0 = first
-// n-vector + rows 0..3 of the m-vector (slot (3, g)), tile 1 = second n-vector + rows 4..7 of the m-vector (ELIM), or
-// just rows 4..7 of u in its register 0 (SUB, only when m > 4).
+// n-vector + rows 0..3 of the m-vector (slot (3, g)), tile 1 = second n-vector + rows 4..7 of the m-vector (ELIM).
+// SUB has ONE output tile (x + u rows 0..3 = 16 rows exactly at n = 12); the m - 4 remaining rows of u (m > 4) would
+// cost a whole second tile of MFMAs for two rows at m = 6 (a quarter of the forward kernel's matrix work), so they are
+// formed on the vector unit instead: each lane multiplies its own slots by the rows' coefficients (UROW table below,
+// indexed [row - 4][k-step][g]) and the four lane groups of a column are added with two cross-lane steps.
 //
 // Per-stage record, in the order the kernel consumes it (element type per product: mfma_es_* below):
-//     SUB  fragments  [ks][ot][64 lanes]      ELIM fragments [ks][ot][64 lanes]      lo [20], hi [20] as fp64
-// lo / hi are indexed by slot (r * 4 + g, r = 0..4); slots that stand for no row carry (-inf, +inf).
+//     SUB  fragments  [ks][64 lanes]      ELIM fragments [ks][2][64 lanes]      lo [20], hi [20]      UROW [m-4][ks][4]
+// lo / hi / UROW are fp64.  lo / hi are indexed by slot (r * 4 + g, r = 0..4); slots that stand for no row carry
+// (-inf, +inf).
 #pragma once
 
 namespace admm {
 
 struct MfmaLayout {
-  int xt;                    // 1 when m > 4 (extra u register / second SUB output tile)
-  int ks_sub, ot_sub;        // k-steps and output tiles of SUB_F / SUB_B
+  int xt;                    // 1 when m > 4 (extra u register)
+  int urows;                 // m - 4 rows of u formed on the vector unit (0 when m <= 4)
+  int ks_sub;                // k-steps of SUB_F / SUB_B (one output tile)
   int ks_elim_f, ks_elim_b;  // k-steps of ELIM_F / ELIM_B (two output tiles each)
   int nf_sub, nf_elim_f, nf_elim_b;   // fragments (of 64 elements) per stage
   int lohi_doubles;          // 40
@@ -51,11 +56,11 @@ constexpr MfmaLayout mfma_layout(int n, int m) {
   MfmaLayout l{};
   (void)n;
   l.xt = m > 4 ? 1 : 0;
+  l.urows = m > 4 ? m - 4 : 0;
   l.ks_sub = 3 + 3 + 1 + l.xt;
-  l.ot_sub = 1 + l.xt;
   l.ks_elim_f = 3 + 3 + 1 + l.xt;
   l.ks_elim_b = 3 + 1 + l.xt;
-  l.nf_sub = l.ks_sub * l.ot_sub;
+  l.nf_sub = l.ks_sub;
   l.nf_elim_f = l.ks_elim_f * 2;
   l.nf_elim_b = l.ks_elim_b * 2;
   l.lohi_doubles = 40;
@@ -73,11 +78,12 @@ constexpr int mfma_es_sub_b(int) { return 8; }
 constexpr int mfma_es_elim_b(int mode) { return mode == 1 ? 4 : 8; }
 
 // bytes of one stage's record (multiples of 16)
+constexpr int mfma_tail_bytes(int n, int m) { return (40 + mfma_layout(n, m).urows * mfma_layout(n, m).ks_sub * 4) * 8; }
 constexpr int mfma_rec_bytes_fwd(int n, int m, int mode) {
-  return mfma_layout(n, m).nf_sub * 64 * mfma_es_sub_f(mode) + mfma_layout(n, m).nf_elim_f * 64 * mfma_es_elim_f(mode) + 40 * 8;
+  return mfma_layout(n, m).nf_sub * 64 * mfma_es_sub_f(mode) + mfma_layout(n, m).nf_elim_f * 64 * mfma_es_elim_f(mode) + mfma_tail_bytes(n, m);
 }
 constexpr int mfma_rec_bytes_bwd(int n, int m, int mode) {
-  return mfma_layout(n, m).nf_sub * 64 * mfma_es_sub_b(mode) + mfma_layout(n, m).nf_elim_b * 64 * mfma_es_elim_b(mode) + 40 * 8;
+  return mfma_layout(n, m).nf_sub * 64 * mfma_es_sub_b(mode) + mfma_layout(n, m).nf_elim_b * 64 * mfma_es_elim_b(mode) + mfma_tail_bytes(n, m);
 }
 
 }  // namespace admm

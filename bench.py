@@ -60,6 +60,9 @@ def parse():
     ap.add_argument("--workload", choices=["cw_rendezvous", "cw_formation", "cw_rendezvous_soc"], default="cw_rendezvous",
                     help="cw_rendezvous = configs[1..3] (n=6, m=3, the metric's workload); cw_formation = configs[4]'s "
                          "shape (n=12, m=6) in fp64 -- a side measurement, never the reported metric's config")
+    ap.add_argument("--precision", choices=["fp64", "mixed", "fp64_mfma"], default="fp64",
+                    help="options.precision_mode of the timed solver (DESIGN.md §4.9): fp64 = one lane per QP (the metric's mode); "
+                         "fp64_mfma / mixed = the MFMA forms (configs[4]; compiled for n=12 m=6, n=6 m=3, n=10 m=4)")
     ap.add_argument("--segments", type=int, default=0)
     ap.add_argument("--zrows", type=int, default=0)
     ap.add_argument("--repeats", type=int, default=5,
@@ -208,7 +211,9 @@ def main():
     else:
         make = pkg.cw_rendezvous if a.workload == "cw_rendezvous" else pkg.cw_formation
         full = make(N=a.horizon, batch=hi_i - lo_i, seed0=pkg.SEED0 + lo_i)
-    opt = pkg.Options(rho=0.05, check_interval=1, segments=a.segments, zrows=a.zrows, device=dev_index)
+    PM = {"fp64": 0, "mixed": 1, "fp64_mfma": 2}
+    opt = pkg.Options(rho=0.05, check_interval=1, segments=a.segments, zrows=a.zrows, device=dev_index,
+                      precision_mode=PM[a.precision])
     solver = pkg.Solver(full, opt)
     geo = solver.geometry()
 
@@ -257,7 +262,7 @@ def main():
     n_, m_ = full.n, full.m
     b_xfz = 8.0 * m_ / (n_ + m_) + 16.0          # d read + v read + v+ written
     xfz_ms = prof["xfz_ms"]
-    pmc_ok = (a.batch, a.horizon, a.workload) == (4096, 1000, "cw_rendezvous")   # the stored PMC runs are of this workload only
+    pmc_ok = (a.batch, a.horizon, a.workload, a.precision) == (4096, 1000, "cw_rendezvous", "fp64")   # the stored PMC runs are of this workload only
     pmc_note = " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE x2)"
 
     def kernel_roofline(name, desc, bytes_per_elem, ms, pmc_name):
@@ -277,10 +282,12 @@ def main():
                                    "state in v-form", b_xfz, xfz_ms, "xfz_kernel<6, 3, true, false, true")
     if prof_alt is not None:
         b_alt = 16.0 + 16.0 * m_ / (n_ + m_) + (8.0 if full.q is not None else 0.0)   # v, v+, d and db rows (+ q)
-        rf = kernel_roofline(f"xfze_kernel<{n_},{m_},RESID=true,RELAX=false,HASQ=false,SOC=false>",
+        kf = "xfze_kernel" if a.precision == "fp64" else "xfzem_kernel"
+        kb = "xbze_kernel" if a.precision == "fp64" else "xbzem_kernel"
+        rf = kernel_roofline(f"{kf}<{n_},{m_},RESID=true,RELAX=false,HASQ=false,SOC=false>",
                              "forward rollout + z-update + dual ascent + residual partials + forward elimination of v+",
                              b_alt, prof_alt["xfze_ms"], "xfze_kernel<6, 3, true, false, false, false>")
-        rb = kernel_roofline(f"xbze_kernel<{n_},{m_},RESID=true,RELAX=false,HASQ=false,SOC=false>",
+        rb = kernel_roofline(f"{kb}<{n_},{m_},RESID=true,RELAX=false,HASQ=false,SOC=false>",
                              "backward rollout + z-update + dual ascent + residual partials + backward elimination of v+", b_alt, prof_alt["xbze_ms"], "xbze_kernel<6, 3, true, false, false, false>")
         pair_ms = prof_alt["xfze_ms"] + prof_alt["xbze_ms"]
         ach = 2 * b_alt * elems / (pair_ms * 1e-3) / 1e9
@@ -295,6 +302,44 @@ def main():
             roofline["traffic_source"] = rf["traffic_source"] + "; mean of the two kernels"
     else:
         roofline = roofline_xfz
+    # MFMA accounting of the timed kernels (configs[4]): instructions per 16-QP tile and stage from the
+    # layout (csrc/admm_mfma_layout.hpp), padding counted as waste: "useful" = the multiply-adds of the one-lane kernels'
+    # operator list, "issued" = 16 x 16 x 4 per MFMA.
+    roofline_mfma = None
+    if a.precision != "fp64" and prof_alt is not None:
+        mode = PM[a.precision]
+        xt = 1 if m_ > 4 else 0
+        nm = {"fwd": {"sub": 7 + xt, "elim": 2 * (7 + xt)}, "bwd": {"sub": 7 + xt, "elim": 2 * (4 + xt)}}
+        es = {"fwd": {"sub": 4 if mode == 1 else 8, "elim": 8}, "bwd": {"sub": 8, "elim": 4 if mode == 1 else 8}}
+        alg = {"fwd": {"sub": 3 * m_ * n_ + n_ * n_, "elim": 3 * m_ * n_ + m_ * m_ + 2 * n_ * n_},
+               "bwd": {"sub": 3 * m_ * n_ + n_ * n_, "elim": 3 * m_ * n_ + m_ * m_ + n_ * n_}}
+        PEAK = {4: 157.3, 8: 78.6}                    # dense TFLOP/s: v_mfma_f32_16x16x4_f32 / v_mfma_f64_16x16x4_f64 (MI355X_MICROARCH.md)
+        CYC = {4: 32, 8: 64}                          # issue cycles per MFMA and SIMD
+        tiles, stages, qps = geo["pitch"] // 16, full.N, geo["pitch"]
+        per = {}
+        for kname, d, ms in (("xfzem", "fwd", prof_alt["xfze_ms"]), ("xbzem", "bwd", prof_alt["xbze_ms"])):
+            useful = sum(2.0 * alg[d][p] for p in ("sub", "elim")) * qps * stages
+            issued = sum(nm[d][p] for p in ("sub", "elim")) * 2048.0 * tiles * stages
+            t_peak = sum(2.0 * alg[d][p] * qps * stages / (PEAK[es[d][p]] * 1e12) for p in ("sub", "elim"))
+            pipe_cyc = sum(nm[d][p] * CYC[es[d][p]] for p in ("sub", "elim")) * tiles * stages
+            per[kname] = {"avg_launch_ms": ms, "mfma_per_tile_stage": nm[d], "element_bytes": es[d],
+                          "useful_flop": useful, "issued_flop": issued, "useful_over_issued": useful / issued,
+                          "useful_TFLOPs": useful / (ms * 1e-3) / 1e12, "issued_TFLOPs": issued / (ms * 1e-3) / 1e12,
+                          "peak_TFLOPs_for_this_mix": useful / t_peak / 1e12,
+                          "matrix_pipe_busy_at_2p4GHz": pipe_cyc / (1024 * 2.4e9 * ms * 1e-3)}
+        tot_ms = prof_alt["xfze_ms"] + prof_alt["xbze_ms"]
+        useful = per["xfzem"]["useful_flop"] + per["xbzem"]["useful_flop"]
+        t_peak = sum(per[k]["useful_flop"] / (per[k]["peak_TFLOPs_for_this_mix"] * 1e12) for k in per)
+        ach = useful / (tot_ms * 1e-3) / 1e12
+        roofline_mfma = {"kernel": f"xfzem_kernel / xbzem_kernel <{n_},{m_}> ({a.precision}): the alternating pair with the stage "
+                                   "operators as v_mfma_*_16x16x4 chains over 16-QP panels",
+                         "bound": "mfma", "achieved": ach, "peak": useful / t_peak / 1e12, "unit": "TFLOP/s",
+                         "frac": ach / (useful / t_peak / 1e12), "traffic": None,
+                         "note": ("achieved = USEFUL flops (the one-lane kernels' operator list, padding and folded blocks "
+                                  "counted as waste) / measured kernel time; peak = dense MFMA peak of the element types, weighted "
+                                  "by each product's useful flops.  The kernels are HBM-bound (roofline_hbm): the matrix pipe is "
+                                  "busy for the fraction per_kernel.*.matrix_pipe_busy_at_2p4GHz of the launch."),
+                         "per_kernel": per}
     zs_ms = prof_unf["zdual_ms"]
     zs = BYTES_PER_ELEM_ZDUAL * elems / (zs_ms * 1e-3) / 1e9
     standalone = {"kernel": "zdual_kernel<RESID=true> (standalone fused z-update + dual + residual, ADMM_FLAG_UNFUSED path)",
@@ -322,6 +367,20 @@ def main():
     warm(solver, 0.25 * a.warm_seconds, every=10)
     dt10 = float(np.median(timed_blocks(solver, 10)))
 
+    # configs[4]: the three precision modes side by side on this workload (rate with residuals every iteration)
+    precision_modes = None
+    if a.workload == "cw_formation" or a.precision != "fp64":
+        precision_modes = {}
+        for name, pm in PM.items():
+            try:
+                with pkg.Solver(full, pkg.Options(rho=0.05, check_interval=1, segments=a.segments, zrows=a.zrows,
+                                                  device=dev_index, precision_mode=pm)) as sp:
+                    warm(sp, 0.4 * a.warm_seconds)
+                    dtm = float(np.median(timed_blocks(sp, 1)))
+                precision_modes[name] = {"batch_iterations_per_s": a.steps / dtm, "ms_per_step": dtm / a.steps * 1e3}
+            except pkg.AdmmError as e:
+                precision_modes[name] = {"error": str(e)}
+
     # iterations-to-epsilon (second half of BASELINE.json's metric; "vs MATLAB" -> vs the CPU oracle):
     # a full admm_solve of this rank's shard to eps_abs = eps_rel = 1e-6, stop test every 10 iterations,
     # once with fixed rho and once with the batch-level adaptive rule.
@@ -336,11 +395,24 @@ def main():
         base = dict(rho=0.05, eps_abs=1e-6, eps_rel=1e-6, max_iter=4000, check_interval=10)
         with pkg.Solver(full, pkg.Options(segments=a.segments, zrows=a.zrows, device=dev_index, **base, **adapt)) as sv:
             info = sv.solve()
+            if adapt.get("precision_mode", 0) != 0:
+                z_mode = sv.get(False, True, False)[1]
         out = {**base, **adapt, "batch_iterations_run": int(info.iters_run), "converged": int(info.n_converged),
+               "mixed_iters": int(info.mixed_iters), "max_r": float(info.max_r), "max_s": float(info.max_s),
                "batch": int(full.batch), "per_qp_median": float(np.median(info.iters)),
                "per_qp_max": int(info.iters.max()), "solve_ms": float(info.solve_ms),
                "rho_final": float(info.rho), "rho_updates": int(info.rho_updates)}
-        if oracle_c is not None:
+        if adapt.get("precision_mode", 0) != 0:
+            # final point of the reduced-precision / MFMA solve against the fp64 one-lane solve of the same options
+            with pkg.Solver(full, pkg.Options(segments=a.segments, zrows=a.zrows, device=dev_index, **base,
+                                              **{**adapt, "precision_mode": 0})) as sv:
+                i64 = sv.solve()
+                z64 = sv.get(False, True, False)[1]
+            out["vs_fp64_path"] = {"fp64_batch_iterations_run": int(i64.iters_run), "fp64_converged": int(i64.n_converged),
+                                   "max_abs_z_difference": float(np.abs(z_mode - z64).max()),
+                                   "fp64_max_r": float(i64.max_r), "fp64_max_s": float(i64.max_s)}
+            del z64
+        if oracle_c is not None and adapt.get("precision_mode", 0) == 0:
             ns = min(64, full.batch)     # the rule is batch-level, so the sample is solved as its own batch on both sides
             sub = full.slice(0, ns)
             ref = oracle_c.solve(sub, **base, **adapt)
@@ -354,6 +426,10 @@ def main():
     iters_to_eps = to_eps()
     iters_to_eps_adaptive = to_eps(adapt_interval=50, adapt_mu=10.0, adapt_tau=2.0)
     iters_to_eps_relaxed = to_eps(adapt_interval=50, adapt_mu=10.0, adapt_tau=2.0, alpha=1.6)   # + over-relaxation
+    iters_to_eps_modes = None
+    if precision_modes is not None:         # the reduced-precision mode is judged on iterations-to-eps vs the fp64 path
+        iters_to_eps_modes = {name: to_eps(adapt_interval=50, adapt_mu=10.0, adapt_tau=2.0, alpha=1.6, precision_mode=pm)
+                              for name, pm in PM.items() if pm != 0 and "error" not in precision_modes[name]}
     solver = None
 
     if rank == 0:
@@ -366,16 +442,22 @@ def main():
             "timing": (f"median of {a.repeats} blocks of exactly {a.steps} steps, each bracketed by barrier + "
                        f"synchronize and reduced with MAX over ranks; warm-up = {a.warmup} steps + {a.warm_seconds} s"),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
+            "dtype": "f64" if a.precision != "mixed" else "f64 state + f32/f64 x-update (mixed)", "data": "synthetic",
             "config": {"workload": (f"configs[2]: batch of {a.batch} independent N={a.horizon} n=6 m=3 "
                                     f"Clohessy-Wiltshire QPs per GPU, residuals every iteration")
                        if a.workload == "cw_rendezvous" else
-                       (f"SIDE MEASUREMENT ({a.workload}): batch of {a.batch} N={a.horizon} n={n_} m={m_} "
+                       (f"configs[4]: x-update as MFMA batched GEMM ({a.precision}), batch of {a.batch} N={a.horizon} n={n_} m={m_} "
+                        f"Clohessy-Wiltshire formation QPs per GPU, residuals every iteration" if a.workload == "cw_formation" else
+                        f"SIDE MEASUREMENT ({a.workload}, {a.precision}): batch of {a.batch} N={a.horizon} n={n_} m={m_} "
                         f"Clohessy-Wiltshire QPs per GPU, residuals every iteration"),
                        "N": a.horizon, "n": n_, "m": m_, "batch_per_gpu": a.batch, "global_batch": gbatch,
                        "rho": 0.05, "sharding": f"batch/{world}, no collective in the iteration",
                        **geo},
-            "roofline": roofline,
+            "roofline": roofline if roofline_mfma is None else roofline_mfma,
+            "roofline_hbm": None if roofline_mfma is None else roofline,
+            "precision": a.precision,
+            "precision_modes": precision_modes,
+            "iters_to_eps_precision_modes": iters_to_eps_modes,
             "roofline_zdual_standalone": standalone,
             "plain_path": plain_path,
             "kernels_ms": {"alternating_resid": None if prof_alt is None else {k: round(v, 5) for k, v in prof_alt.items()},

@@ -12,7 +12,14 @@ from admm_library_amd.solver import host_factor, host_factor_mfma
 
 def _layout(n, m):
     xt = 1 if m > 4 else 0
-    return dict(xt=xt, ks_sub=7 + xt, ot_sub=1 + xt, ks_ef=7 + xt, ks_eb=4 + xt)
+    return dict(xt=xt, urows=max(0, m - 4), ks_sub=7 + xt, ot_sub=1, ks_ef=7 + xt, ks_eb=4 + xt)
+
+
+def _urows(table, regs, L):
+    """Rows 4.. of u as the kernels form them: every lane multiplies its own slot of each k-step register by the
+    UROW coefficient [row - 4][ks][g]; the four lane groups of a column are then added."""
+    t = table.reshape(L["urows"], L["ks_sub"], 4)
+    return np.array([sum((t[j, ks][:, None] * regs[ks]).sum(0) for ks in range(L["ks_sub"])) for j in range(L["urows"])])
 
 
 def _blocks(rec, offs):
@@ -117,8 +124,9 @@ def test_mfma_records_reproduce_the_stage_operators(built, n, m, mode):
         o = _mfma(sub, regs, L["ot_sub"], f32)
         u_ref = -(F["K"] @ x + F["PSI"] @ t + d)
         x_ref = F["A"] @ x + F["B"] @ u_ref
+        urow = recMF[k][o_lh + 320:].view(np.float64)
         got_x = np.array([o[0, r, g] for r in range(3) for g in range(4)])[:n]
-        got_u = np.array([o[0, 3, g] for g in range(4)] + ([o[1, 0, g] for g in range(4)] if L["xt"] else []))[:m]
+        got_u = np.concatenate([np.array([o[0, 3, g] for g in range(4)])[:min(m, 4)]] + ([_urows(urow, regs, L)] if L["urows"] else []))
         assert np.abs(got_x - x_ref).max() <= tol * max(1, np.abs(x_ref).max())
         assert np.abs(got_u - u_ref).max() <= tol * max(1, np.abs(u_ref).max())
         if n < 12:                                               # padding slots of the n-vector come out as exact zeros
@@ -142,7 +150,7 @@ def test_mfma_records_reproduce_the_stage_operators(built, n, m, mode):
         for got, ref in ((got_mu, mu_ref), (got_eps, eps_ref), (got_db, db_ref)):
             assert np.abs(got - ref).max() <= tol * max(1, np.abs(ref).max(), np.abs(FE["DK"]).max())
         # lo / hi in slot order
-        lohi = recMF[k][o_lh:].view(np.float64)
+        lohi = recMF[k][o_lh:o_lh + 320].view(np.float64)
         lo_b, hi_b = B_["LO"][0], B_["HI"][0]
         for r in range(5):
             for g in range(4):
@@ -161,8 +169,9 @@ def test_mfma_records_reproduce_the_stage_operators(built, n, m, mode):
         o = _mfma(sub, regs, L["ot_sub"], f32)
         u_ref = -(BE["KB"] @ x + BE["PSB"] @ t + d)
         xk_ref = BE["AI"] @ x + BE["AIB"] @ u_ref
+        urow = recMB[k][o_lh + 320:].view(np.float64)
         got_x = np.array([o[0, r, g] for r in range(3) for g in range(4)])[:n]
-        got_u = np.array([o[0, 3, g] for g in range(4)] + ([o[1, 0, g] for g in range(4)] if L["xt"] else []))[:m]
+        got_u = np.concatenate([np.array([o[0, 3, g] for g in range(4)])[:min(m, 4)]] + ([_urows(urow, regs, L)] if L["urows"] else []))
         scale = max(1, np.abs(BE["KB"]).max())
         assert np.abs(got_x - xk_ref).max() <= tol * scale * max(1, np.abs(xk_ref).max())
         assert np.abs(got_u - u_ref).max() <= tol * scale * max(1, np.abs(u_ref).max())
@@ -186,7 +195,7 @@ def test_mfma_record_sizes_and_unsupported_dims(built):
     lib = pkg.load_library()
     f, b = C.c_int32(), C.c_int32()
     assert lib.admm_mfma_record_bytes(12, 6, 2, C.byref(f), C.byref(b)) == 0      # fp64: every fragment 512 B
-    assert (f.value, b.value) == ((16 + 16) * 512 + 320, (16 + 10) * 512 + 320)
+    assert (f.value, b.value) == ((8 + 16) * 512 + 320 + 2 * 8 * 4 * 8, (8 + 10) * 512 + 320 + 2 * 8 * 4 * 8)
     assert lib.admm_mfma_record_bytes(6, 3, 1, C.byref(f), C.byref(b)) == 0       # mixed: SUB_F, ELIM_B fragments 256 B
     assert (f.value, b.value) == (7 * 256 + 14 * 512 + 320, 7 * 512 + 8 * 256 + 320)
     assert lib.admm_mfma_record_bytes(13, 3, 2, C.byref(f), C.byref(b)) != 0      # n > 12
