@@ -68,8 +68,10 @@ struct admm_handle {
   // MFMA form of the fused kernels: fragment records, mode (0 = not in use, 1 mixed, 2 fp64), and whether
   // launch_x currently routes to it (the fp64 refinement phase of a MIXED solve turns it off)
   unsigned char *recMF = nullptr, *recMB = nullptr;
+  unsigned char *recMF64 = nullptr, *recMB64 = nullptr;    // MIXED only: all-fp64 records of the refinement phase
   int mfma_mode = 0;
   bool mfma_on = false;
+  bool mfma_refine = false;      // MIXED, refinement phase: the fp64 MFMA kernels on recMF64 / recMB64
   bool alt_allowed = false;      // alternation permitted by the options / compiled kernels (before the precision mode)
   // MIXED solve: phase 1 (fp32) checks the stopping rule with raised tolerances on scratch status arrays
   bool mixed_phase1 = false;
@@ -126,6 +128,7 @@ admm::XLaunch xlaunch_of(const admm_handle* h) {
   l.split_stride = (size_t)h->fac.scanM * h->pitch;
   l.recMF = h->recMF; l.recMB = h->recMB;
   l.mfma_mode = h->mfma_on ? h->mfma_mode : 0;
+  if (h->mfma_refine && h->recMF64) { l.recMF = h->recMF64; l.recMB = h->recMB64; l.mfma_mode = 2; }
   return l;
 }
 
@@ -402,11 +405,13 @@ int validate_problem(const admm_problem* p) {
 }
 
 // MIXED precision: fp32 = the mixed MFMA kernels; otherwise (the fp64 refinement phase of
-// admm_solve) the one-lane fp64 kernels.  Both forms share every device array and the alternation schedule; what an
-// alternating iteration left pending is dropped at the switch (the next iteration starts with a backward sweep).
+// admm_solve) the all-fp64 MFMA kernels on their own records.  Both forms share every other device array and the
+// alternation schedule; what an alternating iteration left pending is dropped at the switch (the next iteration
+// starts with a backward sweep).
 void set_mixed_form(admm_handle* h, bool fp32) {
   if (h->opt.precision_mode != ADMM_PRECISION_MIXED) return;
   h->mfma_on = fp32;
+  h->mfma_refine = !fp32;
   h->alt_state = admm_handle::ALT_NONE;
 }
 
@@ -436,6 +441,8 @@ void release(admm_handle* h) {
     if (*b) { (void)hipFree(*b); *b = nullptr; }
   if (h->recMF) { (void)hipFree(h->recMF); h->recMF = nullptr; }
   if (h->recMB) { (void)hipFree(h->recMB); h->recMB = nullptr; }
+  if (h->recMF64) { (void)hipFree(h->recMF64); h->recMF64 = nullptr; }
+  if (h->recMB64) { (void)hipFree(h->recMB64); h->recMB64 = nullptr; }
   int** ibufs[] = {&h->seg_start, &h->status, &h->iters, &h->nconv, &h->scan_range, &h->scan_rangeB, &h->status1, &h->iters1};
   for (auto b : ibufs)
     if (*b) { (void)hipFree(*b); *b = nullptr; }
@@ -482,6 +489,10 @@ int upload_factor(admm_handle* h) {
   if (h->mfma_mode) {
     HIP_TRY(hipMemcpy(h->recMF, h->fac.recMF.data(), h->fac.recMF.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->recMB, h->fac.recMB.data(), h->fac.recMB.size(), hipMemcpyHostToDevice));
+    if (h->recMF64) {
+      HIP_TRY(hipMemcpy(h->recMF64, h->fac.recMF64.data(), h->fac.recMF64.size(), hipMemcpyHostToDevice));
+      HIP_TRY(hipMemcpy(h->recMB64, h->fac.recMB64.data(), h->fac.recMB64.size(), hipMemcpyHostToDevice));
+    }
   }
   if (h->alt_allowed) {
     HIP_TRY(hipMemcpy(h->recFE, h->fac.recFE.data(), sizeof(double) * h->fac.recFE.size(), hipMemcpyHostToDevice));
@@ -819,6 +830,14 @@ int admm_setup(admm_handle** out, const admm_problem* p, const admm_options* o_i
     HIP_TRY_RELEASE(hipMemset(h->recMB, 0, h->fac.recMB.size() + 1024));
     HIP_TRY_RELEASE(hipMemcpy(h->recMF, h->fac.recMF.data(), h->fac.recMF.size(), hipMemcpyHostToDevice));
     HIP_TRY_RELEASE(hipMemcpy(h->recMB, h->fac.recMB.data(), h->fac.recMB.size(), hipMemcpyHostToDevice));
+    if (!h->fac.recMF64.empty()) {
+      HIP_TRY_RELEASE(hipMalloc((void**)&h->recMF64, h->fac.recMF64.size() + 1024));
+      HIP_TRY_RELEASE(hipMalloc((void**)&h->recMB64, h->fac.recMB64.size() + 1024));
+      HIP_TRY_RELEASE(hipMemset(h->recMF64, 0, h->fac.recMF64.size() + 1024));
+      HIP_TRY_RELEASE(hipMemset(h->recMB64, 0, h->fac.recMB64.size() + 1024));
+      HIP_TRY_RELEASE(hipMemcpy(h->recMF64, h->fac.recMF64.data(), h->fac.recMF64.size(), hipMemcpyHostToDevice));
+      HIP_TRY_RELEASE(hipMemcpy(h->recMB64, h->fac.recMB64.data(), h->fac.recMB64.size(), hipMemcpyHostToDevice));
+    }
     TRY_RELEASE(dalloc(&h->status1, (size_t)h->pitch));
     TRY_RELEASE(dalloc(&h->iters1, (size_t)h->pitch));
   }

@@ -510,14 +510,13 @@ unsigned char* write_frags(unsigned char* dst, const Frags& fr, int elem) {
   return dst + fr.v.size() * elem;
 }
 
-void build_mfma(Factor& f, int mode) {
+void build_mfma(Factor& f, int mode, std::vector<unsigned char>& recMF, std::vector<unsigned char>& recMB, int& RMF, int& RMB) {
   const int N = f.N, n = f.n, m = f.m;
   const MfmaLayout L = mfma_layout(n, m);
-  f.mfma_mode = mode;
-  f.RMF = mfma_rec_bytes_fwd(n, m, mode);
-  f.RMB = mfma_rec_bytes_bwd(n, m, mode);
-  f.recMF.assign((size_t)N * f.RMF, 0);
-  f.recMB.assign((size_t)N * f.RMB, 0);
+  RMF = mfma_rec_bytes_fwd(n, m, mode);
+  RMB = mfma_rec_bytes_bwd(n, m, mode);
+  recMF.assign((size_t)N * RMF, 0);
+  recMB.assign((size_t)N * RMB, 0);
   const RecBLayout lb = rec_b_layout(n, m);
   const RecFLayout lf = rec_f_layout(n, m);
   const RecFELayout lfe = rec_fe_layout(n, m);
@@ -598,7 +597,7 @@ void build_mfma(Factor& f, int mode) {
         put_block(Me, C3, 2 * n, 2 * n, DG, m, m, 1.0);
       }
       pack_product(fe, Me, C3, L.ks_elim_f, 2, mfma_es_elim_f(mode) == 4, elim_out, sub_in);
-      unsigned char* o = write_frags(&f.recMF[(size_t)k * f.RMF], fr, mfma_es_sub_f(mode));
+      unsigned char* o = write_frags(&recMF[(size_t)k * RMF], fr, mfma_es_sub_f(mode));
       o = write_frags(o, fe, mfma_es_elim_f(mode));
       std::memcpy(o, lohi, 40 * 8);
       std::memcpy(o + 40 * 8, urow.data(), (size_t)L.urows * L.ks_sub * 4 * 8);
@@ -630,7 +629,7 @@ void build_mfma(Factor& f, int mode) {
       put_block(Me, C2, 2 * n, 0, SIBT, m, n, 1.0);                             // d0 = Si (B' p + g^u)
       put_block(Me, C2, 2 * n, n, SI, m, m, 1.0);
       pack_product(fe, Me, C2, L.ks_elim_b, 2, mfma_es_elim_b(mode) == 4, elim_out, elimb_in);
-      unsigned char* o = write_frags(&f.recMB[(size_t)k * f.RMB], fr, mfma_es_sub_b(mode));
+      unsigned char* o = write_frags(&recMB[(size_t)k * RMB], fr, mfma_es_sub_b(mode));
       o = write_frags(o, fe, mfma_es_elim_b(mode));
       std::memcpy(o, lohi, 40 * 8);
       std::memcpy(o + 40 * 8, urow.data(), (size_t)L.urows * L.ks_sub * 4 * 8);
@@ -800,10 +799,13 @@ int factorise(const admm_problem& p, double rho, int segments, Factor& f, std::s
   }
 
   build_alternating(f, A, B, Q, R, QN, rho);
-  f.mfma_mode = 0;
+  f.mfma_mode = mfma_mode;
   f.recMF.clear();
   f.recMB.clear();
-  if (mfma_mode) build_mfma(f, mfma_mode);
+  f.recMF64.clear();
+  f.recMB64.clear();
+  if (mfma_mode) build_mfma(f, mfma_mode, f.recMF, f.recMB, f.RMF, f.RMB);
+  if (mfma_mode == 1) build_mfma(f, 2, f.recMF64, f.recMB64, f.RMF64, f.RMB64);
   return ADMM_OK;
 }
 

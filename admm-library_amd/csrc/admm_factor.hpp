@@ -81,6 +81,9 @@ struct Factor {
   int RMF = 0, RMB = 0;             // bytes per stage
   std::vector<unsigned char> recMF; // N * RMF
   std::vector<unsigned char> recMB; // N * RMB
+  // mfma_mode 1 only: the all-fp64 records as well, for the fp64 refinement phase of a mixed solve
+  int RMF64 = 0, RMB64 = 0;
+  std::vector<unsigned char> recMF64, recMB64;
 };
 
 #ifndef ADMM_SCAN_MT

@@ -92,14 +92,15 @@ def pmc_traffic(kernel_substr):
     return None, None
 
 
-def cpu_baseline(N, target_s):
-    """Time the CPU oracle (C/OpenMP restatement) on a bounded sample."""
+def cpu_baseline(N, target_s, workload="cw_rendezvous"):
+    """Time the CPU oracle (C/OpenMP restatement) on a bounded sample of the same workload."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import admm_library_amd as pkg
     import oracle_c
     cores = oracle_c.max_threads()
     sample_batch = max(cores * 4, 16)
-    p = pkg.cw_rendezvous(N=N, batch=sample_batch)
+    make = pkg.cw_formation if workload == "cw_formation" else pkg.cw_rendezvous
+    p = make(N=N, batch=sample_batch, **({"thrust_norm": True} if workload == "cw_rendezvous_soc" else {}))
     oracle_c.solve(p, rho=0.05, max_iter=2, check_interval=1, stop=False, nthreads=cores)   # spin up threads
     t0 = time.perf_counter()
     oracle_c.solve(p, rho=0.05, max_iter=10, check_interval=1, stop=False, nthreads=cores)
@@ -113,7 +114,7 @@ def cpu_baseline(N, target_s):
             break
         t_it = dt / iters
     return {"value": sample_batch * iters / dt, "unit": "QP-iterations/s", "cores": cores, "kind": "port",
-            "sample": f"{iters} iterations of {sample_batch} QPs (N={N}, n=6, m=3), C/OpenMP oracle, "
+            "sample": f"{iters} iterations of {sample_batch} QPs ({workload}, N={N}, n={p.n}, m={p.m}), C/OpenMP oracle, "
                       f"residuals every iteration, {dt:.1f} s"}
 
 
@@ -171,7 +172,7 @@ def main():
     # GPU at idle clocks for whatever is timed next (r01: the driver's 3.3 ms timed region ran on a 0.8 %-busy GPU).
     cpu_base = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        cpu_base = cpu_baseline(a.horizon, a.cpu_seconds)
+        cpu_base = cpu_baseline(a.horizon, a.cpu_seconds, a.workload)
 
     # One process per GPU.  ADMM_BENCH_BACKEND=gloo (+ several ranks sharing one GPU) exists only to
     # rehearse the N > 1 code path on a 1-GPU box; the driver's runs use RCCL ("nccl").

@@ -100,8 +100,8 @@ typedef struct admm_options {
    *              the forward-elimination form (gains up to 2.5e4) stay fp64, as do the state v, the z-update, the
    *              dual and the residuals.  Iterates then carry ~1e-6 relative error.  admm_solve refines in fp64: it
    *              iterates in this form until the stopping rule holds with eps_abs, eps_rel raised to at least 1e-4,
-   *              then continues with the FP64 kernels until it holds as given (admm_info.mixed_iters = length of
-   *              the first phase).  admm_run / admm_iterate always run the mixed form.
+   *              then continues with the FP64_MFMA kernels until it holds as given (admm_info.mixed_iters = length
+   *              of the first phase).  admm_run / admm_iterate always run the mixed form.
    * The two MFMA forms exist for the (n, m) pairs of csrc/admm_mfma.hip, without q and without a thrust-magnitude
    * bound: ADMM_ERR_UNSUPPORTED otherwise. */
   int32_t precision_mode;
