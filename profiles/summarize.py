@@ -16,7 +16,7 @@ import os
 import shutil
 import sys
 
-HERE = os.path.dirname(os.path.abspath(__file__))
+HERE = os.environ.get("PROFILES_OUT") or os.path.dirname(os.path.abspath(__file__))   # PROFILES_OUT: summarise on the GPU box into gpurun_out/
 
 
 def pmc(dirname, counter):
