@@ -25,6 +25,7 @@ FLAG_UNFUSED = 2
 FLAG_SCAN_CHAIN = 4
 FLAG_NO_ALTERNATE = 8
 FLAG_GRAPH = 16
+FLAG_NO_MFMA = 32
 
 PRECISION_FP64 = 0
 PRECISION_MIXED = 1

@@ -114,7 +114,7 @@ using admm::Z_THREADS;
 admm::XLaunch xlaunch_of(const admm_handle* h) {
   admm::XLaunch l{};
   l.stream = h->stream;
-  l.n = h->n; l.m = h->m; l.S = h->S; l.pitch = h->pitch;
+  l.n = h->n; l.m = h->m; l.S = h->S; l.pitch = h->pitch; l.batch = h->batch;
   l.has_q = h->has_q;
   l.has_soc = h->has_soc;
   l.rho = h->opt.rho; l.alpha = h->opt.alpha;
@@ -737,19 +737,22 @@ int admm_setup(admm_handle** out, const admm_problem* p, const admm_options* o_i
   }
 
   // precision mode: the MFMA forms exist for a few (n, m), without q / thrust-magnitude bound
-  if (o.precision_mode != ADMM_PRECISION_FP64) {
+  {
     admm::XLaunch lq{};
     lq.n = p->n; lq.m = p->m;
     lq.mfma_mode = o.precision_mode == ADMM_PRECISION_MIXED ? 1 : 2;
-    const bool compiled = admm::mfma_dims(p->n, p->m) &&
-                          admm::launch_mfma(lq, admm::XKernel::XFZE, false, true);
+    const bool compiled = admm::mfma_dims(p->n, p->m) && admm::launch_mfma(lq, admm::XKernel::XFZE, false, true);
     std::string why;
     if (!compiled) why = "(n, m) has no MFMA instantiation; compiled: " + std::string(admm::dims_mfma());
     else if (h->has_q) why = "a linear term q is not supported by the MFMA forms";
     else if (h->has_soc) why = "a thrust-magnitude bound is not supported by the MFMA forms";
     else if (o.flags & (ADMM_FLAG_UNFUSED | ADMM_FLAG_SCAN_CHAIN)) why = "ADMM_FLAG_UNFUSED / ADMM_FLAG_SCAN_CHAIN exclude the MFMA forms";
-    if (!why.empty()) { release(h); return fail(ADMM_ERR_UNSUPPORTED, "precision_mode " + std::to_string(o.precision_mode) + ": " + why); }
-    h->mfma_mode = lq.mfma_mode;
+    if (o.precision_mode != ADMM_PRECISION_FP64) {
+      if (!why.empty()) { release(h); return fail(ADMM_ERR_UNSUPPORTED, "precision_mode " + std::to_string(o.precision_mode) + ": " + why); }
+      h->mfma_mode = lq.mfma_mode;
+    } else if (why.empty() && !(o.flags & (ADMM_FLAG_NO_MFMA | ADMM_FLAG_NO_ALTERNATE)) && (p->n >= 9 || h->pitch <= 128)) {
+      h->mfma_mode = 2;          // FP64: the fp64 MFMA form where it is the faster one (ADMM_FLAG_NO_MFMA)
+    }
   }
   std::string err;
   rc = admm::factorise(*p, o.rho, h->S, h->fac, err, h->mfma_mode);

@@ -10,6 +10,7 @@ namespace admm {
 struct XLaunch {
   hipStream_t stream;
   int n, m, S, pitch;
+  int batch;                    // QPs really present (columns batch .. pitch-1 are padding)
   bool has_q;
   bool has_soc;                 // thrust-magnitude bound on some stage: SOC kernel forms
   double rho, alpha;

@@ -522,14 +522,15 @@ void build_mfma(Factor& f, int mode, std::vector<unsigned char>& recMF, std::vec
   const RecFELayout lfe = rec_fe_layout(n, m);
   const RecBELayout lbe = rec_be_layout(n, m);
   // slot -> row maps shared by the products
-  auto nvec = [&](int r, int g) { return (r < 3 && 4 * r + g < n) ? 4 * r + g : -1; };    // slots of an n-vector
+  const int NR = L.nr;
+  auto nvec = [&](int r, int g) { return (r < NR && 4 * r + g < n) ? 4 * r + g : -1; };    // slots of an n-vector
   auto sub_out = [&](int, int r, int g) -> int {             // rows: [x (n) ; u (m)]; one tile: x + u rows 0..3
     return r < 3 ? nvec(r, g) : (g < m ? n + g : -1);
   };
   auto sub_in = [&](int ks, int kk) -> int {                 // cols: [x (n) ; second n-vector ; m-vector]
-    if (ks < 3) return nvec(ks, kk);
-    if (ks < 6) return nvec(ks - 3, kk) < 0 ? -1 : n + nvec(ks - 3, kk);
-    if (ks == 6) return kk < m ? 2 * n + kk : -1;
+    if (ks < NR) return nvec(ks, kk);
+    if (ks < 2 * NR) return nvec(ks - NR, kk) < 0 ? -1 : n + nvec(ks - NR, kk);
+    if (ks == 2 * NR) return kk < m ? 2 * n + kk : -1;
     return 4 + kk < m ? 2 * n + 4 + kk : -1;
   };
   // rows 4.. of u: coefficient of the lane's own slot, [row - 4][ks][g] (admm_mfma_layout.hpp)
@@ -547,8 +548,8 @@ void build_mfma(Factor& f, int mode, std::vector<unsigned char>& recMF, std::vec
     return j < m ? 2 * n + j : -1;
   };
   auto elimb_in = [&](int ks, int kk) -> int {               // cols: [p (n) ; g^u (m)]
-    if (ks < 3) return nvec(ks, kk);
-    const int j = 4 * (ks - 3) + kk;
+    if (ks < NR) return nvec(ks, kk);
+    const int j = 4 * (ks - NR) + kk;
     return j < m ? n + j : -1;
   };
   const Mat Im = eye(m);

@@ -24,14 +24,18 @@ bool launch_dim(const XLaunch& l, XKernel k, bool resid, bool query_only) {
   const bool ok = (k == XKernel::XFZE || k == XKernel::XBZE) || (mixed && (k == XKernel::XB || k == XKernel::XFZ));
   if (!ok) return false;
   if (query_only) return true;
-  const dim3 grid((l.pitch + MF_COLS - 1) / MF_COLS, l.S), block(MF_THREADS);
+  // one 16-QP tile per wave for small batches (waves beyond the batch idle), two otherwise
+  const bool nt1 = l.pitch <= 128;
+  const dim3 grid((l.pitch + mf_cols(nt1 ? 1 : 2) - 1) / mf_cols(nt1 ? 1 : 2), l.S), block(MF_THREADS);
   const bool relax = l.alpha != 1.0;
-#define FWD(TS, TE, RS, RX, EL)                                                                                      \
-  hipLaunchKernelGGL((xfzem_kernel<NX, NU, TS, TE, RS, RX, EL>), grid, block, 0, l.stream, l.dbuf, l.tin, l.xin, l.recMF, \
-                     l.seg_start, l.v, l.mvec, l.tseg, l.eseg, l.part, l.alpha, l.rho, l.pitch, l.nsplit, l.split_stride)
-#define BWD(TS, TE, RS, RX, SB)                                                                                      \
-  hipLaunchKernelGGL((xbzem_kernel<NX, NU, TS, TE, RS, RX, SB>), grid, block, 0, l.stream, l.mvec, l.tin, l.xin, l.recMB, \
-                     l.seg_start, l.v, l.dbuf, l.tseg, l.eseg, l.part, l.alpha, l.rho, l.pitch, l.nsplit, l.split_stride)
+#define FWD1(NT_, TS, TE, RS, RX, EL)                                                                                   \
+  hipLaunchKernelGGL((xfzem_kernel<NX, NU, NT_, TS, TE, RS, RX, EL>), grid, block, 0, l.stream, l.dbuf, l.tin, l.xin, l.recMF, \
+                     l.seg_start, l.v, l.mvec, l.tseg, l.eseg, l.part, l.alpha, l.rho, l.pitch, l.nsplit, l.split_stride, l.batch)
+#define BWD1(NT_, TS, TE, RS, RX, SB)                                                                                   \
+  hipLaunchKernelGGL((xbzem_kernel<NX, NU, NT_, TS, TE, RS, RX, SB>), grid, block, 0, l.stream, l.mvec, l.tin, l.xin, l.recMB, \
+                     l.seg_start, l.v, l.dbuf, l.tseg, l.eseg, l.part, l.alpha, l.rho, l.pitch, l.nsplit, l.split_stride, l.batch)
+#define FWD(TS, TE, RS, RX, EL) do { if (nt1) FWD1(1, TS, TE, RS, RX, EL); else FWD1(2, TS, TE, RS, RX, EL); } while (0)
+#define BWD(TS, TE, RS, RX, SB) do { if (nt1) BWD1(1, TS, TE, RS, RX, SB); else BWD1(2, TS, TE, RS, RX, SB); } while (0)
 #define BY_FLAGS(CALL, TS, TE, LAST)                                                      \
   do {                                                                                    \
     if (resid) { if (relax) CALL(TS, TE, true, true, LAST); else CALL(TS, TE, true, false, LAST); }   \
@@ -44,6 +48,8 @@ bool launch_dim(const XLaunch& l, XKernel k, bool resid, bool query_only) {
     case XKernel::XB:   BWD(double, float, false, false, false); break;
     default: return false;
   }
+#undef FWD1
+#undef BWD1
 #undef BY_FLAGS
 #undef BWD
 #undef FWD

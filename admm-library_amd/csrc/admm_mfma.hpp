@@ -36,7 +36,10 @@
 namespace admm {
 
 constexpr int MF_THREADS = 512;
-constexpr int MF_NT = 2;                       // 16-QP tiles per wave
+// 16-QP tiles per wave: template parameter NT of the kernels.  2 for batches that fill the chip (a workgroup then covers
+// 256 QPs, the one-lane kernels' grid); 1 for small batches, where waves whose columns lie beyond the batch skip the
+// arithmetic altogether -- a single QP is then ONE wave per segment running 22 dependent MFMAs per stage (0.65 us)
+// instead of ~450 dependent vector instructions (2.2 us): the small-batch form of the iteration (configs[1]).
 #ifndef ADMM_MF_PF
 #define ADMM_MF_PF 2
 #endif
@@ -45,7 +48,7 @@ constexpr int MF_NT = 2;                       // 16-QP tiles per wave
 #endif
 constexpr int MF_PF_F = ADMM_MF_PF;            // stages of operand prefetch (register ring) of the forward kernel ...
 constexpr int MF_PF_B = ADMM_MF_PF_B;          // ... and of the backward one (2 spilled ~100 registers there); both divide the LDS chunk
-constexpr int MF_COLS = (MF_THREADS / 64) * MF_NT * 16;   // 256 QPs per workgroup
+constexpr int mf_cols(int nt) { return (MF_THREADS / 64) * nt * 16; }   // QPs per workgroup
 
 typedef float mfma_f4 __attribute__((ext_vector_type(4)));
 
@@ -154,12 +157,12 @@ __device__ __forceinline__ double mf_colsum(double x) {
 //     ELIM_F:  [mu+ ; deps ; db_k] = M [mu ; g^x ; g^u],  eps += deps,  db_k -> dbb          (ELIM only)
 // and on exit mu -> mseg[s], eps -> epsseg[s] (ELIM), residual partials -> part (RESID).
 // ---------------------------------------------------------------------------
-template <int NX, int NU, class TS, class TE, bool RESID, bool RELAX, bool ELIM>
+template <int NX, int NU, int NT, class TS, class TE, bool RESID, bool RELAX, bool ELIM>
 __global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void xfzem_kernel(
     const double* __restrict__ dbuf, const double* __restrict__ tin, const double* __restrict__ xin,
     const unsigned char* __restrict__ recMF, const int* __restrict__ seg_start_, double* __restrict__ v,
     double* __restrict__ dbb, double* __restrict__ mseg, double* __restrict__ epsseg, double* __restrict__ part,
-    double alpha, double rho, int pitch, int nsplit, size_t split_stride) {
+    double alpha, double rho, int pitch, int nsplit, size_t split_stride, int batch) {
   typedef MfmaOps<TS> OpsS;
   typedef MfmaOps<TE> OpsE;
   typedef typename OpsS::acc_t accs_t;
@@ -168,7 +171,7 @@ __global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
   static_assert(mfma_dims(NX, NU), "MFMA form: n <= 12, m <= 8");
   constexpr int NB = NX + NU;
   constexpr MfmaLayout ML = mfma_layout(NX, NU);
-  constexpr int XT = ML.xt, UR = ML.urows, KS = ML.ks_sub, KE = ML.ks_elim_f;
+  constexpr int XT = ML.xt, UR = ML.urows, KS = ML.ks_sub, KE = ML.ks_elim_f, NR = ML.nr;
   constexpr int RM = mfma_rec_bytes_fwd(NX, NU, MODE);
   static_assert(sizeof(TS) == mfma_es_sub_f(MODE) && (!ELIM || sizeof(TE) == mfma_es_elim_f(MODE)), "element types vs record layout");
   constexpr int O_ELIM = ML.nf_sub * 64 * mfma_es_sub_f(MODE);     // byte offset of the ELIM fragments
@@ -189,27 +192,30 @@ __global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
   const RowView vm(dbb, (size_t)k0 * NU * P, (size_t)(k1 - k0) * NU * P * 8);
 
   // slot validity of this lane group (compile-time in r, run-time in g)
-  bool okx[3];
+  bool okx[NR];
 #pragma unroll
-  for (int r = 0; r < 3; ++r) okx[r] = 4 * r + g < NX;
+  for (int r = 0; r < NR; ++r) okx[r] = 4 * r + g < NX;
   const bool oku0 = g < NU, oku1 = 4 + g < NU;
 
-  int col[MF_NT];
-  unsigned lbl[MF_NT], lbs[MF_NT];             // lane byte offsets for loads (clamped column) / stores (dropped if clamped)
+  int col[NT];
+  unsigned lbl[NT], lbs[NT];             // lane byte offsets for loads (clamped column) / stores (dropped if clamped)
 #pragma unroll
-  for (int nt = 0; nt < MF_NT; ++nt) {
-    const int col_raw = blockIdx.x * MF_COLS + (wave * MF_NT + nt) * 16 + c;
+  for (int nt = 0; nt < NT; ++nt) {
+    const int col_raw = blockIdx.x * mf_cols(NT) + (wave * NT + nt) * 16 + c;
     col[nt] = col_raw < pitch ? col_raw : pitch - 1;
     lbl[nt] = ((unsigned)g * (unsigned)pitch + (unsigned)col[nt]) * 8u;
     lbs[nt] = col_raw < pitch ? lbl[nt] : ROWVIEW_OOB;
   }
+  // a wave all of whose columns lie beyond the batch (pad columns of the last 64, or the unused waves of a small
+  // batch) takes part in the record staging and the barriers only
+  const bool wave_active = blockIdx.x * mf_cols(NT) + wave * NT * 16 < batch;
 
-  TS X[MF_NT][3], Tin[MF_NT][3];
-  TE Mu[MF_NT][3], Eps[MF_NT][3];
+  TS X[NT][NR], Tin[NT][NR];
+  TE Mu[NT][NR], Eps[NT][NR];
 #pragma unroll
-  for (int nt = 0; nt < MF_NT; ++nt)
+  for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
+    for (int r = 0; r < NR; ++r) {
       const size_t o = ((size_t)s * NX + (okx[r] ? 4 * r + g : 0)) * P + col[nt];
       const double tv = mf_scan_row(tin, o, nsplit, split_stride), xv = mf_scan_row(xin, o, nsplit, split_stride);
       Tin[nt][r] = okx[r] ? (TS)tv : (TS)0;
@@ -217,19 +223,19 @@ __global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
       Mu[nt][r] = (TE)0;
       Eps[nt][r] = (TE)0;
     }
-  double racc[MF_NT][5];
+  double racc[NT][5];
 #pragma unroll
-  for (int nt = 0; nt < MF_NT; ++nt)
+  for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
     for (int q = 0; q < 5; ++q) racc[nt][q] = 0.0;
 
   // operand prefetch ring, MF_PF stages deep: v rows (5 registers) and d rows (2) per tile and slot
-  double pv[MF_PF][MF_NT][5], pd[MF_PF][MF_NT][2];
+  double pv[MF_PF][NT][5], pd[MF_PF][NT][2];
   auto load_stage = [&](int k, int j, int nt) {
     const int kk = k < k1 ? k : k1 - 1;
     const unsigned r0 = (unsigned)(kk - k0) * NB * PB;
 #pragma unroll
-    for (int r = 0; r < 3; ++r) pv[j][nt][r] = vv.load(lbl[nt], r0 + (unsigned)(NU + 4 * r) * PB);
+    for (int r = 0; r < NR; ++r) pv[j][nt][r] = vv.load(lbl[nt], r0 + (unsigned)(NU + 4 * r) * PB);
     pv[j][nt][3] = vv.load(lbl[nt], r0);
     pv[j][nt][4] = XT ? vv.load(lbl[nt], r0 + 4u * PB) : 0.0;
     const unsigned d0 = (unsigned)(kk - k0) * NU * PB;
@@ -239,7 +245,7 @@ __global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
   for (int j = 0; j < MF_PF; ++j)
 #pragma unroll
-    for (int nt = 0; nt < MF_NT; ++nt) load_stage(k0 + j, j, nt);
+    for (int nt = 0; nt < NT; ++nt) load_stage(k0 + j, j, nt);
 
   glds_chunk(recMF + (size_t)k0 * RM, lds[0], ((k1 - k0 < CH) ? k1 - k0 : CH) * RM, wave, lane);
   glds_retire();
@@ -254,14 +260,15 @@ __global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
      for (int j = 0; j < MF_PF; ++j) {
       const int k = kb + j;
       if (k >= khi) break;
+      if (!wave_active) continue;
       const unsigned char* rec = lds[buf] + (k - kc) * RM;
       const TS* af = reinterpret_cast<const TS*>(rec);
       const double* lohi = reinterpret_cast<const double*>(rec + O_LOHI);
-      double c0[MF_NT][5], dk[MF_NT][2];
+      double c0[NT][5], dk[NT][2];
 #pragma unroll
-      for (int nt = 0; nt < MF_NT; ++nt) {
+      for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
-        for (int r = 0; r < 3; ++r) c0[nt][r] = okx[r] ? pv[j][nt][r] : 0.0;
+        for (int r = 0; r < NR; ++r) c0[nt][r] = okx[r] ? pv[j][nt][r] : 0.0;
         c0[nt][3] = oku0 ? pv[j][nt][3] : 0.0;
         c0[nt][4] = (XT && oku1) ? pv[j][nt][4] : 0.0;
         dk[nt][0] = oku0 ? pd[j][nt][0] : 0.0;
@@ -269,11 +276,11 @@ __global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         load_stage(k + MF_PF, j, nt);
       }
       // ---- SUB_F ----
-      accs_t a0[MF_NT];
-      double ur[MF_NT][UR > 0 ? UR : 1];
+      accs_t a0[NT];
+      double ur[NT][UR > 0 ? UR : 1];
       const double* urow = lohi + 40;                          // [row - 4][ks][g]
 #pragma unroll
-      for (int nt = 0; nt < MF_NT; ++nt) {
+      for (int nt = 0; nt < NT; ++nt) {
         a0[nt] = accs_t{0, 0, 0, 0};
 #pragma unroll
         for (int j = 0; j < (UR > 0 ? UR : 1); ++j) ur[nt][j] = 0.0;
@@ -285,25 +292,25 @@ __global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
         for (int j = 0; j < UR; ++j) uc[j] = urow[(j * KS + ks) * 4 + g];
 #pragma unroll
-        for (int nt = 0; nt < MF_NT; ++nt) {
-          const TS b = ks < 3 ? X[nt][ks < 3 ? ks : 0] : (ks < 6 ? Tin[nt][ks < 6 ? (ks >= 3 ? ks - 3 : 0) : 0] : (TS)dk[nt][ks == 6 ? 0 : 1]);
+        for (int nt = 0; nt < NT; ++nt) {
+          const TS b = ks < NR ? X[nt][ks < NR ? ks : 0] : (ks < 2 * NR ? Tin[nt][(ks >= NR && ks < 2 * NR) ? ks - NR : 0] : (TS)dk[nt][ks == 2 * NR ? 0 : 1]);
           a0[nt] = OpsS::mfma(fa0, b, a0[nt]);
 #pragma unroll
           for (int j = 0; j < UR; ++j) ur[nt][j] = fma(uc[j], (double)b, ur[nt][j]);
         }
       }
-      double u1[MF_NT];
+      double u1[NT];
 #pragma unroll
-      for (int nt = 0; nt < MF_NT; ++nt) u1[nt] = XT ? mf_urow_place<UR>(ur[nt], g) : 0.0;
+      for (int nt = 0; nt < NT; ++nt) u1[nt] = XT ? mf_urow_place<UR>(ur[nt], g) : 0.0;
       __builtin_amdgcn_sched_barrier(0);
       // ---- z-update, dual ascent, residual partials; v+ stored in place ----
-      double gg[MF_NT][5];
+      double gg[NT][5];
       const unsigned r0 = (unsigned)(k - k0) * NB * PB;
 #pragma unroll
-      for (int nt = 0; nt < MF_NT; ++nt) {
+      for (int nt = 0; nt < NT; ++nt) {
         double vn;
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
+        for (int r = 0; r < NR; ++r) {
           mf_zupdate<RESID, RELAX>(c0[nt][r], (double)a0[nt][r], lohi[r * 4 + g], lohi[20 + r * 4 + g], alpha, rho, vn, gg[nt][r], racc[nt]);
           vv.store(vn, okx[r] ? lbs[nt] : ROWVIEW_OOB, r0 + (unsigned)(NU + 4 * r) * PB);
           X[nt][r] = a0[nt][r];
@@ -321,18 +328,18 @@ __global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
       // ---- ELIM_F ----
       if (ELIM) {
         const TE* ae = reinterpret_cast<const TE*>(rec + O_ELIM);
-        acce_t e0[MF_NT], e1[MF_NT];
+        acce_t e0[NT], e1[NT];
 #pragma unroll
-        for (int nt = 0; nt < MF_NT; ++nt) {
+        for (int nt = 0; nt < NT; ++nt) {
           e0[nt] = acce_t{0, 0, 0, 0};
-          e1[nt] = acce_t{Eps[nt][0], Eps[nt][1], Eps[nt][2], 0};
+          e1[nt] = acce_t{Eps[nt][0], NR > 1 ? Eps[nt][NR > 1 ? 1 : 0] : (TE)0, NR > 2 ? Eps[nt][NR > 2 ? 2 : 0] : (TE)0, 0};
         }
 #pragma unroll
         for (int ks = 0; ks < KE; ++ks) {
           const TE fa0 = ae[(ks * 2 + 0) * 64 + lane], fa1 = ae[(ks * 2 + 1) * 64 + lane];
 #pragma unroll
-          for (int nt = 0; nt < MF_NT; ++nt) {
-            const TE b = ks < 3 ? Mu[nt][ks < 3 ? ks : 0] : (TE)gg[nt][ks < 6 ? (ks >= 3 ? ks - 3 : 0) : (ks == 6 ? 3 : 4)];
+          for (int nt = 0; nt < NT; ++nt) {
+            const TE b = ks < NR ? Mu[nt][ks < NR ? ks : 0] : (TE)gg[nt][ks < 2 * NR ? (ks >= NR ? ks - NR : 0) : (ks == 2 * NR ? 3 : 4)];
 #ifndef ADMM_MF_ABLATE_ELIM     // timing-only diagnostic: no ELIM MFMAs (wrong results)
             e0[nt] = OpsE::mfma(fa0, b, e0[nt]);
             e1[nt] = OpsE::mfma(fa1, b, e1[nt]);
@@ -343,9 +350,9 @@ __global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         }
         const unsigned m0 = (unsigned)(k - k0) * NU * PB;
 #pragma unroll
-        for (int nt = 0; nt < MF_NT; ++nt) {
+        for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
-          for (int r = 0; r < 3; ++r) { Mu[nt][r] = e0[nt][r]; Eps[nt][r] = e1[nt][r]; }
+          for (int r = 0; r < NR; ++r) { Mu[nt][r] = e0[nt][r]; Eps[nt][r] = e1[nt][r]; }
           vm.store((double)e0[nt][3], oku0 ? lbs[nt] : ROWVIEW_OOB, m0);
           if (XT) vm.store((double)e1[nt][3], oku1 ? lbs[nt] : ROWVIEW_OOB, m0 + 4u * PB);
         }
@@ -358,11 +365,11 @@ __global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     buf ^= 1;
   }
 #pragma unroll
-  for (int nt = 0; nt < MF_NT; ++nt) {
-    const bool st = lbs[nt] != ROWVIEW_OOB;
+  for (int nt = 0; nt < NT; ++nt) {
+    const bool st = wave_active && lbs[nt] != ROWVIEW_OOB;
     if (ELIM) {
 #pragma unroll
-      for (int r = 0; r < 3; ++r)
+      for (int r = 0; r < NR; ++r)
         if (st && okx[r]) {
           const size_t o = ((size_t)s * NX + 4 * r + g) * P + col[nt];
           mseg[o] = (double)Mu[nt][r];
@@ -386,12 +393,12 @@ __global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 //     ELIM_B:  [t+ ; de ; d0_k] = M [g^x + t ; g^u],  e += de,  d0_k -> dbuf
 // and on exit t -> tseg[s], e -> eseg[s]: what xb_kernel / xbze_kernel leave for the plain scan.
 // ---------------------------------------------------------------------------
-template <int NX, int NU, class TS, class TE, bool RESID, bool RELAX, bool SUBST>
+template <int NX, int NU, int NT, class TS, class TE, bool RESID, bool RELAX, bool SUBST>
 __global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void xbzem_kernel(
     const double* __restrict__ dbb, const double* __restrict__ min_, const double* __restrict__ xend,
     const unsigned char* __restrict__ recMB, const int* __restrict__ seg_start_, double* __restrict__ v,
     double* __restrict__ dbuf, double* __restrict__ tseg, double* __restrict__ eseg, double* __restrict__ part,
-    double alpha, double rho, int pitch, int nsplit, size_t split_stride) {
+    double alpha, double rho, int pitch, int nsplit, size_t split_stride, int batch) {
   typedef MfmaOps<TS> OpsS;
   typedef MfmaOps<TE> OpsE;
   typedef typename OpsS::acc_t accs_t;
@@ -400,7 +407,7 @@ __global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
   static_assert(mfma_dims(NX, NU), "MFMA form: n <= 12, m <= 8");
   constexpr int NB = NX + NU;
   constexpr MfmaLayout ML = mfma_layout(NX, NU);
-  constexpr int XT = ML.xt, UR = ML.urows, KS = ML.ks_sub, KE = ML.ks_elim_b;
+  constexpr int XT = ML.xt, UR = ML.urows, KS = ML.ks_sub, KE = ML.ks_elim_b, NR = ML.nr;
   constexpr int RM = mfma_rec_bytes_bwd(NX, NU, MODE);
   static_assert(sizeof(TE) == mfma_es_elim_b(MODE) && (!SUBST || sizeof(TS) == mfma_es_sub_b(MODE)), "element types vs record layout");
   constexpr int O_ELIM = ML.nf_sub * 64 * mfma_es_sub_b(MODE);
@@ -420,27 +427,30 @@ __global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
   const RowView vd(dbuf, (size_t)k0 * NU * P, (size_t)(k1 - k0) * NU * P * 8);
   const RowView vm(dbb, (size_t)k0 * NU * P, (size_t)(k1 - k0) * NU * P * 8);
 
-  bool okx[3];
+  bool okx[NR];
 #pragma unroll
-  for (int r = 0; r < 3; ++r) okx[r] = 4 * r + g < NX;
+  for (int r = 0; r < NR; ++r) okx[r] = 4 * r + g < NX;
   const bool oku0 = g < NU, oku1 = 4 + g < NU;
 
-  int col[MF_NT];
-  unsigned lbl[MF_NT], lbs[MF_NT];
+  int col[NT];
+  unsigned lbl[NT], lbs[NT];
 #pragma unroll
-  for (int nt = 0; nt < MF_NT; ++nt) {
-    const int col_raw = blockIdx.x * MF_COLS + (wave * MF_NT + nt) * 16 + c;
+  for (int nt = 0; nt < NT; ++nt) {
+    const int col_raw = blockIdx.x * mf_cols(NT) + (wave * NT + nt) * 16 + c;
     col[nt] = col_raw < pitch ? col_raw : pitch - 1;
     lbl[nt] = ((unsigned)g * (unsigned)pitch + (unsigned)col[nt]) * 8u;
     lbs[nt] = col_raw < pitch ? lbl[nt] : ROWVIEW_OOB;
   }
+  // a wave all of whose columns lie beyond the batch (pad columns of the last 64, or the unused waves of a small
+  // batch) takes part in the record staging and the barriers only
+  const bool wave_active = blockIdx.x * mf_cols(NT) + wave * NT * 16 < batch;
 
-  TS X[MF_NT][3], Min[MF_NT][3];
-  TE Tt[MF_NT][3], Ee[MF_NT][3];
+  TS X[NT][NR], Min[NT][NR];
+  TE Tt[NT][NR], Ee[NT][NR];
 #pragma unroll
-  for (int nt = 0; nt < MF_NT; ++nt)
+  for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
+    for (int r = 0; r < NR; ++r) {
       if (SUBST) {
         const size_t o = ((size_t)s * NX + (okx[r] ? 4 * r + g : 0)) * P + col[nt];
         const double mv = mf_scan_row(min_, o, nsplit, split_stride), xv = mf_scan_row(xend, o, nsplit, split_stride);
@@ -453,18 +463,18 @@ __global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
       Tt[nt][r] = (TE)0;
       Ee[nt][r] = (TE)0;
     }
-  double racc[MF_NT][5];
+  double racc[NT][5];
 #pragma unroll
-  for (int nt = 0; nt < MF_NT; ++nt)
+  for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
     for (int q = 0; q < 5; ++q) racc[nt][q] = 0.0;
 
-  double pv[MF_PF][MF_NT][5], pd[MF_PF][MF_NT][2];
+  double pv[MF_PF][NT][5], pd[MF_PF][NT][2];
   auto load_stage = [&](int k, int j, int nt) {
     const int kk = k > k0 ? k : k0;
     const unsigned r0 = (unsigned)(kk - k0) * NB * PB;
 #pragma unroll
-    for (int r = 0; r < 3; ++r) pv[j][nt][r] = vv.load(lbl[nt], r0 + (unsigned)(NU + 4 * r) * PB);
+    for (int r = 0; r < NR; ++r) pv[j][nt][r] = vv.load(lbl[nt], r0 + (unsigned)(NU + 4 * r) * PB);
     pv[j][nt][3] = vv.load(lbl[nt], r0);
     pv[j][nt][4] = XT ? vv.load(lbl[nt], r0 + 4u * PB) : 0.0;
     if (SUBST) {
@@ -478,7 +488,7 @@ __global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
   for (int j = 0; j < MF_PF; ++j)
 #pragma unroll
-    for (int nt = 0; nt < MF_NT; ++nt) load_stage(k1 - 1 - j, j, nt);
+    for (int nt = 0; nt < NT; ++nt) load_stage(k1 - 1 - j, j, nt);
 
   {  // first chunk: stages k1-CH .. k1-1 (clipped at k0); LDS slot j = k - klo
     const int klo = (k1 - CH > k0) ? k1 - CH : k0;
@@ -497,28 +507,29 @@ __global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
      for (int j = 0; j < MF_PF; ++j) {
       const int k = kb - j;
       if (k < klo) break;
+      if (!wave_active) continue;
       const unsigned char* rec = lds[buf] + (k - klo) * RM;
       const TS* af = reinterpret_cast<const TS*>(rec);
       const double* lohi = reinterpret_cast<const double*>(rec + O_LOHI);
-      double c0[MF_NT][5], dk[MF_NT][2];
+      double c0[NT][5], dk[NT][2];
 #pragma unroll
-      for (int nt = 0; nt < MF_NT; ++nt) {
+      for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
-        for (int r = 0; r < 3; ++r) c0[nt][r] = okx[r] ? pv[j][nt][r] : 0.0;
+        for (int r = 0; r < NR; ++r) c0[nt][r] = okx[r] ? pv[j][nt][r] : 0.0;
         c0[nt][3] = oku0 ? pv[j][nt][3] : 0.0;
         c0[nt][4] = (XT && oku1) ? pv[j][nt][4] : 0.0;
         dk[nt][0] = oku0 ? pd[j][nt][0] : 0.0;
         dk[nt][1] = (XT && oku1) ? pd[j][nt][1] : 0.0;
         load_stage(k - MF_PF, j, nt);
       }
-      double gg[MF_NT][5];
+      double gg[NT][5];
       if (SUBST) {
         // ---- SUB_B ----
-        accs_t a0[MF_NT];
-        double ur[MF_NT][UR > 0 ? UR : 1];
+        accs_t a0[NT];
+        double ur[NT][UR > 0 ? UR : 1];
         const double* urow = lohi + 40;
 #pragma unroll
-        for (int nt = 0; nt < MF_NT; ++nt) {
+        for (int nt = 0; nt < NT; ++nt) {
           a0[nt] = accs_t{0, 0, 0, 0};
 #pragma unroll
           for (int j = 0; j < (UR > 0 ? UR : 1); ++j) ur[nt][j] = 0.0;
@@ -530,24 +541,24 @@ __global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
           for (int j = 0; j < UR; ++j) uc[j] = urow[(j * KS + ks) * 4 + g];
 #pragma unroll
-          for (int nt = 0; nt < MF_NT; ++nt) {
-            const TS b = ks < 3 ? X[nt][ks < 3 ? ks : 0] : (ks < 6 ? Min[nt][ks < 6 ? (ks >= 3 ? ks - 3 : 0) : 0] : (TS)dk[nt][ks == 6 ? 0 : 1]);
+          for (int nt = 0; nt < NT; ++nt) {
+            const TS b = ks < NR ? X[nt][ks < NR ? ks : 0] : (ks < 2 * NR ? Min[nt][(ks >= NR && ks < 2 * NR) ? ks - NR : 0] : (TS)dk[nt][ks == 2 * NR ? 0 : 1]);
             a0[nt] = OpsS::mfma(fa0, b, a0[nt]);
 #pragma unroll
             for (int j = 0; j < UR; ++j) ur[nt][j] = fma(uc[j], (double)b, ur[nt][j]);
           }
         }
-        double u1[MF_NT];
+        double u1[NT];
 #pragma unroll
-        for (int nt = 0; nt < MF_NT; ++nt) u1[nt] = XT ? mf_urow_place<UR>(ur[nt], g) : 0.0;
+        for (int nt = 0; nt < NT; ++nt) u1[nt] = XT ? mf_urow_place<UR>(ur[nt], g) : 0.0;
         __builtin_amdgcn_sched_barrier(0);
         // ---- z-update: w block k = (u_k, x_{k+1}) ----
         const unsigned r0 = (unsigned)(k - k0) * NB * PB;
 #pragma unroll
-        for (int nt = 0; nt < MF_NT; ++nt) {
+        for (int nt = 0; nt < NT; ++nt) {
           double vn;
 #pragma unroll
-          for (int r = 0; r < 3; ++r) {
+          for (int r = 0; r < NR; ++r) {
             mf_zupdate<RESID, RELAX>(c0[nt][r], (double)X[nt][r], lohi[r * 4 + g], lohi[20 + r * 4 + g], alpha, rho, vn, gg[nt][r], racc[nt]);
             vv.store(vn, okx[r] ? lbs[nt] : ROWVIEW_OOB, r0 + (unsigned)(NU + 4 * r) * PB);
             X[nt][r] = a0[nt][r];                                 // x_k
@@ -564,33 +575,33 @@ __global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
       } else {
         // the plain path's backward sweep: linear term of the CURRENT state, z = clip(v), y = v - z
 #pragma unroll
-        for (int nt = 0; nt < MF_NT; ++nt)
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
           for (int q = 0; q < 5; ++q) {
             const int slot = q * 4 + g;
             const double zz = fmin(fmax(c0[nt][q], lohi[slot]), lohi[20 + slot]);
-            gg[nt][q] = (q < 4 || XT) ? -rho * (zz - (c0[nt][q] - zz)) : 0.0;
+            gg[nt][q] = ((q < NR || q == 3) || (q == 4 && XT)) ? -rho * (zz - (c0[nt][q] - zz)) : 0.0;
           }
       }
       __builtin_amdgcn_sched_barrier(0);
       // ---- ELIM_B ----
       {
         const TE* ae = reinterpret_cast<const TE*>(rec + O_ELIM);
-        acce_t e0[MF_NT], e1[MF_NT];
-        TE pp[MF_NT][3];
+        acce_t e0[NT], e1[NT];
+        TE pp[NT][NR];
 #pragma unroll
-        for (int nt = 0; nt < MF_NT; ++nt) {
+        for (int nt = 0; nt < NT; ++nt) {
           e0[nt] = acce_t{0, 0, 0, 0};
-          e1[nt] = acce_t{Ee[nt][0], Ee[nt][1], Ee[nt][2], 0};
+          e1[nt] = acce_t{Ee[nt][0], NR > 1 ? Ee[nt][NR > 1 ? 1 : 0] : (TE)0, NR > 2 ? Ee[nt][NR > 2 ? 2 : 0] : (TE)0, 0};
 #pragma unroll
-          for (int r = 0; r < 3; ++r) pp[nt][r] = (TE)gg[nt][r] + Tt[nt][r];
+          for (int r = 0; r < NR; ++r) pp[nt][r] = (TE)gg[nt][r] + Tt[nt][r];
         }
 #pragma unroll
         for (int ks = 0; ks < KE; ++ks) {
           const TE fa0 = ae[(ks * 2 + 0) * 64 + lane], fa1 = ae[(ks * 2 + 1) * 64 + lane];
 #pragma unroll
-          for (int nt = 0; nt < MF_NT; ++nt) {
-            const TE b = ks < 3 ? pp[nt][ks < 3 ? ks : 0] : (TE)gg[nt][ks == 3 ? 3 : 4];
+          for (int nt = 0; nt < NT; ++nt) {
+            const TE b = ks < NR ? pp[nt][ks < NR ? ks : 0] : (TE)gg[nt][ks == NR ? 3 : 4];
 #ifndef ADMM_MF_ABLATE_ELIM     // timing-only diagnostic: no ELIM MFMAs (wrong results)
             e0[nt] = OpsE::mfma(fa0, b, e0[nt]);
             e1[nt] = OpsE::mfma(fa1, b, e1[nt]);
@@ -601,9 +612,9 @@ __global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         }
         const unsigned d0 = (unsigned)(k - k0) * NU * PB;
 #pragma unroll
-        for (int nt = 0; nt < MF_NT; ++nt) {
+        for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
-          for (int r = 0; r < 3; ++r) { Tt[nt][r] = e0[nt][r]; Ee[nt][r] = e1[nt][r]; }
+          for (int r = 0; r < NR; ++r) { Tt[nt][r] = e0[nt][r]; Ee[nt][r] = e1[nt][r]; }
           vd.store((double)e0[nt][3], oku0 ? lbs[nt] : ROWVIEW_OOB, d0);
           if (XT) vd.store((double)e1[nt][3], oku1 ? lbs[nt] : ROWVIEW_OOB, d0 + 4u * PB);
         }
@@ -616,10 +627,10 @@ __global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     buf ^= 1;
   }
 #pragma unroll
-  for (int nt = 0; nt < MF_NT; ++nt) {
-    const bool st = lbs[nt] != ROWVIEW_OOB;
+  for (int nt = 0; nt < NT; ++nt) {
+    const bool st = wave_active && lbs[nt] != ROWVIEW_OOB;
 #pragma unroll
-    for (int r = 0; r < 3; ++r)
+    for (int r = 0; r < NR; ++r)
       if (st && okx[r]) {
         const size_t o = ((size_t)s * NX + 4 * r + g) * P + col[nt];
         tseg[o] = (double)Tt[nt][r];

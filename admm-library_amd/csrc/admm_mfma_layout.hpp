@@ -16,8 +16,9 @@
 // Vector tile ("slot" addressing).  A 16-row x 16-QP accumulator tile is 4 registers per lane; lane l serves
 // QP column c = l & 15 and lane group g = l >> 4.  Register r of lane group g is called slot (r, g).  A block
 // vector (u (m), x (n)), n <= 12, m <= 8, is held as
-//     main tile:   slots (r, g), r = 0..2  ->  x row 4 r + g        slot (3, g)  ->  u row g
-//     extra reg:   slot  (4, g)            ->  u row 4 + g           (only when m > 4)
+//     main tile:   slots (r, g), r < NR = ceil(n / 4)  ->  x row 4 r + g        slot (3, g)  ->  u row g
+//     extra reg:   slot  (4, g)                        ->  u row 4 + g           (only when m > 4)
+// (registers NR .. 2 of the main tile stand for nothing when n <= 8: they are never loaded, stored or multiplied)
 // As the B operand of v_mfma_*_16x16x4 a register IS one k-step: lane group g supplies k = g, so k-step "register r"
 // multiplies matrix columns {slot (r, 0..3)}.  As a D result the hardware row of slot (r, g) is
 //     fp64 (v_mfma_f64_16x16x4_f64):  row = g + 4 r        fp32 (v_mfma_f32_16x16x4_f32):  row = 4 g + r
@@ -29,7 +30,7 @@
 //                    ELIM_F: [mu+ ; deps ; db] = [FM, PI, GA ; OB DK, 0, OB DG ; DK, 0, DG] [mu ; g^x ; g^u]
 //   backward kernel  SUB_B : [x_k ; u]         = [AI-AIB' KB, -AIB' PSB, -AIB' ; -KB, -PSB, -I] [x_{k+1} ; m_in ; db]   (AIB' = A^-1 B)
 //                    ELIM_B: [t+ ; de ; d0]    = [AT-KT BT, -KT ; OM SI BT, OM SI ; SI BT, SI]  [p ; g^u]
-// k-steps: each input n-vector is 3 registers, the m-vector 1 (+1 when m > 4).  Output tiles: tile 0 = first
+// k-steps: each input n-vector is NR registers, the m-vector 1 (+1 when m > 4).  Output tiles: tile 0 = first
 // n-vector + rows 0..3 of the m-vector (slot (3, g)), tile 1 = second n-vector + rows 4..7 of the m-vector (ELIM).
 // SUB has ONE output tile (x + u rows 0..3 = 16 rows exactly at n = 12); the m - 4 remaining rows of u (m > 4) would
 // cost a whole second tile of MFMAs for two rows at m = 6 (a quarter of the forward kernel's matrix work), so they are
@@ -45,6 +46,7 @@
 namespace admm {
 
 struct MfmaLayout {
+  int nr;                    // registers of an n-vector: ceil(n / 4)
   int xt;                    // 1 when m > 4 (extra u register)
   int urows;                 // m - 4 rows of u formed on the vector unit (0 when m <= 4)
   int ks_sub;                // k-steps of SUB_F / SUB_B (one output tile)
@@ -54,12 +56,12 @@ struct MfmaLayout {
 };
 constexpr MfmaLayout mfma_layout(int n, int m) {
   MfmaLayout l{};
-  (void)n;
+  l.nr = (n + 3) / 4;
   l.xt = m > 4 ? 1 : 0;
   l.urows = m > 4 ? m - 4 : 0;
-  l.ks_sub = 3 + 3 + 1 + l.xt;
-  l.ks_elim_f = 3 + 3 + 1 + l.xt;
-  l.ks_elim_b = 3 + 1 + l.xt;
+  l.ks_sub = 2 * l.nr + 1 + l.xt;
+  l.ks_elim_f = 2 * l.nr + 1 + l.xt;
+  l.ks_elim_b = l.nr + 1 + l.xt;
   l.nf_sub = l.ks_sub;
   l.nf_elim_f = l.ks_elim_f * 2;
   l.nf_elim_b = l.ks_elim_b * 2;

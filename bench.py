@@ -60,9 +60,10 @@ def parse():
     ap.add_argument("--workload", choices=["cw_rendezvous", "cw_formation", "cw_rendezvous_soc"], default="cw_rendezvous",
                     help="cw_rendezvous = configs[1..3] (n=6, m=3, the metric's workload); cw_formation = configs[4]'s "
                          "shape (n=12, m=6) in fp64 -- a side measurement, never the reported metric's config")
-    ap.add_argument("--precision", choices=["fp64", "mixed", "fp64_mfma"], default="fp64",
-                    help="options.precision_mode of the timed solver (DESIGN.md §4.9): fp64 = one lane per QP (the metric's mode); "
-                         "fp64_mfma / mixed = the MFMA forms (configs[4]; compiled for n=12 m=6, n=6 m=3, n=10 m=4)")
+    ap.add_argument("--precision", choices=["fp64", "fp64_one_lane", "mixed", "fp64_mfma"], default="fp64",
+                    help="options.precision_mode of the timed solver (DESIGN.md §4.9): fp64 = the default (the library picks the "
+                         "one-lane or the fp64 MFMA kernels: one-lane at the metric's n=6 batch=4096); fp64_one_lane = "
+                         "ADMM_FLAG_NO_MFMA; fp64_mfma / mixed = the MFMA forms (configs[4]; compiled for n=12 m=6, n=6 m=3, n=10 m=4)")
     ap.add_argument("--segments", type=int, default=0)
     ap.add_argument("--zrows", type=int, default=0)
     ap.add_argument("--repeats", type=int, default=5,
@@ -212,9 +213,10 @@ def main():
     else:
         make = pkg.cw_rendezvous if a.workload == "cw_rendezvous" else pkg.cw_formation
         full = make(N=a.horizon, batch=hi_i - lo_i, seed0=pkg.SEED0 + lo_i)
-    PM = {"fp64": 0, "mixed": 1, "fp64_mfma": 2}
+    PM = {"fp64": 0, "fp64_one_lane": 0, "mixed": 1, "fp64_mfma": 2}
+    PFLAGS = {"fp64": 0, "fp64_one_lane": 32, "mixed": 0, "fp64_mfma": 0}          # 32 = ADMM_FLAG_NO_MFMA
     opt = pkg.Options(rho=0.05, check_interval=1, segments=a.segments, zrows=a.zrows, device=dev_index,
-                      precision_mode=PM[a.precision])
+                      precision_mode=PM[a.precision], flags=PFLAGS[a.precision])
     solver = pkg.Solver(full, opt)
     geo = solver.geometry()
 
@@ -261,6 +263,9 @@ def main():
     L = full.L
     elems = L * geo["pitch"]
     n_, m_ = full.n, full.m
+    # whether the timed handle runs the MFMA form (include/admm_hip.h: ADMM_FLAG_NO_MFMA)
+    uses_mfma = a.precision in ("mixed", "fp64_mfma") or (a.precision == "fp64" and (n_ >= 9 or geo["pitch"] <= 128)
+                                                           and (n_, m_) in ((12, 6), (6, 3), (10, 4)) and full.q is None and full.unorm is None)
     b_xfz = 8.0 * m_ / (n_ + m_) + 16.0          # d read + v read + v+ written
     xfz_ms = prof["xfz_ms"]
     pmc_ok = (a.batch, a.horizon, a.workload, a.precision) == (4096, 1000, "cw_rendezvous", "fp64")   # the stored PMC runs are of this workload only
@@ -283,8 +288,8 @@ def main():
                                    "state in v-form", b_xfz, xfz_ms, "xfz_kernel<6, 3, true, false, true")
     if prof_alt is not None:
         b_alt = 16.0 + 16.0 * m_ / (n_ + m_) + (8.0 if full.q is not None else 0.0)   # v, v+, d and db rows (+ q)
-        kf = "xfze_kernel" if a.precision == "fp64" else "xfzem_kernel"
-        kb = "xbze_kernel" if a.precision == "fp64" else "xbzem_kernel"
+        kf = "xfzem_kernel" if uses_mfma else "xfze_kernel"
+        kb = "xbzem_kernel" if uses_mfma else "xbze_kernel"
         rf = kernel_roofline(f"{kf}<{n_},{m_},RESID=true,RELAX=false,HASQ=false,SOC=false>",
                              "forward rollout + z-update + dual ascent + residual partials + forward elimination of v+",
                              b_alt, prof_alt["xfze_ms"], "xfze_kernel<6, 3, true, false, false, false>")
@@ -307,8 +312,8 @@ def main():
     # layout (csrc/admm_mfma_layout.hpp), padding counted as waste: "useful" = the multiply-adds of the one-lane kernels'
     # operator list, "issued" = 16 x 16 x 4 per MFMA.
     roofline_mfma = None
-    if a.precision != "fp64" and prof_alt is not None:
-        mode = PM[a.precision]
+    if uses_mfma and prof_alt is not None:
+        mode = 1 if a.precision == "mixed" else 2
         xt = 1 if m_ > 4 else 0
         nm = {"fwd": {"sub": 7 + xt, "elim": 2 * (7 + xt)}, "bwd": {"sub": 7 + xt, "elim": 2 * (4 + xt)}}
         es = {"fwd": {"sub": 4 if mode == 1 else 8, "elim": 8}, "bwd": {"sub": 8, "elim": 4 if mode == 1 else 8}}
@@ -375,7 +380,7 @@ def main():
         for name, pm in PM.items():
             try:
                 with pkg.Solver(full, pkg.Options(rho=0.05, check_interval=1, segments=a.segments, zrows=a.zrows,
-                                                  device=dev_index, precision_mode=pm)) as sp:
+                                                  device=dev_index, precision_mode=pm, flags=PFLAGS[name])) as sp:
                     warm(sp, 0.4 * a.warm_seconds)
                     dtm = float(np.median(timed_blocks(sp, 1)))
                 precision_modes[name] = {"batch_iterations_per_s": a.steps / dtm, "ms_per_step": dtm / a.steps * 1e3}
@@ -413,7 +418,7 @@ def main():
                                    "max_abs_z_difference": float(np.abs(z_mode - z64).max()),
                                    "fp64_max_r": float(i64.max_r), "fp64_max_s": float(i64.max_s)}
             del z64
-        if oracle_c is not None and adapt.get("precision_mode", 0) == 0:
+        if oracle_c is not None and adapt.get("precision_mode", 0) == 0 and "flags" not in adapt:
             ns = min(64, full.batch)     # the rule is batch-level, so the sample is solved as its own batch on both sides
             sub = full.slice(0, ns)
             ref = oracle_c.solve(sub, **base, **adapt)
@@ -431,6 +436,7 @@ def main():
     if precision_modes is not None:         # the reduced-precision mode is judged on iterations-to-eps vs the fp64 path
         iters_to_eps_modes = {name: to_eps(adapt_interval=50, adapt_mu=10.0, adapt_tau=2.0, alpha=1.6, precision_mode=pm)
                               for name, pm in PM.items() if pm != 0 and "error" not in precision_modes[name]}
+        iters_to_eps_modes["fp64_one_lane"] = to_eps(adapt_interval=50, adapt_mu=10.0, adapt_tau=2.0, alpha=1.6, flags=32)
     solver = None
 
     if rank == 0:

@@ -92,9 +92,11 @@ typedef struct admm_options {
   double adapt_mu;        /* > 1 */
   double adapt_tau;       /* > 1 */
   /* Arithmetic of the x-update (ABI v4; BASELINE.json configs[4]).  ADMM_PRECISION_*:
-   *   FP64       one lane per QP, fp64 vector FMAs (every compiled (n, m), q, thrust-magnitude bound).
-   *   FP64_MFMA  the fused stage operators as chains of v_mfma_f64_16x16x4_f64 over 16-QP panels: the same fp64
-   *              iteration (iterates equal to FP64's to rounding), faster where operand delivery binds (n = 12).
+   *   FP64       fp64 throughout; the library picks the kernel form: one lane per QP with fp64 vector FMAs (every
+   *              compiled (n, m), q, thrust-magnitude bound), or FP64_MFMA's kernels where those are faster
+   *              (ADMM_FLAG_NO_MFMA).
+   *   FP64_MFMA  the fused stage operators as chains of v_mfma_f64_16x16x4_f64 over 16-QP panels, always: the same
+   *              fp64 iteration (iterates equal to the one-lane kernels' to rounding).
    *   MIXED      as FP64_MFMA, but the two products of the Riccati form (forward rollout, backward elimination:
    *              operators O(1)) run in fp32 on v_mfma_f32_16x16x4_f32, at half the matrix-pipe cycles; the two of
    *              the forward-elimination form (gains up to 2.5e4) stay fp64, as do the state v, the z-update, the
@@ -122,6 +124,13 @@ typedef struct admm_options {
                                   the fp64-MFMA GEMM form (xscan_mfma_kernel) */
 #define ADMM_FLAG_UNFUSED 2    /* iterate with separate forward-rollout and z/dual kernels (w stored
                                   every iteration) instead of the fused xfz kernel */
+
+#define ADMM_FLAG_NO_MFMA 32    /* ADMM_PRECISION_FP64 only: always the one-lane-per-QP kernels.  By default FP64 takes the
+                                  fp64 MFMA form of the fused kernels (same iteration, iterates equal to rounding;
+                                  DESIGN.md §4.9) where it is compiled for (n, m), the problem has no q and no
+                                  thrust-magnitude bound, and it is the faster of the two: n >= 9 (operand delivery binds
+                                  the one-lane kernels there), or a batch of at most 128 QPs (one wave per segment runs a
+                                  chain of ~15 MFMAs per stage instead of ~450 dependent vector instructions) */
 
 #define ADMM_FLAG_NO_ALTERNATE 8 /* always eliminate backward / substitute forward (xb + xfz kernels); by
                                   default (unless the forward form fails its host check for the problem),

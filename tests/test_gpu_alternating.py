@@ -59,7 +59,9 @@ def test_alternating_iterates_match_oracle(gpu, idx):
     p = make()
     for K in (1, 2, 3, 4, 5, 6, 7, 8, 9, 16):
         ref = oc.solve(p, rho=rho, max_iter=K, stop=False)
-        for flags in (0, _abi.FLAG_GRAPH):
+        # FLAG_NO_MFMA: the one-lane kernels this file is about (for small batches of q-free problems of an
+        # MFMA-compiled shape the default is the fp64 MFMA form, tests/test_gpu_mfma.py)
+        for flags in (0, _abi.FLAG_NO_MFMA, _abi.FLAG_NO_MFMA | _abi.FLAG_GRAPH):
             with pkg.Solver(p, pkg.Options(rho=rho, segments=segs, flags=flags)) as s:
                 s.iterate(K)
                 w, z, y = s.get()

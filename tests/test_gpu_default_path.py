@@ -25,11 +25,13 @@ def _close(got, ref, what):
     return err
 
 
-def test_config1_iterates_default_path(gpu):
+@pytest.mark.parametrize("flags", [0, 32], ids=["default_mfma_form", "one_lane_kernels"])
+def test_config1_iterates_default_path(gpu, flags):
     """configs[1]: cw_rendezvous(N=1000, batch=1), segments=0 (auto -> 64 one-wave segments, split-K
-    scan), default flags: iterates vs the oracle after 1, 2, 10, 40, 200 iterations."""
+    scan), default flags: iterates vs the oracle after 1, 2, 10, 40, 200 iterations.  The default for a batch
+    this small is the fp64 MFMA form of the fused kernels; ADMM_FLAG_NO_MFMA = the one-lane kernels."""
     p = pkg.cw_rendezvous(N=1000, batch=1)
-    with pkg.Solver(p, pkg.Options(rho=0.05)) as s:
+    with pkg.Solver(p, pkg.Options(rho=0.05, flags=flags)) as s:
         geo = s.geometry()
         assert geo["segments"] > 1                       # the parallel-in-time form really runs
         done = 0
@@ -42,13 +44,14 @@ def test_config1_iterates_default_path(gpu):
                 _close(a, ref[name], (upto, name))
 
 
-def test_config1_solve_default_path(gpu):
+@pytest.mark.parametrize("flags", [0, 32], ids=["default_mfma_form", "one_lane_kernels"])
+def test_config1_solve_default_path(gpu, flags):
     """configs[1]: a full admm_solve on the default path -- same iteration count, per-QP first-converged
     iteration, residuals and solution as the oracle."""
     p = pkg.cw_rendezvous(N=1000, batch=1)
     kw = dict(rho=0.05, eps_abs=1e-6, eps_rel=1e-6, max_iter=4000, check_interval=10)
     ref = oc.solve(p, **kw)
-    with pkg.Solver(p, pkg.Options(**kw)) as s:
+    with pkg.Solver(p, pkg.Options(flags=flags, **kw)) as s:
         info = s.solve()
         w, z, y = s.get()
     assert int(info.iters_run) == int(ref["iters_run"])

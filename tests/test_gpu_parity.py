@@ -112,7 +112,7 @@ def test_zdual_kernel(gpu, alpha, resid):
             assert np.abs(got - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
 
 
-@pytest.mark.parametrize("flags", [0, 8, 2], ids=["default", "fused_plain", "unfused"])
+@pytest.mark.parametrize("flags", [0, 32, 8, 2], ids=["default", "one_lane", "fused_plain", "unfused"])
 @pytest.mark.parametrize("idx", [0, 1, 3, 5, 7, 9, 15, 16, 17, 18, 20])
 def test_iterate_parity(gpu, idx, flags):
     """T4: iterates of the full loop vs the C oracle after 1, 2, 10, 40 iterations, on the
@@ -367,7 +367,7 @@ def test_randomised_configurations(gpu):
             assert np.abs(a - b).max() <= TOL * max(1.0, np.abs(b).max()), ctx
 
 
-@pytest.mark.parametrize("flags", [0, 8, 2], ids=["default", "fused_plain", "unfused"])
+@pytest.mark.parametrize("flags", [0, 32, 8, 2], ids=["default", "one_lane", "fused_plain", "unfused"])
 @pytest.mark.parametrize("shape", [(148, 1, 1, 300), (300, 2, 2, 64), (200, 3, 1, 5)])
 def test_tiny_blocks_with_segments_longer_than_one_record_chunk(gpu, shape, flags):
     """Regression (found by tools/stress_alt.py): for tiny (n, m) the per-stage records are so small

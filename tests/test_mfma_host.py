@@ -11,8 +11,8 @@ from admm_library_amd.solver import host_factor, host_factor_mfma
 
 
 def _layout(n, m):
-    xt = 1 if m > 4 else 0
-    return dict(xt=xt, urows=max(0, m - 4), ks_sub=7 + xt, ot_sub=1, ks_ef=7 + xt, ks_eb=4 + xt)
+    xt, nr = 1 if m > 4 else 0, (n + 3) // 4
+    return dict(xt=xt, nr=nr, urows=max(0, m - 4), ks_sub=2 * nr + 1 + xt, ot_sub=1, ks_ef=2 * nr + 1 + xt, ks_eb=nr + 1 + xt)
 
 
 def _urows(table, regs, L):
@@ -120,7 +120,8 @@ def test_mfma_records_reproduce_the_stage_operators(built, n, m, mode):
         eli = recMF[k][o_el:o_lh].view(dt_of(es["elim_f"])).reshape(L["ks_ef"], 2, 64)
         f32, tol = es["sub_f"] == 4, tol_of(es["sub_f"])
         X, T, D = _to_slots(x, None, n, m), _to_slots(t, None, n, m), _to_slots(None, d, n, m)
-        regs = [X[0], X[1], X[2], T[0], T[1], T[2], D[3]] + ([D[4]] if L["xt"] else [])
+        NR = L["nr"]
+        regs = list(X[:NR]) + list(T[:NR]) + [D[3]] + ([D[4]] if L["xt"] else [])
         o = _mfma(sub, regs, L["ot_sub"], f32)
         u_ref = -(F["K"] @ x + F["PSI"] @ t + d)
         x_ref = F["A"] @ x + F["B"] @ u_ref
@@ -132,7 +133,7 @@ def test_mfma_records_reproduce_the_stage_operators(built, n, m, mode):
         if n < 12:                                               # padding slots of the n-vector come out as exact zeros
             assert all(np.all(o[0, r, g] == 0) for r in range(3) for g in range(4) if 4 * r + g >= n)
         M, G = _to_slots(mu, None, n, m), _to_slots(gx, gu, n, m)
-        regs = [M[0], M[1], M[2], G[0], G[1], G[2], G[3]] + ([G[4]] if L["xt"] else [])
+        regs = list(M[:NR]) + list(G[:NR]) + [G[3]] + ([G[4]] if L["xt"] else [])
         f32, tol = es["elim_f"] == 4, tol_of(es["elim_f"])
         eps0 = rng.standard_normal((n, 16))
         acc = np.zeros((2, 16, 16))
@@ -165,7 +166,7 @@ def test_mfma_records_reproduce_the_stage_operators(built, n, m, mode):
         sub = recMB[k][:o_el].view(dt_of(es["sub_b"])).reshape(L["ks_sub"], L["ot_sub"], 64)
         eli = recMB[k][o_el:o_lh].view(dt_of(es["elim_b"])).reshape(L["ks_eb"], 2, 64)
         f32, tol = es["sub_b"] == 4, tol_of(es["sub_b"])
-        regs = [X[0], X[1], X[2], T[0], T[1], T[2], D[3]] + ([D[4]] if L["xt"] else [])     # x_{k+1}, m_in, db
+        regs = list(X[:NR]) + list(T[:NR]) + [D[3]] + ([D[4]] if L["xt"] else [])     # x_{k+1}, m_in, db
         o = _mfma(sub, regs, L["ot_sub"], f32)
         u_ref = -(BE["KB"] @ x + BE["PSB"] @ t + d)
         xk_ref = BE["AI"] @ x + BE["AIB"] @ u_ref
@@ -177,7 +178,7 @@ def test_mfma_records_reproduce_the_stage_operators(built, n, m, mode):
         assert np.abs(got_u - u_ref).max() <= tol * scale * max(1, np.abs(u_ref).max())
         f32, tol = es["elim_b"] == 4, tol_of(es["elim_b"])
         Pp, Gu = _to_slots(p_, None, n, m), _to_slots(None, gu, n, m)
-        regs = [Pp[0], Pp[1], Pp[2], Gu[3]] + ([Gu[4]] if L["xt"] else [])
+        regs = list(Pp[:NR]) + [Gu[3]] + ([Gu[4]] if L["xt"] else [])
         o = _mfma(eli, regs, 2, f32)
         h = B_["BT"] @ p_ + gu
         d_ref = B_["SI"] @ h
@@ -197,7 +198,7 @@ def test_mfma_record_sizes_and_unsupported_dims(built):
     assert lib.admm_mfma_record_bytes(12, 6, 2, C.byref(f), C.byref(b)) == 0      # fp64: every fragment 512 B
     assert (f.value, b.value) == ((8 + 16) * 512 + 320 + 2 * 8 * 4 * 8, (8 + 10) * 512 + 320 + 2 * 8 * 4 * 8)
     assert lib.admm_mfma_record_bytes(6, 3, 1, C.byref(f), C.byref(b)) == 0       # mixed: SUB_F, ELIM_B fragments 256 B
-    assert (f.value, b.value) == (7 * 256 + 14 * 512 + 320, 7 * 512 + 8 * 256 + 320)
+    assert (f.value, b.value) == (5 * 256 + 10 * 512 + 320, 5 * 512 + 6 * 256 + 320)          # n = 6: two registers per n-vector
     assert lib.admm_mfma_record_bytes(13, 3, 2, C.byref(f), C.byref(b)) != 0      # n > 12
     assert lib.admm_mfma_record_bytes(6, 9, 2, C.byref(f), C.byref(b)) != 0       # m > 8
     assert lib.admm_mfma_record_bytes(6, 3, 0, C.byref(f), C.byref(b)) != 0
