@@ -143,6 +143,7 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     o.adapt_max = static_cast<int32_t>(scalar_or(O, "adapt_max", o.adapt_max));
     o.adapt_mu = scalar_or(O, "adapt_mu", o.adapt_mu);
     o.adapt_tau = scalar_or(O, "adapt_tau", o.adapt_tau);
+    o.precision_mode = static_cast<int32_t>(scalar_or(O, "precision_mode", o.precision_mode));   // ADMM_PRECISION_*
     admm_handle* h = nullptr;
     check(admm_setup(&h, &p, &o));
     remember(h, L, p.batch);
@@ -163,8 +164,9 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     admm_info info;
     check(admm_solve(h, z0, y0, &info));
     const char* names[] = {"iters_run", "n_converged", "max_r", "max_s", "solve_ms", "iters", "status", "r", "s",
-                           "rho", "rho_updates"};
-    plhs[0] = mxCreateStructMatrix(1, 1, 11, names);
+                           "rho", "rho_updates", "mixed_iters"};
+    plhs[0] = mxCreateStructMatrix(1, 1, 12, names);
+    mxSetField(plhs[0], 0, "mixed_iters", mxCreateDoubleScalar(info.mixed_iters));
     mxSetField(plhs[0], 0, "rho", mxCreateDoubleScalar(info.rho));
     mxSetField(plhs[0], 0, "rho_updates", mxCreateDoubleScalar(info.rho_updates));
     mxSetField(plhs[0], 0, "iters_run", mxCreateDoubleScalar(info.iters_run));
