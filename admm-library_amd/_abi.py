@@ -92,7 +92,7 @@ def marshal_problem(p: Problem):
             np.broadcast_to(np.asarray(p.unorm, np.float64), (p.N,) if p.lo.ndim == 2 else (1,)), np.float64),
     }
     cp = CProblem(N=p.N, n=p.n, m=p.m, batch=p.batch,
-                  time_varying=int(p.time_varying), stage_bounds=int(p.lo.ndim == 2),
+                  time_varying=2 if p.per_instance else int(p.time_varying), stage_bounds=p.lo.ndim - 1,
                   A=dptr(keep["A"]), B=dptr(keep["B"]), Q=dptr(keep["Q"]), R=dptr(keep["R"]),
                   QN=dptr(keep["QN"]), x0=dptr(keep["x0"]), lo=dptr(keep["lo"]),
                   hi=dptr(keep["hi"]), q=dptr(keep["q"]), unorm=dptr(keep["unorm"]))

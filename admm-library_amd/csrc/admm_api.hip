@@ -77,6 +77,12 @@ struct admm_handle {
   bool mixed_phase1 = false;
   int mixed_iters = 0;
   int *status1 = nullptr, *iters1 = nullptr;
+  // per-instance dynamics (csrc/admm_pinst.hpp): device-side factor, operands per QP in HBM
+  bool pinst = false, pbounds = false;
+  double *Ad = nullptr, *Bd = nullptr, *Kd = nullptr, *Sd = nullptr, *lod = nullptr, *hid = nullptr;
+  double *Qd = nullptr, *Rd = nullptr, *QNd = nullptr;
+  int* pfail = nullptr;
+  size_t stage_rows = 0;         // rows the staging buffer holds (L, or N n^2 for the per-instance upload of A)
   bool alt = false;              // the alternating kernels exist for this problem and are enabled
   // what the last kernel left behind for the next x-update:
   //   ALT_NONE  nothing (the next iteration starts with xb_kernel)
@@ -132,6 +138,25 @@ admm::XLaunch xlaunch_of(const admm_handle* h) {
   return l;
 }
 
+admm::PLaunch plaunch_of(const admm_handle* h) {
+  admm::PLaunch l{};
+  l.stream = h->stream;
+  l.n = h->n; l.m = h->m; l.N = h->N; l.pitch = h->pitch; l.batch = h->batch;
+  l.has_q = h->has_q; l.pbounds = h->pbounds;
+  l.rho = h->opt.rho; l.alpha = h->opt.alpha;
+  l.Ad = h->Ad; l.Bd = h->Bd; l.Q = h->Qd; l.R = h->Rd; l.QN = h->QNd; l.Kd = h->Kd; l.Sd = h->Sd; l.fail = h->pfail;
+  l.lo = h->pbounds ? h->lod : h->lo; l.hi = h->pbounds ? h->hid : h->hi;
+  l.z = h->z; l.y = h->y; l.q = h->q; l.x0 = h->x0; l.v = h->v; l.w = h->w; l.dbuf = h->dbuf; l.part = h->part;
+  return l;
+}
+
+int launch_p(admm_handle* h, admm::PKernel k, bool vform, bool resid) {
+  admm::PLaunch l = plaunch_of(h);
+  l.vform = vform; l.resid = resid;
+  if (!admm::launch_pinst(l, k, false)) return fail(ADMM_ERR_UNSUPPORTED, "no per-instance kernel for this (n, m)");
+  return ADMM_OK;
+}
+
 bool dispatch_x(const admm::XLaunch& l, admm::XKernel k, bool a, bool b, bool query_only) {
   return admm::launch_group0(l, k, a, b, query_only) || admm::launch_group1(l, k, a, b, query_only) ||
          admm::launch_group2(l, k, a, b, query_only) || admm::launch_group3(l, k, a, b, query_only);
@@ -148,6 +173,14 @@ std::string supported_list() {
 }
 
 int launch_x(admm_handle* h, admm::XKernel k, bool a, bool b) {
+  if (h->pinst) {
+    switch (k) {
+      case admm::XKernel::XB: return launch_p(h, admm::PKernel::XB, a, false);
+      case admm::XKernel::XF: return launch_p(h, admm::PKernel::XF, false, false);
+      case admm::XKernel::XFZ: return launch_p(h, admm::PKernel::XFZ, a, b);
+      default: return fail(ADMM_ERR_UNSUPPORTED, "kernel form not available with per-instance dynamics");
+    }
+  }
   const admm::XLaunch l = xlaunch_of(h);
   // MFMA form: the alternating pair (fp64 records) or the plain path's v-form kernels (fp32 records); every other
   // kernel form -- (z, y)-input first iterations, read-out -- stays on the one-lane fp64 kernels (same arrays)
@@ -192,6 +225,7 @@ int launch_xscan_mfma(admm_handle* h, bool forward_form = false, bool with_final
 }
 
 int launch_xscan(admm_handle* h) {
+  if (h->pinst) return ADMM_OK;                 // one segment: nothing to couple
   if (!(h->opt.flags & ADMM_FLAG_SCAN_CHAIN)) return launch_xscan_mfma(h);
   return launch_x(h, admm::XKernel::XSCAN_CHAIN, false, false);
 }
@@ -205,6 +239,11 @@ int launch_xfz(admm_handle* h, bool resid, bool vin) { return launch_x(h, admm::
 // z = clip(v), y = v - z into the z / y arrays (read-out and mode switches)
 int ensure_zy(admm_handle* h) {
   if (h->zy_valid) return ADMM_OK;
+  if (h->pbounds) {
+    admm::launch_pv_to_zy(h->stream, h->v, h->z, h->y, h->lod, h->hid, (size_t)h->L * h->pitch);
+    h->zy_valid = true;
+    return ADMM_OK;
+  }
   dim3 grid((h->pitch / 2 + Z_THREADS - 1) / Z_THREADS, h->zchunks), block(Z_THREADS);
   if (h->has_soc)
     hipLaunchKernelGGL(admm::v_to_zy_soc_kernel, grid, block, 0, h->stream, (const double*)h->v, h->z, h->y,
@@ -332,6 +371,7 @@ int step_x(admm_handle* h) {
 
 // QP-major host array (batch x rows) -> batch-minor device array (rows x pitch)
 int upload_transposed(admm_handle* h, const double* src, double* dst, int rows) {
+  if ((size_t)rows > h->stage_rows) return fail(ADMM_ERR_INVALID, "internal: staging buffer too small");
   HIP_TRY(hipMemcpyAsync(h->stage, src, sizeof(double) * (size_t)rows * h->batch, hipMemcpyHostToDevice, h->stream));
   dim3 grid((rows + admm::T_TILE - 1) / admm::T_TILE, (h->pitch + admm::T_TILE - 1) / admm::T_TILE), block(admm::T_TILE * 8);
   hipLaunchKernelGGL(admm::to_batch_minor_kernel, grid, block, 0, h->stream, h->stage, dst, h->batch, rows, h->pitch);
@@ -382,7 +422,18 @@ int validate_problem(const admm_problem* p) {
   const size_t L = (size_t)p->N * nb;
   if (L * (size_t)p->batch > ((size_t)1 << 40)) return fail(ADMM_ERR_INVALID, "problem too large");
   if (L > (size_t)0x7fffffff) return fail(ADMM_ERR_INVALID, "L = N (n + m) exceeds 2^31 - 1");
-  const size_t nbnd = (size_t)nb * (p->stage_bounds ? p->N : 1);
+  if (p->time_varying < 0 || p->time_varying > 2 || p->stage_bounds < 0 || p->stage_bounds > 2)
+    return fail(ADMM_ERR_INVALID, "time_varying / stage_bounds must be 0, 1 or 2");
+  if (p->stage_bounds == 2 && p->time_varying != 2)
+    return fail(ADMM_ERR_INVALID, "per-instance bounds (stage_bounds = 2) need per-instance dynamics (time_varying = 2)");
+  if (p->time_varying == 2) {
+    if (p->unorm) return fail(ADMM_ERR_UNSUPPORTED, "the thrust-magnitude bound is not available with per-instance dynamics");
+    if (!p->Q || !p->R || !p->QN) return fail(ADMM_ERR_INVALID, "Q, R, QN must be non-NULL");
+    if (!finite_all(p->A, (size_t)p->n * p->n * p->N * p->batch) || !finite_all(p->B, (size_t)p->n * p->m * p->N * p->batch) ||
+        !finite_all(p->Q, (size_t)p->n * p->n) || !finite_all(p->R, (size_t)p->m * p->m) || !finite_all(p->QN, (size_t)p->n * p->n))
+      return fail(ADMM_ERR_INVALID, "non-finite entry in A, B, Q, R or QN");
+  }
+  const size_t nbnd = (size_t)nb * (p->stage_bounds ? p->N : 1) * (p->stage_bounds == 2 ? p->batch : 1);
   for (size_t i = 0; i < nbnd; ++i) {
     if (std::isnan(p->lo[i]) || std::isnan(p->hi[i])) return fail(ADMM_ERR_INVALID, "NaN in bounds");
     if (p->lo[i] > p->hi[i]) return fail(ADMM_ERR_INVALID, "lo > hi at bound index " + std::to_string(i));
@@ -439,6 +490,12 @@ void release(admm_handle* h) {
                      &h->recFE, &h->recBE, &h->mvec, &h->scanWpB};
   for (auto b : bufs)
     if (*b) { (void)hipFree(*b); *b = nullptr; }
+  {
+    double** pb[] = {&h->Ad, &h->Bd, &h->Kd, &h->Sd, &h->lod, &h->hid, &h->Qd, &h->Rd, &h->QNd};
+    for (auto b : pb)
+      if (*b) { (void)hipFree(*b); *b = nullptr; }
+    if (h->pfail) { (void)hipFree(h->pfail); h->pfail = nullptr; }
+  }
   if (h->recMF) { (void)hipFree(h->recMF); h->recMF = nullptr; }
   if (h->recMB) { (void)hipFree(h->recMB); h->recMB = nullptr; }
   if (h->recMF64) { (void)hipFree(h->recMF64); h->recMF64 = nullptr; }
@@ -542,6 +599,101 @@ bool problem_has_soc(const admm_problem* p) {
   if (p->unorm)
     for (int k = 0; k < (p->stage_bounds ? p->N : 1); ++k) soc = soc || std::isfinite(p->unorm[k]);
   return soc;
+}
+
+
+// ---- per-instance dynamics ----
+// Riccati factorisation of every QP on the device; ADMM_ERR_NUMERIC if some S_k is not positive definite.
+int pinst_factor(admm_handle* h, double rho) {
+  HIP_TRY(hipMemsetAsync(h->pfail, 0, sizeof(int), h->stream));
+  admm::PLaunch l = plaunch_of(h);
+  l.rho = rho;
+  if (!admm::launch_pinst(l, admm::PKernel::FACTOR, false)) return fail(ADMM_ERR_UNSUPPORTED, "no per-instance kernel for this (n, m)");
+  HIP_TRY(hipGetLastError());
+  int bad = 0;
+  HIP_TRY(hipMemcpyAsync(&bad, h->pfail, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (bad) return fail(ADMM_ERR_NUMERIC, "R + rho I + B'PB is not positive definite for some QP");
+  return ADMM_OK;
+}
+
+// shared weights as row-major device arrays; A, B, bounds per instance
+int pinst_upload(admm_handle* h, const admm_problem* p) {
+  const int n = h->n, m = h->m;
+  std::vector<double> Q((size_t)n * n), R((size_t)m * m), QN((size_t)n * n);
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j) { Q[(size_t)i * n + j] = 0.5 * (p->Q[(size_t)j * n + i] + p->Q[(size_t)i * n + j]); QN[(size_t)i * n + j] = 0.5 * (p->QN[(size_t)j * n + i] + p->QN[(size_t)i * n + j]); }
+  for (int i = 0; i < m; ++i)
+    for (int j = 0; j < m; ++j) R[(size_t)i * m + j] = 0.5 * (p->R[(size_t)j * m + i] + p->R[(size_t)i * m + j]);
+  HIP_TRY(hipMemcpy(h->Qd, Q.data(), sizeof(double) * Q.size(), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->Rd, R.data(), sizeof(double) * R.size(), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(h->QNd, QN.data(), sizeof(double) * QN.size(), hipMemcpyHostToDevice));
+  int rc;
+  if ((rc = upload_transposed(h, p->A, h->Ad, h->N * n * n))) return rc;
+  if ((rc = upload_transposed(h, p->B, h->Bd, h->N * n * m))) return rc;
+  if (h->pbounds) {
+    if ((rc = upload_transposed(h, p->lo, h->lod, h->L))) return rc;
+    if ((rc = upload_transposed(h, p->hi, h->hid, h->L))) return rc;
+  } else if ((rc = upload_bounds(h, p))) {
+    return rc;
+  }
+  return ADMM_OK;
+}
+
+int setup_pinst(admm_handle* h, const admm_problem* p) {
+  const admm_options& o = h->opt;
+  if (o.precision_mode != ADMM_PRECISION_FP64) return fail(ADMM_ERR_UNSUPPORTED, "precision_mode: the MFMA forms need batch-shared dynamics");
+  if (o.flags & (ADMM_FLAG_UNFUSED | ADMM_FLAG_GRAPH))
+    return fail(ADMM_ERR_UNSUPPORTED, "ADMM_FLAG_UNFUSED / ADMM_FLAG_GRAPH are not available with per-instance dynamics");
+  {
+    admm::PLaunch lq{};
+    lq.n = p->n; lq.m = p->m;
+    if (!admm::launch_pinst(lq, admm::PKernel::XB, true))
+      return fail(ADMM_ERR_UNSUPPORTED, "(n, m) = (" + std::to_string(p->n) + ", " + std::to_string(p->m) +
+                                            ") has no per-instance kernel; compiled: " + admm::dims_pinst());
+  }
+  h->pinst = true;
+  h->pbounds = p->stage_bounds == 2;
+  h->S = 1;
+  h->alt = h->alt_allowed = false;
+  h->time_varying = 2;
+  h->stage_bounds = p->stage_bounds;
+  {  // z-kernel chunking of the shared-bounds read-out kernel (as in admm_setup)
+    const int col_groups = (h->pitch / 2 + Z_THREADS - 1) / Z_THREADS;
+    int chunks = std::max(1, (h->num_cus + col_groups - 1) / col_groups);
+    int zr = ((h->L + chunks - 1) / chunks + 3) / 4 * 4;
+    if (zr < 4) zr = 4;
+    h->zrows = zr;
+    h->zchunks = (h->L + zr - 1) / zr;
+  }
+  const size_t P = h->pitch, L = h->L;
+  const int n = h->n, m = h->m, N = h->N;
+  HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  int rc;
+#define PD(ptr, cnt) do { if ((rc = dalloc(&(ptr), (size_t)(cnt)))) return rc; HIP_TRY(hipMemsetAsync((ptr), 0, sizeof(*(ptr)) * (size_t)(cnt), h->stream)); } while (0)
+  PD(h->w, L * P); PD(h->z, L * P); PD(h->y, L * P); PD(h->v, L * P);
+  if (h->has_q) PD(h->q, L * P);
+  PD(h->dbuf, (size_t)N * m * P);
+  PD(h->scan_in, (size_t)n * P);                 // only x0 lives here
+  h->x0 = h->scan_in;
+  PD(h->part, (size_t)std::max(h->zchunks, 1) * 5 * P);
+  PD(h->resid, 5 * P);
+  PD(h->lo, L); PD(h->hi, L); PD(h->ub, (size_t)N);
+  PD(h->Ad, (size_t)N * n * n * P); PD(h->Bd, (size_t)N * n * m * P);
+  PD(h->Kd, (size_t)N * m * n * P); PD(h->Sd, (size_t)N * m * m * P);
+  if (h->pbounds) { PD(h->lod, L * P); PD(h->hid, L * P); }
+  PD(h->Qd, (size_t)n * n); PD(h->Rd, (size_t)m * m); PD(h->QNd, (size_t)n * n);
+  PD(h->pfail, 1); PD(h->status, P); PD(h->iters, P); PD(h->nconv, 1);
+  h->stage_rows = std::max(L, (size_t)N * n * n);
+  if ((rc = dalloc(&h->stage, h->stage_rows * (size_t)h->batch))) return rc;
+#undef PD
+  HIP_TRY(hipHostMalloc((void**)&h->h_nconv, sizeof(int), hipHostMallocDefault));
+  if ((rc = pinst_upload(h, p))) return rc;
+  if ((rc = upload_transposed(h, p->x0, h->x0, n))) return rc;
+  if (h->has_q && (rc = upload_transposed(h, p->q, h->q, (int)L))) return rc;
+  if ((rc = pinst_factor(h, o.rho))) return rc;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return ADMM_OK;
 }
 
 }  // namespace
@@ -690,6 +842,12 @@ int admm_setup(admm_handle** out, const admm_problem* p, const admm_options* o_i
   h->pitch = ((p->batch + 63) / 64) * 64;
   h->has_q = p->q != nullptr;
   h->has_soc = problem_has_soc(p);
+  if (p->time_varying == 2) {                    // per-instance dynamics: its own set-up (device factorisation)
+    rc = setup_pinst(h, p);
+    if (rc) { std::string keep = g_err; release(h); g_err = keep; return rc; }
+    *out = h;
+    return ADMM_OK;
+  }
 
   // x-update segments: ONE workgroup (256 columns x one segment) per CU -- the grid
   // ceil(pitch / 256) x S should fill the 256 CUs once and not spill into a ragged second round
@@ -870,6 +1028,7 @@ int admm_setup(admm_handle** out, const admm_problem* p, const admm_options* o_i
   TRY_RELEASE(dalloc(&h->status, P));
   TRY_RELEASE(dalloc(&h->iters, P));
   TRY_RELEASE(dalloc(&h->nconv, 1));
+  h->stage_rows = L;
   TRY_RELEASE(dalloc(&h->stage, L * (size_t)h->batch));
   HIP_TRY_RELEASE(hipHostMalloc((void**)&h->h_nconv, sizeof(int), hipHostMallocDefault));
 
@@ -923,6 +1082,25 @@ int admm_update_instances(admm_handle* h, const double* x0, const double* q) {
 static int set_rho_internal(admm_handle* h, double rho_new) {
   if (!(rho_new > 0.0) || !std::isfinite(rho_new)) return fail(ADMM_ERR_INVALID, "rho must be positive and finite");
   if (rho_new == h->opt.rho) return ADMM_OK;
+  if (h->pinst) {
+    int rc;
+    if ((rc = ensure_w(h))) return rc;          // w of the last x-update must be rebuilt with the OLD factor
+    if ((rc = ensure_zy(h))) return rc;
+    const double c = h->opt.rho / rho_new;
+    hipLaunchKernelGGL(admm::scale_kernel, dim3(2048), dim3(256), 0, h->stream, h->y, c, (size_t)h->L * h->pitch / 2);
+    HIP_TRY(hipGetLastError());
+    h->zy_valid = true;
+    h->v_valid = false;
+    if ((rc = pinst_factor(h, rho_new))) {        // refactor in place failed: restore the old factor and the dual
+      hipLaunchKernelGGL(admm::scale_kernel, dim3(2048), dim3(256), 0, h->stream, h->y, 1.0 / c, (size_t)h->L * h->pitch / 2);
+      std::string keep = g_err;
+      (void)pinst_factor(h, h->opt.rho);
+      g_err = keep;
+      return rc;
+    }
+    h->opt.rho = rho_new;
+    return ADMM_OK;
+  }
   admm_problem p{};
   p.N = h->N; p.n = h->n; p.m = h->m; p.batch = h->batch;
   p.time_varying = h->time_varying; p.stage_bounds = h->stage_bounds;
@@ -975,6 +1153,20 @@ int admm_update_problem(admm_handle* h, const admm_problem* p) {
     return fail(ADMM_ERR_INVALID, "admm_update_problem: q must be given iff the handle was set up with one");
   if (problem_has_soc(p) != h->has_soc)
     return fail(ADMM_ERR_INVALID, "admm_update_problem: a thrust-magnitude bound cannot be added to or removed from a handle");
+  if ((p->time_varying == 2) != h->pinst || (h->pinst && (p->stage_bounds == 2) != h->pbounds))
+    return fail(ADMM_ERR_INVALID, "admm_update_problem: per-instance dynamics / bounds cannot be added to or removed from a handle");
+  if (h->pinst) {
+    if ((rc = ensure_w(h))) return rc;           // w of the last x-update belongs to the old problem data
+    if ((rc = ensure_zy(h))) return rc;
+    h->zy_valid = true;
+    h->v_valid = false;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->stage_bounds = p->stage_bounds;
+    if ((rc = pinst_upload(h, p))) return rc;
+    if ((rc = upload_transposed(h, p->x0, h->x0, h->n))) return rc;
+    if (h->has_q && (rc = upload_transposed(h, p->q, h->q, h->L))) return rc;
+    return pinst_factor(h, h->opt.rho);
+  }
   admm::Factor f;
   std::string err;
   if ((rc = admm::factorise(*p, h->opt.rho, h->S, f, err, h->mfma_mode))) return fail(rc, err);
@@ -1035,6 +1227,7 @@ int admm_step_x(admm_handle* h) {
 
 int admm_step_z(admm_handle* h, int32_t residuals) {
   if (!h) return fail(ADMM_ERR_INVALID, "NULL handle");
+  if (h->pbounds) return fail(ADMM_ERR_UNSUPPORTED, "admm_step_z: the standalone z kernel has no per-instance bounds form");
   HIP_TRY(hipSetDevice(h->device));
   int rc = ensure_w(h);
   if (!rc) rc = ensure_zy(h);
@@ -1309,6 +1502,7 @@ int admm_get_info(admm_handle* h, int32_t* iters, int32_t* status, double* r, do
 int admm_profile(admm_handle* h, int32_t iters, int32_t residuals, int32_t fused_path, double ms[6]) {
   if (!h || !ms) return fail(ADMM_ERR_INVALID, "NULL argument");
   if (iters < 1 || iters > 4096) return fail(ADMM_ERR_INVALID, "iters must lie in [1, 4096]");
+  if (h->pinst && fused_path != 1) return fail(ADMM_ERR_UNSUPPORTED, "admm_profile: per-instance dynamics run the plain fused path only (fused_path = 1)");
   HIP_TRY(hipSetDevice(h->device));
   constexpr int NE = 6;     // events per iteration
   if ((fused_path == 2 || fused_path == 3) && !h->alt) return fail(ADMM_ERR_UNSUPPORTED, "the alternating-direction kernels are not enabled for this handle");

@@ -42,6 +42,23 @@ bool launch_group3(const XLaunch& l, XKernel k, bool a, bool b, bool query_only)
 // (n, m) pair or the kernel has no MFMA instantiation.
 bool launch_mfma(const XLaunch& l, XKernel k, bool resid, bool query_only);
 const char* dims_mfma();
+// ---- per-instance dynamics (admm_pinst.hpp): everything per QP, batch-minor; one lane sweeps the whole horizon ----
+struct PLaunch {
+  hipStream_t stream;
+  int n, m, N, pitch, batch;
+  bool has_q, vform, resid, pbounds;   // vform: state read from v; pbounds: lo / hi per instance ([k][n+m][pitch])
+  double rho, alpha;
+  const double *Ad, *Bd, *Q, *R, *QN;  // Q, R, QN: shared, row-major, on the device
+  double *Kd, *Sd;
+  int* fail;
+  const double *lo, *hi;
+  const double *z, *y, *q, *x0;
+  double *v, *w, *dbuf, *part;
+};
+enum class PKernel { FACTOR, XB, XF, XFZ };
+bool launch_pinst(const PLaunch& l, PKernel k, bool query_only);
+void launch_pv_to_zy(hipStream_t stream, const double* v, double* z, double* y, const double* lo, const double* hi, size_t count);
+const char* dims_pinst();
 // " (n,m) (n,m) ..." of a group, for error messages
 const char* dims_group0();
 const char* dims_group1();

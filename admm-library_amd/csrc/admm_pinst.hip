@@ -1,0 +1,76 @@
+// Per-instance dynamics (admm_pinst.hpp): instantiations and launcher.  Adding a shape = adding X(n, m) below.
+#include "admm_dispatch.hpp"
+#include "admm_pinst.hpp"
+
+#define ADMM_PINST_DIMS(X) X(6, 3) X(2, 1) X(4, 2) X(3, 2)
+
+namespace admm {
+
+const char* dims_pinst() {
+#define ADMM_STR2(x) #x
+#define ADMM_STR(x) ADMM_STR2(x)
+#define X(NX, NU) "(" ADMM_STR(NX) "," ADMM_STR(NU) ") "
+  return ADMM_PINST_DIMS(X);
+#undef X
+}
+
+namespace {
+
+template <int NX, int NU>
+void launch_dim(const PLaunch& l, PKernel k) {
+  const dim3 grid((l.pitch + PI_THREADS - 1) / PI_THREADS), block(PI_THREADS);
+  const bool relax = l.alpha != 1.0;
+  switch (k) {
+    case PKernel::FACTOR:
+      hipLaunchKernelGGL((pfactor_kernel<NX, NU>), grid, block, 0, l.stream, l.Ad, l.Bd, l.Q, l.R, l.QN, l.rho, l.Kd, l.Sd,
+                         l.fail, l.N, l.pitch, l.batch);
+      break;
+    case PKernel::XB: {
+#define XB(HQ, VF, PB_)                                                                                               \
+  hipLaunchKernelGGL((pxb_kernel<NX, NU, HQ, VF, PB_>), grid, block, 0, l.stream, l.vform ? l.v : l.z, l.y, l.q, l.Ad, \
+                     l.Bd, l.Kd, l.Sd, l.lo, l.hi, l.dbuf, l.rho, l.N, l.pitch)
+#define XB2(HQ, VF) do { if (l.pbounds) XB(HQ, VF, true); else XB(HQ, VF, false); } while (0)
+      if (l.has_q) { if (l.vform) XB2(true, true); else XB2(true, false); }
+      else         { if (l.vform) XB2(false, true); else XB2(false, false); }
+#undef XB2
+#undef XB
+      break;
+    }
+    case PKernel::XF:      // read-out: w of the last x-update
+      hipLaunchKernelGGL((pxfz_kernel<NX, NU, false, false, false, false, false, true>), grid, block, 0, l.stream, l.dbuf,
+                         l.x0, l.Ad, l.Bd, l.Kd, l.lo, l.hi, l.z, l.y, l.v, l.w, l.part, l.alpha, l.N, l.pitch);
+      break;
+    case PKernel::XFZ: {
+#define XFZ(RS, RX, VI, PB_)                                                                                          \
+  hipLaunchKernelGGL((pxfz_kernel<NX, NU, true, RS, RX, VI, PB_, false>), grid, block, 0, l.stream, l.dbuf, l.x0, l.Ad, \
+                     l.Bd, l.Kd, l.lo, l.hi, l.z, l.y, l.v, l.w, l.part, l.alpha, l.N, l.pitch)
+#define XFZ3(RS, RX, VI) do { if (l.pbounds) XFZ(RS, RX, VI, true); else XFZ(RS, RX, VI, false); } while (0)
+#define XFZ2(RS, RX) do { if (l.vform) XFZ3(RS, RX, true); else XFZ3(RS, RX, false); } while (0)
+      if (l.resid) { if (relax) XFZ2(true, true); else XFZ2(true, false); }
+      else         { if (relax) XFZ2(false, true); else XFZ2(false, false); }
+#undef XFZ2
+#undef XFZ3
+#undef XFZ
+      break;
+    }
+  }
+}
+
+}  // namespace
+
+bool launch_pinst(const PLaunch& l, PKernel k, bool query_only) {
+#define X(NX, NU)                              \
+  if (l.n == NX && l.m == NU) {                \
+    if (!query_only) launch_dim<NX, NU>(l, k); \
+    return true;                               \
+  }
+  ADMM_PINST_DIMS(X)
+#undef X
+  return false;
+}
+
+void launch_pv_to_zy(hipStream_t stream, const double* v, double* z, double* y, const double* lo, const double* hi, size_t count) {
+  hipLaunchKernelGGL(pv_to_zy_kernel, dim3(2048), dim3(256), 0, stream, v, z, y, lo, hi, count);
+}
+
+}  // namespace admm

@@ -1,0 +1,362 @@
+// admm_pinst.hpp -- per-instance dynamics (admm_problem.time_varying = 2): every QP has its own
+// A_k, B_k (and, with stage_bounds = 2, its own per-stage box) -- the QP class a batched successive-convexification
+// loop produces.  No reference counterpart exists (README.md:1-2 only).
+//
+// Nothing is shared by the batch any more, so nothing is wave-uniform: the KKT factor is per QP and is computed ON THE
+// DEVICE (pfactor_kernel: one lane runs the Riccati recursion of its QP), and the sweeps read their stage operators
+// from HBM per lane instead of from LDS broadcasts.  All per-instance arrays are batch-minor like the state:
+//     X[(k * E + e) * pitch + col]          element e of stage k of QP col
+// so every wave-level access is still one contiguous 512-B row segment.
+//   Ad [k][n*n] A_k and Bd [k][n*m] B_k, COLUMN-major per stage (the ABI's own order: the upload is one transposition
+//   of the caller's array)      Kd [k][m*n] row-major      Sd [k][m*m] = (R + rho I + B'PB)^-1
+//   lod / hid [k][m+n]  (stage_bounds = 2; otherwise the shared expanded arrays lo / hi [L])
+// Iteration = the plain path without segments (one lane sweeps the whole horizon; the batch is the only parallelism):
+//     pxb_kernel  backward sweep (d rows -> dbuf)      pxfz_kernel  forward rollout + z-update + dual + residuals
+// Algorithmic HBM bytes per stacked element and iteration (n = 6, m = 3, fp64, v-form):
+//     factor operands  A 36 + B 18 + K 18 + S 9 = 81 doubles (backward), K + A + B = 72 (forward)  -> 153 x 8 / 9 = 136 B
+//     state            v 8 + d 2.67 (pxb), d 2.67 + v 8 + v+ 8 (pxfz)                              ->  29.33 B
+//     per-instance box lo, hi read by both kernels                                                  ->  32 B
+// i.e. ~200 B/element against 21-29 B for batch-shared dynamics: this path is bound by FACTOR traffic (SURVEY.md §7
+// "factor traffic can dominate"), a different roofline from the headline's.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+
+namespace admm {
+
+constexpr int PI_THREADS = 64;      // one wave per workgroup: small batches still spread over the CUs
+
+// ---------------------------------------------------------------------------
+// Riccati factorisation of every QP, one lane per QP, stages N-1 .. 0:
+//     S = R + rho I + B'PB,  Si = S^-1,  K = Si B'PA,  P <- Q + rho I + A'PA - K'SK      (P_N = QN + rho I)
+// Q, R, QN: shared, row-major.  *fail is set if some S is not positive definite / not finite.
+// ---------------------------------------------------------------------------
+template <int NX, int NU>
+__global__ __launch_bounds__(PI_THREADS) void pfactor_kernel(
+    const double* __restrict__ Ad, const double* __restrict__ Bd, const double* __restrict__ Qm,
+    const double* __restrict__ Rm, const double* __restrict__ QNm, double rho,
+    double* __restrict__ Kd, double* __restrict__ Sd, int* __restrict__ fail, int N, int pitch, int batch) {
+  const int col = blockIdx.x * PI_THREADS + threadIdx.x;
+  if (col >= pitch) return;
+  const size_t P_ = (size_t)pitch;
+  const bool real = col < batch;            // pad columns hold zero dynamics: factor them like the rest (finite), never flag them
+  double P[NX][NX];
+#pragma unroll
+  for (int i = 0; i < NX; ++i)
+#pragma unroll
+    for (int j = 0; j < NX; ++j) P[i][j] = QNm[i * NX + j] + (i == j ? rho : 0.0);
+  bool bad = false;
+  for (int k = N - 1; k >= 0; --k) {
+    double A[NX][NX], B[NX][NU];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+#pragma unroll
+      for (int j = 0; j < NX; ++j) A[i][j] = Ad[((size_t)k * NX * NX + j * NX + i) * P_ + col];
+#pragma unroll
+      for (int j = 0; j < NU; ++j) B[i][j] = Bd[((size_t)k * NX * NU + j * NX + i) * P_ + col];
+    }
+    double S[NU][NU], Si[NU][NU];
+    {
+      double PB[NX][NU];
+#pragma unroll
+      for (int i = 0; i < NX; ++i)
+#pragma unroll
+        for (int j = 0; j < NU; ++j) {
+          double a = 0.0;
+#pragma unroll
+          for (int l = 0; l < NX; ++l) a = fma(P[i][l], B[l][j], a);
+          PB[i][j] = a;
+        }
+#pragma unroll
+      for (int a_ = 0; a_ < NU; ++a_)
+#pragma unroll
+        for (int b_ = 0; b_ < NU; ++b_) {
+          double a = Rm[a_ * NU + b_] + (a_ == b_ ? rho : 0.0);
+#pragma unroll
+          for (int i = 0; i < NX; ++i) a = fma(B[i][a_], PB[i][b_], a);
+          S[a_][b_] = a;
+        }
+    }
+#pragma unroll
+    for (int a_ = 0; a_ < NU; ++a_)
+#pragma unroll
+      for (int b_ = a_ + 1; b_ < NU; ++b_) { const double v = 0.5 * (S[a_][b_] + S[b_][a_]); S[a_][b_] = S[b_][a_] = v; }
+    {  // Gauss-Jordan inverse of the SPD m x m matrix (no pivoting needed; a non-positive pivot flags failure)
+      double W[NU][NU];
+#pragma unroll
+      for (int a_ = 0; a_ < NU; ++a_)
+#pragma unroll
+        for (int b_ = 0; b_ < NU; ++b_) { W[a_][b_] = S[a_][b_]; Si[a_][b_] = (a_ == b_) ? 1.0 : 0.0; }
+#pragma unroll
+      for (int c = 0; c < NU; ++c) {
+        const double pv = W[c][c];
+        if (!(pv > 0.0) || !(pv < INFINITY)) bad = true;
+        const double ip = 1.0 / pv;
+#pragma unroll
+        for (int j = 0; j < NU; ++j) { W[c][j] *= ip; Si[c][j] *= ip; }
+#pragma unroll
+        for (int r = 0; r < NU; ++r) {
+          if (r == c) continue;
+          const double f = W[r][c];
+#pragma unroll
+          for (int j = 0; j < NU; ++j) { W[r][j] = fma(-f, W[c][j], W[r][j]); Si[r][j] = fma(-f, Si[c][j], Si[r][j]); }
+        }
+      }
+#pragma unroll
+      for (int a_ = 0; a_ < NU; ++a_)
+#pragma unroll
+        for (int b_ = a_ + 1; b_ < NU; ++b_) { const double v = 0.5 * (Si[a_][b_] + Si[b_][a_]); Si[a_][b_] = Si[b_][a_] = v; }
+    }
+    double PA[NX][NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i)
+#pragma unroll
+      for (int l = 0; l < NX; ++l) {
+        double a = 0.0;
+#pragma unroll
+        for (int r = 0; r < NX; ++r) a = fma(P[i][r], A[r][l], a);
+        PA[i][l] = a;
+      }
+    double K[NU][NX];
+    {
+      double BtPA[NU][NX];
+#pragma unroll
+      for (int j = 0; j < NU; ++j)
+#pragma unroll
+        for (int l = 0; l < NX; ++l) {
+          double a = 0.0;
+#pragma unroll
+          for (int i = 0; i < NX; ++i) a = fma(B[i][j], PA[i][l], a);
+          BtPA[j][l] = a;
+        }
+#pragma unroll
+      for (int j = 0; j < NU; ++j)
+#pragma unroll
+        for (int l = 0; l < NX; ++l) {
+          double a = 0.0;
+#pragma unroll
+          for (int t = 0; t < NU; ++t) a = fma(Si[j][t], BtPA[t][l], a);
+          K[j][l] = a;
+        }
+    }
+    // P <- Q + rho I + A'PA - K' S K
+#pragma unroll
+    for (int i = 0; i < NX; ++i)
+#pragma unroll
+      for (int l = 0; l < NX; ++l) {
+        double a = Qm[i * NX + l] + (i == l ? rho : 0.0);
+#pragma unroll
+        for (int r = 0; r < NX; ++r) a = fma(A[r][i], PA[r][l], a);
+        P[i][l] = a;
+      }
+    {
+      double SK[NU][NX];
+#pragma unroll
+      for (int j = 0; j < NU; ++j)
+#pragma unroll
+        for (int l = 0; l < NX; ++l) {
+          double a = 0.0;
+#pragma unroll
+          for (int t = 0; t < NU; ++t) a = fma(S[j][t], K[t][l], a);
+          SK[j][l] = a;
+        }
+#pragma unroll
+      for (int i = 0; i < NX; ++i)
+#pragma unroll
+        for (int l = 0; l < NX; ++l) {
+          double a = P[i][l];
+#pragma unroll
+          for (int j = 0; j < NU; ++j) a = fma(-K[j][i], SK[j][l], a);
+          P[i][l] = a;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i)
+#pragma unroll
+      for (int l = i + 1; l < NX; ++l) { const double v = 0.5 * (P[i][l] + P[l][i]); P[i][l] = P[l][i] = v; }
+#pragma unroll
+    for (int j = 0; j < NU; ++j) {
+#pragma unroll
+      for (int l = 0; l < NX; ++l) Kd[((size_t)k * NU * NX + j * NX + l) * P_ + col] = K[j][l];
+#pragma unroll
+      for (int t = 0; t < NU; ++t) Sd[((size_t)k * NU * NU + j * NU + t) * P_ + col] = Si[j][t];
+    }
+  }
+  if (bad && real) atomicOr(fail, 1);
+}
+
+// bounds of stacked row (k, r): per instance (PB) or shared
+template <bool PB>
+__device__ __forceinline__ void pi_bounds(const double* lo, const double* hi, int k, int r, int nb, size_t P_, int col,
+                                          double& l, double& h) {
+  if (PB) {
+    const size_t o = ((size_t)k * nb + r) * P_ + col;
+    l = lo[o];
+    h = hi[o];
+  } else {
+    l = lo[(size_t)k * nb + r];
+    h = hi[(size_t)k * nb + r];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Backward sweep (as xb_kernel, one segment = the whole horizon):
+//     g = q - rho (z - y);  p = g^x + t;  h = B'p + g^u;  d_k = Si h -> dbuf;  t = A'p - K'h
+// ---------------------------------------------------------------------------
+template <int NX, int NU, bool HASQ, bool VFORM, bool PB>
+__global__ __launch_bounds__(PI_THREADS) void pxb_kernel(
+    const double* __restrict__ z, const double* __restrict__ y, const double* __restrict__ q,
+    const double* __restrict__ Ad, const double* __restrict__ Bd, const double* __restrict__ Kd,
+    const double* __restrict__ Sd, const double* __restrict__ lo, const double* __restrict__ hi,
+    double* __restrict__ dbuf, double rho, int N, int pitch) {
+  constexpr int NB = NX + NU;
+  const int col = blockIdx.x * PI_THREADS + threadIdx.x;
+  if (col >= pitch) return;
+  const size_t P_ = (size_t)pitch;
+  double t[NX];
+#pragma unroll
+  for (int i = 0; i < NX; ++i) t[i] = 0.0;
+  for (int k = N - 1; k >= 0; --k) {
+    double g[NB];
+#pragma unroll
+    for (int r = 0; r < NB; ++r) {
+      const size_t o = ((size_t)k * NB + r) * P_ + col;
+      double zz = z[o], yy;
+      if (VFORM) {
+        double l, h;
+        pi_bounds<PB>(lo, hi, k, r, NB, P_, col, l, h);
+        const double v = zz;
+        zz = fmin(fmax(v, l), h);
+        yy = v - zz;
+      } else {
+        yy = y[o];
+      }
+      g[r] = -rho * (zz - yy);
+      if (HASQ) g[r] += q[o];
+    }
+    double p[NX], h[NU], d[NU];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) p[i] = g[NU + i] + t[i];
+#pragma unroll
+    for (int j = 0; j < NU; ++j) {
+      double a = g[j];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) a = fma(Bd[((size_t)k * NX * NU + j * NX + i) * P_ + col], p[i], a);
+      h[j] = a;
+    }
+#pragma unroll
+    for (int j = 0; j < NU; ++j) {
+      double a = 0.0;
+#pragma unroll
+      for (int l = 0; l < NU; ++l) a = fma(Sd[((size_t)k * NU * NU + j * NU + l) * P_ + col], h[l], a);
+      d[j] = a;
+      dbuf[((size_t)k * NU + j) * P_ + col] = a;
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      double a = 0.0;
+#pragma unroll
+      for (int l = 0; l < NX; ++l) a = fma(Ad[((size_t)k * NX * NX + i * NX + l) * P_ + col], p[l], a);
+#pragma unroll
+      for (int j = 0; j < NU; ++j) a = fma(-Kd[((size_t)k * NU * NX + j * NX + i) * P_ + col], h[j], a);
+      t[i] = a;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Forward rollout (+ z-update, dual ascent, residual partials when ZUP; + w stored when STOREW):
+//     u = -K x - d;  x <- A x + B u;   ZUP: v+ = wh + y_old -> v, partials -> part[5][pitch]
+// ZUP = false, STOREW = true is the read-out kernel (w of the last x-update).
+// ---------------------------------------------------------------------------
+template <int NX, int NU, bool ZUP, bool RESID, bool RELAX, bool VIN, bool PB, bool STOREW>
+__global__ __launch_bounds__(PI_THREADS) void pxfz_kernel(
+    const double* __restrict__ dbuf, const double* __restrict__ x0, const double* __restrict__ Ad,
+    const double* __restrict__ Bd, const double* __restrict__ Kd, const double* __restrict__ lo,
+    const double* __restrict__ hi, const double* __restrict__ zin, const double* __restrict__ yin,
+    double* __restrict__ v, double* __restrict__ w, double* __restrict__ part, double alpha, int N, int pitch) {
+  constexpr int NB = NX + NU;
+  const int col = blockIdx.x * PI_THREADS + threadIdx.x;
+  if (col >= pitch) return;
+  const size_t P_ = (size_t)pitch;
+  double x[NX];
+#pragma unroll
+  for (int i = 0; i < NX; ++i) x[i] = x0[(size_t)i * P_ + col];
+  double a_r = 0, a_s = 0, a_w = 0, a_z = 0, a_y = 0;
+  for (int k = 0; k < N; ++k) {
+    double wv[NB];
+#pragma unroll
+    for (int j = 0; j < NU; ++j) {
+      double a = dbuf[((size_t)k * NU + j) * P_ + col];
+#pragma unroll
+      for (int i = 0; i < NX; ++i) a = fma(Kd[((size_t)k * NU * NX + j * NX + i) * P_ + col], x[i], a);
+      wv[j] = -a;
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      double a = 0.0;
+#pragma unroll
+      for (int l = 0; l < NX; ++l) a = fma(Ad[((size_t)k * NX * NX + l * NX + i) * P_ + col], x[l], a);
+#pragma unroll
+      for (int j = 0; j < NU; ++j) a = fma(Bd[((size_t)k * NX * NU + j * NX + i) * P_ + col], wv[j], a);
+      wv[NU + i] = a;
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) x[i] = wv[NU + i];
+#pragma unroll
+    for (int r = 0; r < NB; ++r) {
+      const size_t o = ((size_t)k * NB + r) * P_ + col;
+      if (STOREW) w[o] = wv[r];
+      if (ZUP) {
+        double l, h;
+        pi_bounds<PB>(lo, hi, k, r, NB, P_, col, l, h);
+        double zo, yo;
+        if (VIN) {
+          const double c0 = v[o];
+          zo = fmin(fmax(c0, l), h);
+          yo = c0 - zo;
+        } else {
+          yo = yin[o];
+          zo = (RESID || RELAX) ? zin[o] : 0.0;
+        }
+        double wh = wv[r];
+        if (RELAX) wh = fma(alpha, wv[r], (1.0 - alpha) * zo);
+        const double vn = wh + yo;
+        v[o] = vn;
+        if (RESID) {
+          const double zn = fmin(fmax(vn, l), h);
+          const double yn = vn - zn;
+          const double dr = wv[r] - zn, ds = zn - zo;
+          a_r = fma(dr, dr, a_r);
+          a_s = fma(ds, ds, a_s);
+          a_w = fma(wv[r], wv[r], a_w);
+          a_z = fma(zn, zn, a_z);
+          a_y = fma(yn, yn, a_y);
+        }
+      }
+    }
+  }
+  if (ZUP && RESID) {
+    part[0 * P_ + col] = a_r;
+    part[1 * P_ + col] = a_s;
+    part[2 * P_ + col] = a_w;
+    part[3 * P_ + col] = a_z;
+    part[4 * P_ + col] = a_y;
+  }
+}
+
+// v -> (z, y) with per-instance bounds (read-out, mode switches)
+static __global__ __launch_bounds__(256) void pv_to_zy_kernel(const double* __restrict__ v, double* __restrict__ z,
+                                                              double* __restrict__ y, const double* __restrict__ lo,
+                                                              const double* __restrict__ hi, size_t count) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) {
+    const double vv = v[i];
+    const double zz = fmin(fmax(vv, lo[i]), hi[i]);
+    z[i] = zz;
+    y[i] = vv - zz;
+  }
+}
+
+}  // namespace admm

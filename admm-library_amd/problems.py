@@ -30,14 +30,14 @@ class Problem:
     with w = (u_0, x_1, ..., u_{N-1}, x_N), block k = (u_k, x_{k+1}).
     """
     N: int
-    A: np.ndarray                 # (n, n) LTI or (N, n, n) LTV
-    B: np.ndarray                 # (n, m) or (N, n, m)
+    A: np.ndarray                 # (n, n) LTI, (N, n, n) LTV, or (batch, N, n, n) per-instance LTV (DESIGN.md §4.10)
+    B: np.ndarray                 # (n, m), (N, n, m) or (batch, N, n, m)
     Q: np.ndarray                 # (n, n)
     R: np.ndarray                 # (m, m)
     QN: np.ndarray                # (n, n)
     x0: np.ndarray                # (batch, n)
-    lo: np.ndarray                # (m + n,) or (N, m + n); -inf allowed
-    hi: np.ndarray                # (m + n,) or (N, m + n); +inf allowed
+    lo: np.ndarray                # (m + n,), (N, m + n), or (batch, N, m + n) per instance; -inf allowed
+    hi: np.ndarray                # likewise; +inf allowed
     q: Optional[np.ndarray] = None  # (batch, L) or None
     # thrust-magnitude bound ||u_k||_2 <= unorm (scalar, or (N,) when the box is per stage); None = off.
     # Where finite, the box of the control rows must be (-inf, inf).
@@ -66,13 +66,27 @@ class Problem:
 
     @property
     def time_varying(self) -> bool:
-        return self.A.ndim == 3
+        return self.A.ndim >= 3
+
+    @property
+    def per_instance(self) -> bool:
+        """Every QP has its own dynamics (admm_problem.time_varying = 2)."""
+        return self.A.ndim == 4
+
+    @property
+    def per_instance_bounds(self) -> bool:
+        """Every QP has its own per-stage box (admm_problem.stage_bounds = 2)."""
+        return self.lo.ndim == 3
 
     def slice(self, start: int, stop: int) -> "Problem":
         """Contiguous sub-batch [start, stop): the sharding unit."""
-        return dataclasses.replace(
-            self, x0=np.ascontiguousarray(self.x0[start:stop]),
-            q=None if self.q is None else np.ascontiguousarray(self.q[start:stop]))
+        rep = dict(x0=np.ascontiguousarray(self.x0[start:stop]),
+                   q=None if self.q is None else np.ascontiguousarray(self.q[start:stop]))
+        if self.per_instance:
+            rep.update(A=np.ascontiguousarray(self.A[start:stop]), B=np.ascontiguousarray(self.B[start:stop]))
+        if self.per_instance_bounds:
+            rep.update(lo=np.ascontiguousarray(self.lo[start:stop]), hi=np.ascontiguousarray(self.hi[start:stop]))
+        return dataclasses.replace(self, **rep)
 
     def validate(self) -> None:
         n, m, N = self.n, self.m, self.N
@@ -85,14 +99,22 @@ class Problem:
         if self.B.ndim == 3 and self.B.shape[0] != N:
             raise ValueError("time-varying B must have N stages")
         if self.A.ndim != self.B.ndim:
-            raise ValueError("A and B must both be LTI or both be LTV")
+            raise ValueError("A and B must both be LTI, both LTV or both per-instance")
+        if self.A.ndim == 4 and (self.A.shape[:2] != (self.x0.shape[0], N) or self.B.shape[:2] != (self.x0.shape[0], N)):
+            raise ValueError("per-instance A / B must be (batch, N, n, n) / (batch, N, n, m)")
         if self.Q.shape != (n, n) or self.QN.shape != (n, n) or self.R.shape != (m, m):
             raise ValueError("weight shape mismatch")
         if self.x0.ndim != 2 or self.x0.shape[1] != n:
             raise ValueError("x0 must be (batch, n)")
         for b in (self.lo, self.hi):
-            if b.shape not in ((n + m,), (N, n + m)):
-                raise ValueError("bounds must be (n+m,) or (N, n+m)")
+            if b.shape not in ((n + m,), (N, n + m), (self.x0.shape[0], N, n + m)):
+                raise ValueError("bounds must be (n+m,), (N, n+m) or (batch, N, n+m)")
+        if self.lo.shape != self.hi.shape:
+            raise ValueError("lo and hi must have the same shape")
+        if self.lo.ndim == 3 and not self.per_instance:
+            raise ValueError("per-instance bounds need per-instance dynamics")
+        if self.per_instance and self.unorm is not None:
+            raise ValueError("the thrust-magnitude bound is not available with per-instance dynamics")
         if np.any(np.isnan(self.lo)) or np.any(np.isnan(self.hi)) or np.any(self.lo > self.hi):
             raise ValueError("bounds must satisfy lo <= hi and contain no NaN")
         if self.q is not None and self.q.shape != (self.batch, self.L):
@@ -103,7 +125,7 @@ class Problem:
                 raise ValueError("unorm must be a scalar, or (N,) together with per-stage bounds")
             if np.any(np.isnan(un)) or np.any(un <= 0):
                 raise ValueError("unorm must be positive (inf = off)")
-            lo_u = np.atleast_2d(self.lo)[:, :m]           # (1 or N, m)
+            lo_u = np.atleast_2d(self.lo)[:, :m]           # (1 or N, m)   (per-instance problems were refused above)
             hi_u = np.atleast_2d(self.hi)[:, :m]
             fin = np.isfinite(np.broadcast_to(un, (lo_u.shape[0],)))
             if np.any(np.isfinite(lo_u[fin])) or np.any(np.isfinite(hi_u[fin])):
@@ -262,3 +284,20 @@ def random_ltv(N: int, n: int, m: int, batch: int, seed: int = SEED0,
         hi[soc, :m] = np.inf
     return Problem(N=N, A=A, B=B, Q=Q, R=R, QN=QN, x0=x0, lo=lo, hi=hi, q=q, unorm=unorm,
                    name=f"random_ltv_N{N}_n{n}_m{m}_b{batch}")
+
+
+def random_instances(N: int, n: int, m: int, batch: int, seed: int = SEED0, with_q: bool = True,
+                     instance_bounds: bool = True) -> Problem:
+    """Per-instance time-varying dynamics (admm_problem.time_varying = 2): every QP is its own
+    perturbation of a common random LTV plant, with its own per-stage box (instance_bounds) and linear term --
+    the QP class a batched successive-convexification loop produces."""
+    base = random_ltv(N, n, m, batch, seed, with_q=with_q)
+    rng = np.random.default_rng(seed + 7)
+    A = base.A[None] + 0.05 * rng.standard_normal((batch, N, n, n)) / np.sqrt(n)
+    B = base.B[None] + 0.05 * rng.standard_normal((batch, N, n, m))
+    lo, hi = base.lo, base.hi
+    if instance_bounds:
+        wid = rng.uniform(0.7, 1.3, (batch, N, n + m))
+        lo = base.lo[None] * wid
+        hi = base.hi[None] * rng.uniform(0.7, 1.3, (batch, N, n + m))
+    return dataclasses.replace(base, A=A, B=B, lo=lo, hi=hi, name=f"random_instances_N{N}_n{n}_m{m}_b{batch}")

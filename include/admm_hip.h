@@ -46,14 +46,19 @@ typedef enum admm_status {
 /* minimise  1/2 sum_k [u_k' R u_k + x_{k+1}' Q_{k+1} x_{k+1}] + q' w
  * s.t.      x_{k+1} = A_k x_k + B_k u_k,  x_0 given,   lo <= w <= hi   [and/or ||u_k||_2 <= unorm_k]
  * Dynamics, weights and the box are shared by the whole batch; x0 and q are
- * per instance. */
+ * per instance.  (time_varying = 2 / stage_bounds = 2: dynamics / box per instance as well; weights stay shared.) */
 typedef struct admm_problem {
   int32_t N;              /* horizon (stages) */
   int32_t n;              /* state dimension */
   int32_t m;              /* control dimension */
   int32_t batch;          /* number of independent QPs */
-  int32_t time_varying;   /* 0: A is n*n, B is n*m;  1: A is n*n*N, B is n*m*N */
-  int32_t stage_bounds;   /* 0: lo/hi are (m+n);     1: lo/hi are (m+n)*N */
+  int32_t time_varying;   /* 0: A is n*n, B is n*m;  1: A is n*n*N, B is n*m*N;
+                             2: PER-INSTANCE dynamics, A is n*n*N*batch, B is n*m*N*batch (QP b's stages are contiguous):
+                                the KKT system of every QP is factored on the device and the sweeps stream their stage
+                                operators from HBM per QP (the (n, m) pairs of csrc/admm_pinst.hip; no
+                                thrust-magnitude bound, precision_mode FP64 only) */
+  int32_t stage_bounds;   /* 0: lo/hi are (m+n);     1: lo/hi are (m+n)*N;   2 (with time_varying = 2 only): per
+                             instance, lo/hi are (m+n)*N*batch */
   const double* A;
   const double* B;
   const double* Q;        /* n*n symmetric PSD */

@@ -50,6 +50,9 @@ def solve(p: pkg.Problem, rho=0.1, alpha=1.0, eps_abs=1e-6, eps_rel=1e-6, max_it
           check_interval=10, z0=None, y0=None, stop=True, nthreads=0,
           adapt_interval=0, adapt_max=16, adapt_mu=10.0, adapt_tau=2.0):
     """Returns dict(w, z, y, iters_run, iters, status, r, s, rho, rho_updates)."""
+    if p.per_instance:
+        return _solve_per_instance(p, rho=rho, alpha=alpha, eps_abs=eps_abs, eps_rel=eps_rel, max_iter=max_iter,
+                                   check_interval=check_interval, z0=z0, y0=y0, stop=stop, adapt_interval=adapt_interval)
     lib = load()
     if nthreads == 0:
         # never more threads than QPs: idle OpenMP threads spin at every barrier, and on a box whose CPU
@@ -78,6 +81,37 @@ def solve(p: pkg.Problem, rho=0.1, alpha=1.0, eps_abs=1e-6, eps_rel=1e-6, max_it
         raise RuntimeError("oracle_solve failed (bad input or S_k not SPD)")
     return dict(w=w, z=z, y=y, iters_run=int(run.value), iters=iters, status=status, r=r, s=s,
                 rho=float(rho_out.value), rho_updates=int(upd.value))
+
+
+def _one_instance(p: pkg.Problem, b: int) -> pkg.Problem:
+    """QP b of a per-instance problem as an ordinary one-QP problem with time-varying dynamics and per-stage bounds."""
+    import dataclasses
+    lo, hi = (p.lo[b], p.hi[b]) if p.per_instance_bounds else (p.lo, p.hi)
+    return dataclasses.replace(p, A=np.ascontiguousarray(p.A[b]), B=np.ascontiguousarray(p.B[b]), lo=lo, hi=hi,
+                               x0=p.x0[b:b + 1].copy(), q=None if p.q is None else p.q[b:b + 1].copy())
+
+
+def _solve_per_instance(p, z0=None, y0=None, stop=True, adapt_interval=0, **kw):
+    """Per-instance dynamics (admm_problem.time_varying = 2): the QPs share nothing, so the oracle for this class IS the
+    one-QP oracle above applied QP by QP -- first with the stopping rule (per-QP first-converged iterations), then, as
+    the batch loop of DESIGN.md §2.5 prescribes, for the number of iterations the slowest QP needed."""
+    if adapt_interval:
+        raise NotImplementedError("the oracle for per-instance dynamics has no batch-level adaptive rho")
+    B, L = p.batch, p.L
+    subs = [_one_instance(p, b) for b in range(B)]
+    st0 = lambda a, b: None if a is None else np.asarray(a, np.float64).reshape(B, L)[b:b + 1]
+    first = [solve(subs[b], z0=st0(z0, b), y0=st0(y0, b), stop=True, nthreads=1, **kw) for b in range(B)] if stop else None
+    run = max(f["iters_run"] for f in first) if stop else kw["max_iter"]
+    kw2 = dict(kw, max_iter=run)
+    fin = [solve(subs[b], z0=st0(z0, b), y0=st0(y0, b), stop=False, nthreads=1, **kw2) for b in range(B)]
+    cat = lambda k: np.concatenate([f[k] for f in fin])
+    out = dict(w=cat("w"), z=cat("z"), y=cat("y"), iters_run=run, r=cat("r"), s=cat("s"), rho=kw["rho"], rho_updates=0)
+    src = first if stop else fin
+    out["iters"] = np.concatenate([f["iters"] for f in src]).astype(np.int32)
+    out["status"] = np.concatenate([f["status"] for f in src]).astype(np.int32)
+    if stop:                       # a QP that never met the rule reports max_iter, as in the batched loop
+        out["iters"] = np.where(out["status"] == 1, out["iters"], kw["max_iter"]).astype(np.int32)
+    return out
 
 
 def factor(p: pkg.Problem, rho: float):

@@ -1,0 +1,103 @@
+"""Per-instance dynamics (admm_problem.time_varying = 2, stage_bounds = 2): every QP has its own
+A_k, B_k and box; the KKT factor is computed on the device.  HIP path through the C ABI against the C oracle applied
+QP by QP (oracle_c._solve_per_instance).  Tolerance 1e-10 on fp64 iterates.  PARITY UNPINNED."""
+import dataclasses
+
+import numpy as np
+import pytest
+
+import admm_library_amd as pkg
+import oracle_c as oc
+from admm_library_amd import _abi
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-10
+
+CASES = [
+    dict(N=25, n=6, m=3, batch=70, seed=3),                                   # the SCvx model's shape, two waves
+    dict(N=25, n=6, m=3, batch=9, seed=4, instance_bounds=False),             # box shared by the batch
+    dict(N=40, n=2, m=1, batch=5, seed=5, with_q=False),
+    dict(N=12, n=4, m=2, batch=130, seed=6),
+    dict(N=7, n=3, m=2, batch=3, seed=7),
+    dict(N=1, n=6, m=3, batch=2, seed=8),
+]
+
+
+def _close(got, ref):
+    return all(np.abs(a - ref[k]).max() <= TOL * max(1.0, np.abs(ref[k]).max()) for a, k in zip(got, ("w", "z", "y")))
+
+
+@pytest.mark.parametrize("alpha", [1.0, 1.5])
+@pytest.mark.parametrize("idx", range(len(CASES)))
+def test_iterates_match_the_oracle(gpu, idx, alpha):
+    p = pkg.random_instances(**CASES[idx])
+    with pkg.Solver(p, pkg.Options(rho=0.3, alpha=alpha)) as s:
+        assert s.geometry()["segments"] == 1
+        done = 0
+        for upto in (1, 2, 3, 10, 40):
+            s.run(upto - done, residual_every=2)
+            done = upto
+            ref = oc.solve(p, rho=0.3, alpha=alpha, max_iter=upto, stop=False)
+            assert _close(s.get(), ref), upto
+
+
+def test_factor_kernel_matches_the_oracle_factor(gpu):
+    """One x-update from a random (z, y): w = the oracle's Riccati solve of every QP with ITS dynamics."""
+    import admm_ref as ar
+    p = pkg.random_instances(N=18, n=6, m=3, batch=11, seed=12)
+    rng = np.random.default_rng(1)
+    z, y = rng.standard_normal((p.batch, p.L)), rng.standard_normal((p.batch, p.L))
+    with pkg.Solver(p, pkg.Options(rho=0.7)) as s:
+        s.set_state(z=z, y=y)
+        s.step_x()
+        w = s.get()[0]
+    for b in range(p.batch):
+        f = ar.factor(p.A[b], p.B[b], p.Q, p.R, p.QN, 0.7, p.N)
+        g = -0.7 * (z[b] - y[b]) + p.q[b]
+        w_ref = ar.x_update(f, g[None], p.x0[b:b + 1])[0]
+        assert np.abs(w[b] - w_ref).max() <= 1e-11 * max(1.0, np.abs(w_ref).max())
+
+
+def test_solve_set_rho_update_problem(gpu):
+    p = pkg.random_instances(N=20, n=6, m=3, batch=66, seed=21)
+    kw = dict(rho=0.3, eps_abs=1e-7, eps_rel=1e-7, max_iter=3000, check_interval=10)
+    ref = oc.solve(p, **kw)
+    with pkg.Solver(p, pkg.Options(**kw)) as s:
+        info = s.solve()
+        assert int(info.iters_run) == ref["iters_run"]
+        np.testing.assert_array_equal(info.status, ref["status"])
+        assert (np.abs(info.iters - ref["iters"]) <= 10).all()
+        assert _close(s.get(), ref)
+        # a rho change refactors every QP on the device; the scaled dual is rescaled
+        s.set_rho(0.9)
+        s.iterate(7)
+        got = s.get()
+        z0, y0 = ref["z"], ref["y"] * (0.3 / 0.9)
+        ref2 = oc.solve(p, rho=0.9, max_iter=7, stop=False, z0=z0, y0=y0)
+        assert _close(got, ref2)
+        # new dynamics / bounds / x0 / q on the same handle = a fresh handle
+        p2 = pkg.random_instances(N=20, n=6, m=3, batch=66, seed=22)
+        s.update_problem(p2)
+        s.set_state(z=np.zeros((66, p2.L)), y=np.zeros((66, p2.L)))
+        s.iterate(12)
+        assert _close(s.get(), oc.solve(p2, rho=0.9, max_iter=12, stop=False))
+
+
+def test_validation_and_unsupported(gpu):
+    p = pkg.random_instances(N=10, n=6, m=3, batch=4, seed=1)
+    inv = {v: k for k, v in _abi.STATUS_NAMES.items()}
+    bad = dataclasses.replace(p, A=p.A.copy())
+    bad.A[2, 3, 1, 1] = np.nan
+    with pytest.raises(ValueError):
+        pkg.Solver(bad, pkg.Options(rho=0.3))
+    with pytest.raises(pkg.AdmmError) as e:
+        pkg.Solver(pkg.random_instances(N=10, n=5, m=3, batch=4, seed=1), pkg.Options(rho=0.3))       # no kernel for (5, 3)
+    assert e.value.code == inv["ADMM_ERR_UNSUPPORTED"]
+    with pytest.raises(pkg.AdmmError) as e:
+        pkg.Solver(p, pkg.Options(rho=0.3, precision_mode=_abi.PRECISION_MIXED))
+    assert e.value.code == inv["ADMM_ERR_UNSUPPORTED"]
+    # an indefinite R makes S_k indefinite for rho small: the device factorisation reports it
+    ind = dataclasses.replace(p, R=-0.5 * np.eye(3))
+    with pytest.raises(pkg.AdmmError) as e:
+        pkg.Solver(ind, pkg.Options(rho=0.01))
+    assert e.value.code == inv["ADMM_ERR_NUMERIC"]
