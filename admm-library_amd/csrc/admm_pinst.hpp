@@ -187,23 +187,52 @@ __global__ __launch_bounds__(PI_THREADS) void pfactor_kernel(
   if (bad && real) atomicOr(fail, 1);
 }
 
-// bounds of stacked row (k, r): per instance (PB) or shared
-template <bool PB>
-__device__ __forceinline__ void pi_bounds(const double* lo, const double* hi, int k, int r, int nb, size_t P_, int col,
-                                          double& l, double& h) {
-  if (PB) {
-    const size_t o = ((size_t)k * nb + r) * P_ + col;
-    l = lo[o];
-    h = hi[o];
-  } else {
-    l = lo[(size_t)k * nb + r];
-    h = hi[(size_t)k * nb + r];
+// ---------------------------------------------------------------------------
+// Stage operands of one QP, fetched as ONE batch of independent loads (the first version read each operand where it
+// was used: ~100 dependent round trips per stage, 18-30 us per stage; batched: one round trip).  The sweeps keep TWO of
+// these in registers and ping-pong: the loads of stage k -+ 1 are in flight while stage k is computed.
+// ---------------------------------------------------------------------------
+template <int NX, int NU, bool BACKWARD, bool HASQ, bool TWO /* second state array (z, y form) */, bool PB, bool BOUNDS, bool DIN>
+struct PiStage {
+  static constexpr int NB = NX + NU;
+  double A[NX * NX], B[NX * NU], K[NU * NX];
+  double S[BACKWARD ? NU * NU : 1];
+  double s0[NB], s1[TWO ? NB : 1], q[HASQ ? NB : 1], lo[BOUNDS ? NB : 1], hi[BOUNDS ? NB : 1], d[DIN ? NU : 1];
+  __device__ __forceinline__ void load(int k, const double* Ad, const double* Bd, const double* Kd, const double* Sd,
+                                       const double* st0, const double* st1, const double* qd, const double* lod,
+                                       const double* hid, const double* dd, size_t P_, int col) {
+#pragma unroll
+    for (int e = 0; e < NX * NX; ++e) A[e] = Ad[((size_t)k * NX * NX + e) * P_ + col];
+#pragma unroll
+    for (int e = 0; e < NX * NU; ++e) B[e] = Bd[((size_t)k * NX * NU + e) * P_ + col];
+#pragma unroll
+    for (int e = 0; e < NU * NX; ++e) K[e] = Kd[((size_t)k * NU * NX + e) * P_ + col];
+    if (BACKWARD) {
+#pragma unroll
+      for (int e = 0; e < NU * NU; ++e) S[e] = Sd[((size_t)k * NU * NU + e) * P_ + col];
+    }
+#pragma unroll
+    for (int r = 0; r < NB; ++r) {
+      const size_t o = ((size_t)k * NB + r) * P_ + col;
+      s0[r] = st0[o];
+      if (TWO) s1[r] = st1[o];
+      if (HASQ) q[r] = qd[o];
+      if (BOUNDS) {
+        if (PB) { lo[r] = lod[o]; hi[r] = hid[o]; }
+        else    { lo[r] = lod[(size_t)k * NB + r]; hi[r] = hid[(size_t)k * NB + r]; }
+      }
+    }
+    if (DIN) {
+#pragma unroll
+      for (int j = 0; j < NU; ++j) d[j] = dd[((size_t)k * NU + j) * P_ + col];
+    }
   }
-}
+};
 
 // ---------------------------------------------------------------------------
 // Backward sweep (as xb_kernel, one segment = the whole horizon):
 //     g = q - rho (z - y);  p = g^x + t;  h = B'p + g^u;  d_k = Si h -> dbuf;  t = A'p - K'h
+// A, B are column-major per stage: A[i][l] = A[l * NX + i], B[i][j] = B[j * NX + i]; K row-major [j][i].
 // ---------------------------------------------------------------------------
 template <int NX, int NU, bool HASQ, bool VFORM, bool PB>
 __global__ __launch_bounds__(PI_THREADS) void pxb_kernel(
@@ -212,57 +241,63 @@ __global__ __launch_bounds__(PI_THREADS) void pxb_kernel(
     const double* __restrict__ Sd, const double* __restrict__ lo, const double* __restrict__ hi,
     double* __restrict__ dbuf, double rho, int N, int pitch) {
   constexpr int NB = NX + NU;
+  typedef PiStage<NX, NU, true, HASQ, !VFORM, PB, VFORM, false> Stage;
   const int col = blockIdx.x * PI_THREADS + threadIdx.x;
   if (col >= pitch) return;
   const size_t P_ = (size_t)pitch;
   double t[NX];
 #pragma unroll
   for (int i = 0; i < NX; ++i) t[i] = 0.0;
-  for (int k = N - 1; k >= 0; --k) {
+  auto body = [&](const Stage& s, int k) {
     double g[NB];
 #pragma unroll
     for (int r = 0; r < NB; ++r) {
-      const size_t o = ((size_t)k * NB + r) * P_ + col;
-      double zz = z[o], yy;
+      double zz = s.s0[r], yy;
       if (VFORM) {
-        double l, h;
-        pi_bounds<PB>(lo, hi, k, r, NB, P_, col, l, h);
-        const double v = zz;
-        zz = fmin(fmax(v, l), h);
-        yy = v - zz;
+        zz = fmin(fmax(s.s0[r], s.lo[r]), s.hi[r]);
+        yy = s.s0[r] - zz;
       } else {
-        yy = y[o];
+        yy = s.s1[r];
       }
       g[r] = -rho * (zz - yy);
-      if (HASQ) g[r] += q[o];
+      if (HASQ) g[r] += s.q[r];
     }
-    double p[NX], h[NU], d[NU];
+    double p[NX], h[NU];
 #pragma unroll
     for (int i = 0; i < NX; ++i) p[i] = g[NU + i] + t[i];
 #pragma unroll
     for (int j = 0; j < NU; ++j) {
       double a = g[j];
 #pragma unroll
-      for (int i = 0; i < NX; ++i) a = fma(Bd[((size_t)k * NX * NU + j * NX + i) * P_ + col], p[i], a);
+      for (int i = 0; i < NX; ++i) a = fma(s.B[j * NX + i], p[i], a);
       h[j] = a;
     }
 #pragma unroll
     for (int j = 0; j < NU; ++j) {
       double a = 0.0;
 #pragma unroll
-      for (int l = 0; l < NU; ++l) a = fma(Sd[((size_t)k * NU * NU + j * NU + l) * P_ + col], h[l], a);
-      d[j] = a;
+      for (int l = 0; l < NU; ++l) a = fma(s.S[j * NU + l], h[l], a);
       dbuf[((size_t)k * NU + j) * P_ + col] = a;
     }
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
       double a = 0.0;
 #pragma unroll
-      for (int l = 0; l < NX; ++l) a = fma(Ad[((size_t)k * NX * NX + i * NX + l) * P_ + col], p[l], a);
+      for (int l = 0; l < NX; ++l) a = fma(s.A[i * NX + l], p[l], a);          // A'p: A[l][i] = A[i * NX + l]
 #pragma unroll
-      for (int j = 0; j < NU; ++j) a = fma(-Kd[((size_t)k * NU * NX + j * NX + i) * P_ + col], h[j], a);
+      for (int j = 0; j < NU; ++j) a = fma(-s.K[j * NX + i], h[j], a);
       t[i] = a;
     }
+  };
+  const double* st0 = z;
+  Stage sa, sb;
+  sa.load(N - 1, Ad, Bd, Kd, Sd, st0, y, q, lo, hi, nullptr, P_, col);
+  for (int k = N - 1; k >= 0; k -= 2) {
+    sb.load(k - 1 >= 0 ? k - 1 : 0, Ad, Bd, Kd, Sd, st0, y, q, lo, hi, nullptr, P_, col);
+    body(sa, k);
+    if (k - 1 < 0) break;
+    sa.load(k - 2 >= 0 ? k - 2 : 0, Ad, Bd, Kd, Sd, st0, y, q, lo, hi, nullptr, P_, col);
+    body(sb, k - 1);
   }
 }
 
@@ -278,6 +313,9 @@ __global__ __launch_bounds__(PI_THREADS) void pxfz_kernel(
     const double* __restrict__ hi, const double* __restrict__ zin, const double* __restrict__ yin,
     double* __restrict__ v, double* __restrict__ w, double* __restrict__ part, double alpha, int N, int pitch) {
   constexpr int NB = NX + NU;
+  constexpr bool NEEDZ = RESID || RELAX;
+  // state operands: VIN: s0 = v;  else s0 = y and (NEEDZ) s1 = z
+  typedef PiStage<NX, NU, false, false, ZUP && !VIN && NEEDZ, PB, ZUP, true> Stage;
   const int col = blockIdx.x * PI_THREADS + threadIdx.x;
   if (col >= pitch) return;
   const size_t P_ = (size_t)pitch;
@@ -285,22 +323,22 @@ __global__ __launch_bounds__(PI_THREADS) void pxfz_kernel(
 #pragma unroll
   for (int i = 0; i < NX; ++i) x[i] = x0[(size_t)i * P_ + col];
   double a_r = 0, a_s = 0, a_w = 0, a_z = 0, a_y = 0;
-  for (int k = 0; k < N; ++k) {
+  auto body = [&](const Stage& s, int k) {
     double wv[NB];
 #pragma unroll
     for (int j = 0; j < NU; ++j) {
-      double a = dbuf[((size_t)k * NU + j) * P_ + col];
+      double a = s.d[j];
 #pragma unroll
-      for (int i = 0; i < NX; ++i) a = fma(Kd[((size_t)k * NU * NX + j * NX + i) * P_ + col], x[i], a);
+      for (int i = 0; i < NX; ++i) a = fma(s.K[j * NX + i], x[i], a);
       wv[j] = -a;
     }
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
       double a = 0.0;
 #pragma unroll
-      for (int l = 0; l < NX; ++l) a = fma(Ad[((size_t)k * NX * NX + l * NX + i) * P_ + col], x[l], a);
+      for (int l = 0; l < NX; ++l) a = fma(s.A[l * NX + i], x[l], a);
 #pragma unroll
-      for (int j = 0; j < NU; ++j) a = fma(Bd[((size_t)k * NX * NU + j * NX + i) * P_ + col], wv[j], a);
+      for (int j = 0; j < NU; ++j) a = fma(s.B[j * NX + i], wv[j], a);
       wv[NU + i] = a;
     }
 #pragma unroll
@@ -310,23 +348,20 @@ __global__ __launch_bounds__(PI_THREADS) void pxfz_kernel(
       const size_t o = ((size_t)k * NB + r) * P_ + col;
       if (STOREW) w[o] = wv[r];
       if (ZUP) {
-        double l, h;
-        pi_bounds<PB>(lo, hi, k, r, NB, P_, col, l, h);
         double zo, yo;
         if (VIN) {
-          const double c0 = v[o];
-          zo = fmin(fmax(c0, l), h);
-          yo = c0 - zo;
+          zo = fmin(fmax(s.s0[r], s.lo[r]), s.hi[r]);
+          yo = s.s0[r] - zo;
         } else {
-          yo = yin[o];
-          zo = (RESID || RELAX) ? zin[o] : 0.0;
+          yo = s.s0[r];
+          zo = NEEDZ ? s.s1[NEEDZ ? r : 0] : 0.0;
         }
         double wh = wv[r];
         if (RELAX) wh = fma(alpha, wv[r], (1.0 - alpha) * zo);
         const double vn = wh + yo;
         v[o] = vn;
         if (RESID) {
-          const double zn = fmin(fmax(vn, l), h);
+          const double zn = fmin(fmax(vn, s.lo[r]), s.hi[r]);
           const double yn = vn - zn;
           const double dr = wv[r] - zn, ds = zn - zo;
           a_r = fma(dr, dr, a_r);
@@ -337,6 +372,16 @@ __global__ __launch_bounds__(PI_THREADS) void pxfz_kernel(
         }
       }
     }
+  };
+  const double* st0 = ZUP ? (VIN ? v : yin) : dbuf;      // (!ZUP: the state operands are unused; any valid array)
+  Stage sa, sb;
+  sa.load(0, Ad, Bd, Kd, nullptr, st0, zin, nullptr, lo, hi, dbuf, P_, col);
+  for (int k = 0; k < N; k += 2) {
+    sb.load(k + 1 < N ? k + 1 : N - 1, Ad, Bd, Kd, nullptr, st0, zin, nullptr, lo, hi, dbuf, P_, col);
+    body(sa, k);
+    if (k + 1 >= N) break;
+    sa.load(k + 2 < N ? k + 2 : N - 1, Ad, Bd, Kd, nullptr, st0, zin, nullptr, lo, hi, dbuf, P_, col);
+    body(sb, k + 1);
   }
   if (ZUP && RESID) {
     part[0 * P_ + col] = a_r;

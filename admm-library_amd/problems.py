@@ -301,3 +301,24 @@ def random_instances(N: int, n: int, m: int, batch: int, seed: int = SEED0, with
         lo = base.lo[None] * wid
         hi = base.hi[None] * rng.uniform(0.7, 1.3, (batch, N, n + m))
     return dataclasses.replace(base, A=A, B=B, lo=lo, hi=hi, name=f"random_instances_N{N}_n{n}_m{m}_b{batch}")
+
+
+def cw_rendezvous_instances(N: int = 200, batch: int = 64, seed0: int = SEED0, u_max: float = 0.2,
+                            spread: float = 0.05) -> Problem:
+    """cw_rendezvous with PER-INSTANCE dynamics: QP i flies about its own reference orbit (mean motion scaled by
+    1 + spread * U(-1, 1), so its Clohessy-Wiltshire matrices are those of a different time step) and has its own
+    input box -- the shape of a Monte-Carlo / batched successive-convexification workload."""
+    base = cw_rendezvous(N=N, batch=batch, seed0=seed0, u_max=u_max)
+    dt = 2.0 * np.pi / N
+    A = np.empty((batch, N, 6, 6))
+    B = np.empty((batch, N, 6, 3))
+    lo = np.empty((batch, N, 9))
+    hi = np.empty((batch, N, 9))
+    for i in range(batch):
+        rng = np.random.default_rng(seed0 + 100003 * (i + 1))
+        Ai, Bi = cw_matrices(dt * (1.0 + spread * rng.uniform(-1.0, 1.0)))
+        A[i], B[i] = Ai[None], Bi[None]
+        um = u_max * (1.0 + spread * rng.uniform(-1.0, 1.0))
+        lo[i] = np.array([-um] * 3 + [-np.inf] * 6)[None]
+        hi[i] = np.array([um] * 3 + [np.inf] * 6)[None]
+    return dataclasses.replace(base, A=A, B=B, lo=lo, hi=hi, name=f"cw_rendezvous_instances_N{N}_b{batch}")

@@ -23,8 +23,10 @@ The QP of one outer iteration, in the correction (du, dx) about the reference (u
                max(u_lo - ub_k, -tr_u) <= du_k <= min(u_hi - ub_k, tr_u),   |dx| <= tr_x
 
 i.e. the hot path's QP with time-varying (A_k, B_k), per-stage bounds and the linear term
-q = (R ub_k, Q_{k+1} xb_{k+1}).  Dynamics are shared by the batch in the C ABI, so one outer loop
-drives ONE trajectory (batch = 1; DESIGN.md §7 lists per-instance dynamics as out of scope).
+q = (R ub_k, Q_{k+1} xb_{k+1}).  scvx() drives ONE trajectory (batch-shared dynamics, batch = 1);
+scvx_batch() drives MANY at once -- a Monte-Carlo set of initial conditions, say: every trajectory
+has its own linearisation, box and linear term, i.e. one QP batch with per-instance dynamics
+(admm_problem.time_varying = 2, stage_bounds = 2) per outer iteration.
 """
 from __future__ import annotations
 
@@ -62,12 +64,15 @@ def rk4_step(s: np.ndarray, u: np.ndarray, dt: float, substeps: int = 4, rc: flo
 
 
 def rollout(x0: np.ndarray, u: np.ndarray, dt: float, step=rk4_step) -> np.ndarray:
-    """States x_1..x_N (N, n) of the nonlinear dynamics from x0 under controls u (N, m)."""
-    xs = np.empty((u.shape[0], x0.shape[0]))
+    """States x_1..x_N (N, n) of the nonlinear dynamics from x0 under controls u (N, m); with a leading
+    batch axis on both ((B, n), (B, N, m)) the B trajectories are propagated together -> (B, N, n)."""
+    u = np.asarray(u, np.float64)
     s = np.asarray(x0, np.float64)
-    for k in range(u.shape[0]):
-        s = step(s, u[k], dt)
-        xs[k] = s
+    N = u.shape[-2]
+    xs = np.empty(u.shape[:-1] + (s.shape[-1],))
+    for k in range(N):
+        s = step(s, u[..., k, :], dt)
+        xs[..., k, :] = s
     return xs
 
 
@@ -75,16 +80,16 @@ def linearise(xprev: np.ndarray, u: np.ndarray, dt: float, step=rk4_step, eps: f
               ) -> Tuple[np.ndarray, np.ndarray]:
     """A_k = dF/dx, B_k = dF/du of the stage map F at (xprev_k, u_k), k = 0..N-1, by central
     differences (vectorised over stages and perturbation directions)."""
-    N, n = xprev.shape
-    m = u.shape[1]
-    A = np.empty((N, n, n))
-    B = np.empty((N, n, m))
+    lead, n = xprev.shape[:-1], xprev.shape[-1]          # (N,) or (B, N)
+    m = u.shape[-1]
+    A = np.empty(lead + (n, n))
+    B = np.empty(lead + (n, m))
     for j in range(n):
         d = np.zeros(n); d[j] = eps
-        A[:, :, j] = (step(xprev + d, u, dt) - step(xprev - d, u, dt)) / (2.0 * eps)
+        A[..., :, j] = (step(xprev + d, u, dt) - step(xprev - d, u, dt)) / (2.0 * eps)
     for j in range(m):
         d = np.zeros(m); d[j] = eps
-        B[:, :, j] = (step(xprev, u + d, dt) - step(xprev, u - d, dt)) / (2.0 * eps)
+        B[..., :, j] = (step(xprev, u + d, dt) - step(xprev, u - d, dt)) / (2.0 * eps)
     return A, B
 
 
@@ -99,11 +104,12 @@ class ScvxResult:
     history: List[dict]           # per outer iteration: cost, predicted / actual decrease, ratio, trust radius, |du|, ADMM iterations
 
 
-def trajectory_cost(x: np.ndarray, u: np.ndarray, Q, R, QN) -> float:
-    c = 0.5 * np.einsum("ki,ij,kj->", u, R, u)
-    c += 0.5 * np.einsum("ki,ij,kj->", x[:-1], Q, x[:-1])
-    c += 0.5 * x[-1] @ QN @ x[-1]
-    return float(c)
+def trajectory_cost(x: np.ndarray, u: np.ndarray, Q, R, QN):
+    """Nonlinear cost of one trajectory (float), or of B trajectories with a leading batch axis ((B,) array)."""
+    c = 0.5 * np.einsum("...ki,ij,...kj->...", u, R, u)
+    c = c + 0.5 * np.einsum("...ki,ij,...kj->...", x[..., :-1, :], Q, x[..., :-1, :])
+    c = c + 0.5 * np.einsum("...i,ij,...j->...", x[..., -1, :], QN, x[..., -1, :])
+    return float(c) if np.ndim(c) == 0 else c
 
 
 def correction_qp(xb: np.ndarray, ub: np.ndarray, x0: np.ndarray, dt: float, Q, R, QN, u_lo, u_hi,
@@ -209,3 +215,90 @@ def scvx(x0: np.ndarray, N: int, dt: float, Q, R, QN, u_lo, u_hi,
             break
     return ScvxResult(u=ub, x=xb, cost=J, outer_iterations=len(hist), accepted=accepted, converged=converged,
                       history=hist)
+
+
+def correction_qp_batch(xb: np.ndarray, ub: np.ndarray, x0: np.ndarray, dt: float, Q, R, QN, u_lo, u_hi,
+                        tr_u: np.ndarray, tr_x: np.ndarray, step=rk4_step) -> Problem:
+    """The correction QPs of B trajectories as ONE batch with per-instance dynamics, box and linear term
+    (xb (B, N, n), ub (B, N, m), x0 (B, n), trust radii (B,))."""
+    Bn, N, n = xb.shape
+    m = ub.shape[-1]
+    xprev = np.concatenate([x0[:, None, :], xb[:, :-1, :]], axis=1)
+    A, B = linearise(xprev, ub, dt, step)
+    q = np.empty((Bn, N, m + n))
+    q[..., :m] = ub @ R.T
+    q[:, :-1, m:] = xb[:, :-1, :] @ Q.T
+    q[:, -1, m:] = xb[:, -1, :] @ QN.T
+    lo = np.empty((Bn, N, m + n))
+    hi = np.empty((Bn, N, m + n))
+    lo[..., :m] = np.maximum(u_lo - ub, -tr_u[:, None, None])
+    hi[..., :m] = np.minimum(u_hi - ub, tr_u[:, None, None])
+    lo[..., m:] = -tr_x[:, None, None]
+    hi[..., m:] = tr_x[:, None, None]
+    return Problem(N=N, A=A, B=B, Q=np.asarray(Q, np.float64), R=np.asarray(R, np.float64),
+                   QN=np.asarray(QN, np.float64), x0=np.zeros((Bn, n)), lo=lo, hi=hi, q=q.reshape(Bn, -1),
+                   name=f"scvx_correction_batch{Bn}_N{N}")
+
+
+def scvx_batch(x0: np.ndarray, N: int, dt: float, Q, R, QN, u_lo, u_hi,
+               qp_solver: Optional[Callable[[Problem], Tuple[np.ndarray, int]]] = None,
+               tr_u: float = 0.1, tr_x: float = 20.0, max_outer: int = 20, tol: float = 1e-6,
+               rho_reject: float = 0.1, rho_expand: float = 0.7, step=rk4_step,
+               qp_options: Optional[dict] = None) -> List[ScvxResult]:
+    """scvx() for B initial conditions x0 (B, n) at once: the same trust-region loop per trajectory (own trust radii,
+    own accept / reject decisions, own stop), but ONE batched QP solve per outer iteration -- per-instance dynamics,
+    bounds and linear term (correction_qp_batch).  A trajectory that has stopped keeps its place in the batch with a
+    zero-width box (its correction is then exactly zero) until the last one stops."""
+    x0 = np.atleast_2d(np.asarray(x0, np.float64))
+    Bn = x0.shape[0]
+    Q, R, QN = (np.asarray(a, np.float64) for a in (Q, R, QN))
+    n, m = Q.shape[0], R.shape[0]
+    u_lo = np.broadcast_to(np.asarray(u_lo, np.float64), (m,))
+    u_hi = np.broadcast_to(np.asarray(u_hi, np.float64), (m,))
+    if qp_solver is None:
+        qp_solver = gpu_qp_solver(**(qp_options or dict(rho=0.5, eps_abs=1e-8, eps_rel=1e-8, max_iter=20000,
+                                                        check_interval=25)))
+    ub = np.zeros((Bn, N, m))
+    xb = rollout(x0, ub, dt, step)
+    J = trajectory_cost(xb, ub, Q, R, QN)
+    tru = np.full(Bn, float(tr_u))
+    trx = np.full(Bn, float(tr_x))
+    active = np.ones(Bn, bool)
+    converged = np.zeros(Bn, bool)
+    accepted = np.zeros(Bn, int)
+    hist: List[List[dict]] = [[] for _ in range(Bn)]
+    for it in range(1, max_outer + 1):
+        if not active.any():
+            break
+        p = correction_qp_batch(xb, ub, x0, dt, Q, R, QN, u_lo, u_hi, np.where(active, tru, 0.0), np.where(active, trx, 0.0), step)
+        z, admm_iters = qp_solver(p)
+        d = np.asarray(z, np.float64).reshape(Bn, N, m + n)
+        du, dx = d[..., :m], d[..., m:]
+        J_lin = trajectory_cost(xb + dx, ub + du, Q, R, QN)
+        u_new = np.clip(ub + du, u_lo, u_hi)
+        x_new = rollout(x0, u_new, dt, step)
+        J_new = trajectory_cost(x_new, u_new, Q, R, QN)
+        predicted, actual = J - J_lin, J - J_new
+        for b in np.flatnonzero(active):
+            ratio = actual[b] / predicted[b] if predicted[b] > 0 else -np.inf
+            step_norm = float(np.abs(du[b]).max())
+            rec = dict(iteration=it, cost=float(J[b]), cost_candidate=float(J_new[b]), predicted=float(predicted[b]),
+                       actual=float(actual[b]), ratio=float(ratio), tr_u=float(tru[b]), tr_x=float(trx[b]), du_max=step_norm,
+                       admm_iterations=admm_iters, accepted=False)
+            if predicted[b] <= tol * max(1.0, abs(J[b])):
+                hist[b].append(rec)
+                converged[b], active[b] = True, False
+                continue
+            if ratio >= rho_reject:
+                ub[b], xb[b], J[b] = u_new[b], x_new[b], J_new[b]
+                accepted[b] += 1
+                rec["accepted"] = True
+                if ratio >= rho_expand:
+                    tru[b], trx[b] = 2.0 * tru[b], 2.0 * trx[b]
+            else:
+                tru[b], trx[b] = 0.5 * tru[b], 0.5 * trx[b]
+            hist[b].append(rec)
+            if rec["accepted"] and step_norm <= tol:
+                converged[b], active[b] = True, False
+    return [ScvxResult(u=ub[b], x=xb[b], cost=float(J[b]), outer_iterations=len(hist[b]), accepted=int(accepted[b]),
+                       converged=bool(converged[b]), history=hist[b]) for b in range(Bn)]

@@ -67,3 +67,22 @@ def test_scvx_converges_with_the_oracle_as_qp_solver():
     xcw = sc.rollout(case.X0, ucw, case.DT)
     assert sc.trajectory_cost(xcw, ucw, case.Q, case.R, case.QN) > 5 * res.cost
     assert np.linalg.norm(xcw[-1, :3]) > 20 * np.linalg.norm(res.x[-1, :2])      # CW-only misses along-track by tens of km
+
+
+def test_batched_loop_equals_the_single_trajectory_loops():
+    """scvx_batch() (one QP batch with per-instance dynamics, bounds and linear term per outer iteration) against
+    scvx() run trajectory by trajectory, both with the CPU oracle as QP solver: same accept / reject decisions and
+    outer iteration counts, same controls up to the QP tolerance."""
+    rng = np.random.default_rng(3)
+    x0s = case.X0[None] * (1.0 + 0.05 * rng.standard_normal((2, 6)))
+    qp = case.oracle_qp_solver(**case.QP)
+    batch = sc.scvx_batch(x0s, case.N, case.DT, case.Q, case.R, case.QN, -case.U_MAX, case.U_MAX, qp_solver=qp, **case.SCVX)
+    for b in range(2):
+        one = sc.scvx(x0s[b], case.N, case.DT, case.Q, case.R, case.QN, -case.U_MAX, case.U_MAX, qp_solver=qp, **case.SCVX)
+        got = batch[b]
+        assert got.converged and one.converged
+        assert got.outer_iterations == one.outer_iterations and got.accepted == one.accepted
+        assert [h["accepted"] for h in got.history] == [h["accepted"] for h in one.history]
+        assert abs(got.cost - one.cost) <= 1e-6 * abs(one.cost)
+        assert np.abs(got.u - one.u).max() <= 1e-2
+        np.testing.assert_allclose(got.x, sc.rollout(x0s[b], got.u, case.DT), atol=1e-12)
