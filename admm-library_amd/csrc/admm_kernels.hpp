@@ -693,27 +693,36 @@ __global__ __launch_bounds__(256) void xscan_mfma_kernel(
 // HBM per stacked element: reads d (8 m/(n+m)), writes w (8 B).
 // ---------------------------------------------------------------------------
 template <int NX, int NU>
-__global__ __launch_bounds__(XB_THREADS) void xf_kernel(
+__global__ __launch_bounds__(XB_THREADS) ADMM_X_OCCUPANCY void xf_kernel(
     const double* __restrict__ dbuf, const double* __restrict__ tin, const double* __restrict__ xin,
-    const double* __restrict__ recF_, const int* __restrict__ seg_start_,
+    const double* __restrict__ recF, const int* __restrict__ seg_start_,
     double* __restrict__ w, int pitch, int nsplit, size_t split_stride) {
+  // Read-out (admm_get's w, admm_step_x, the unfused path): the rollout of xfz_kernel on the same LDS-staged records
+  // and buffer addressing, storing w instead of updating v.  (Round 1's version read every operand through the
+  // scalar unit: 165 us at configs[2] against xfz's 112 us for MORE traffic.)
   constexpr int NB = NX + NU;
   constexpr RecFLayout LF = rec_f_layout(NX, NU);
   constexpr int RF = LF.SIZE;
-  constexpr int O_PSI = LF.PSI, O_K = LF.K, O_A = LF.A, O_B = LF.B;
-  const int col = blockIdx.x * XB_THREADS + threadIdx.x;
+  constexpr int PF = prefetch_depth(NB);
+  constexpr int CH = stage_chunk(RF, PF);
+  __shared__ __attribute__((aligned(16))) double rec[CH * RF];
+  const int col_raw = blockIdx.x * XB_THREADS + threadIdx.x;
+  const int col = col_raw < pitch ? col_raw : pitch - 1;      // clamped lanes: loads only (see xb_kernel)
+  const unsigned lb_st = col_raw < pitch ? (unsigned)col * 8u : ROWVIEW_OOB;
   const int s = blockIdx.y;
-  if (col >= pitch) return;
   cint_p seg_start = as_const(seg_start_);
   const int k0 = seg_start[s], k1 = seg_start[s + 1];
   const size_t P = (size_t)pitch;
+  const unsigned lb = (unsigned)col * 8u;
+  const unsigned PB = (unsigned)pitch * 8u;
+  const RowView vw(w, (size_t)k0 * NB * P, (size_t)(k1 - k0) * NB * P * 8);
+  const RowView vd(dbuf, (size_t)k0 * NU * P, (size_t)(k1 - k0) * NU * P * 8);
   double t[NX], x[NX];
   {
     const size_t o = (size_t)s * NX * P + col;
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
-      // the scan may have been split over K (small batches, <= 8 slabs): partial sums, added in
-      // split order.  Unrolled so that every slab's loads are in flight together.
+      // the scan may have been split over K (small batches, <= 8 slabs): partial sums, added in split order
       double tp[8], xp[8];
 #pragma unroll
       for (int sp = 0; sp < 8; ++sp) {
@@ -731,49 +740,52 @@ __global__ __launch_bounds__(XB_THREADS) void xf_kernel(
       x[i] = xa;
     }
   }
-  double ld[NU];
-  {
-    const size_t d0 = (size_t)k0 * NU * P + col;
+  double ld[PF][NU];
 #pragma unroll
-    for (int j = 0; j < NU; ++j) ld[j] = dbuf[d0 + j * P];
+  for (int j = 0; j < PF; ++j) {
+    const int kj = (k0 + j < k1) ? k0 + j : k1 - 1;
+    const unsigned d0 = (unsigned)(kj - k0) * NU * PB;
+#pragma unroll
+    for (int jj = 0; jj < NU; ++jj) ld[j][jj] = vd.load(lb, d0 + jj * PB);
   }
-  for (int k = k0; k < k1; ++k) {
-    double d[NU];
+  for (int kc = k0; kc < k1; kc += CH) {
+    const int khi = (kc + CH - 1 < k1 - 1) ? kc + CH - 1 : k1 - 1;
+    __syncthreads();
+    stage_records<XB_THREADS>(rec, recF + (size_t)kc * RF, (khi - kc + 1) * RF, threadIdx.x);
+    __syncthreads();
+    for (int kb = kc; kb <= khi; kb += PF) {
 #pragma unroll
-    for (int j = 0; j < NU; ++j) d[j] = ld[j];
-    {
-      const int kn = (k + 1 < k1) ? k + 1 : k;
-      const size_t d0 = (size_t)kn * NU * P + col;
+      for (int j = 0; j < PF; ++j) {
+        const int k = kb + j;
+        if (k > khi) break;
+        const double* rf = rec + (k - kc) * RF;
+        double uacc[NU], xn[NX], uu[NU];
 #pragma unroll
-      for (int j = 0; j < NU; ++j) ld[j] = dbuf[d0 + j * P];
-    }
-    cdouble_p rf = as_const(recF_) + (size_t)k * RF;
-    double u[NU], xn[NX];
+        for (int jj = 0; jj < NU; ++jj) uacc[jj] = ld[j][jj];
+        {
+          const int kn = (k + PF < k1) ? k + PF : k1 - 1;
+          const unsigned d0 = (unsigned)(kn - k0) * NU * PB;
 #pragma unroll
-    for (int j = 0; j < NU; ++j) {
-      double a = d[j];
+          for (int jj = 0; jj < NU; ++jj) ld[j][jj] = vd.load(lb, d0 + jj * PB);
+        }
+        lds_matvec_acc<NU, NX, false>(rf + LF.PSI, t, uacc);    // d0 + Psi t_in
+        lds_matvec_acc<NU, NX, false>(rf + LF.K, x, uacc);      //      + K x
 #pragma unroll
-      for (int i = 0; i < NX; ++i) a = fma(rf[O_PSI + j * NX + i], t[i], a);
+        for (int jj = 0; jj < NU; ++jj) uu[jj] = -uacc[jj];
 #pragma unroll
-      for (int i = 0; i < NX; ++i) a = fma(rf[O_K + j * NX + i], x[i], a);
-      u[j] = -a;
-    }
+        for (int i = 0; i < NX; ++i) xn[i] = 0.0;
+        lds_matvec_acc<NX, NX, false>(rf + LF.A, x, xn);        // x+ = A x
+        lds_matvec_acc<NX, NU, false>(rf + LF.B, uu, xn);       //      + B u
+        const unsigned r0 = (unsigned)(k - k0) * NB * PB;
 #pragma unroll
-    for (int i = 0; i < NX; ++i) {
-      double a = 0.0;
+        for (int jj = 0; jj < NU; ++jj) vw.store(uu[jj], lb_st, r0 + jj * PB);
 #pragma unroll
-      for (int l = 0; l < NX; ++l) a = fma(rf[O_A + i * NX + l], x[l], a);
-#pragma unroll
-      for (int j = 0; j < NU; ++j) a = fma(rf[O_B + i * NU + j], u[j], a);
-      xn[i] = a;
-    }
-    const size_t r0 = (size_t)k * NB * P + col;
-#pragma unroll
-    for (int j = 0; j < NU; ++j) w[r0 + j * P] = u[j];
-#pragma unroll
-    for (int i = 0; i < NX; ++i) {
-      x[i] = xn[i];
-      w[r0 + (NU + i) * P] = xn[i];
+        for (int i = 0; i < NX; ++i) {
+          x[i] = xn[i];
+          vw.store(xn[i], lb_st, r0 + (NU + i) * PB);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
   }
 }
@@ -1033,7 +1045,25 @@ static __global__ __launch_bounds__(Z_THREADS) void v_to_zy_kernel(
   const int r_end = (r_begin + zrows < L) ? r_begin + zrows : L;
   cdouble_p lo = as_const(lo_);
   cdouble_p hi = as_const(hi_);
-  for (int r = r_begin; r < r_end; ++r) {
+  constexpr int U = 4;                 // rows in flight per lane (a row-at-a-time loop ran at 3.5 TB/s: 250 us at configs[2])
+  int r = r_begin;
+  for (; r + U <= r_end; r += U) {
+    double2 vv[U];
+#pragma unroll
+    for (int i = 0; i < U; ++i) vv[i] = *reinterpret_cast<const double2*>(v + (size_t)(r + i) * pitch + col);
+#pragma unroll
+    for (int i = 0; i < U; ++i) {
+      const size_t o = (size_t)(r + i) * pitch + col;
+      double2 zz, yy;
+      zz.x = fmin(fmax(vv[i].x, lo[r + i]), hi[r + i]);
+      zz.y = fmin(fmax(vv[i].y, lo[r + i]), hi[r + i]);
+      yy.x = vv[i].x - zz.x;
+      yy.y = vv[i].y - zz.y;
+      *reinterpret_cast<double2*>(z + o) = zz;
+      *reinterpret_cast<double2*>(y + o) = yy;
+    }
+  }
+  for (; r < r_end; ++r) {
     const size_t o = (size_t)r * pitch + col;
     const double2 vv = *reinterpret_cast<const double2*>(v + o);
     double2 zz, yy;
