@@ -95,13 +95,25 @@ void parse_problem(const mxArray* P, admm_problem& p) {
   const mwSize* bd = mxGetDimensions(B);
   p.m = static_cast<int32_t>(bd[1]);
   p.batch = static_cast<int32_t>(mxGetN(x0));
-  p.time_varying = mxGetNumberOfDimensions(A) == 3 ? 1 : 0;
-  p.stage_bounds = mxGetN(lo) > 1 ? 1 : 0;
+  // per_instance (logical field, optional): A is n x n x N x batch, B n x m x N x batch (time_varying = 2); with
+  // per_instance_bounds lo / hi are (m+n) x N x batch (stage_bounds = 2).  Explicit flags, because MATLAB drops
+  // trailing singleton dimensions (an n x n x N x 1 array IS 3-D).
+  const mxArray* pi = field(P, "per_instance", false);
+  const mxArray* pib = field(P, "per_instance_bounds", false);
+  const bool per_inst = pi && !mxIsEmpty(pi) && mxGetScalar(pi) != 0.0;
+  const bool per_inst_b = per_inst && pib && !mxIsEmpty(pib) && mxGetScalar(pib) != 0.0;
+  p.time_varying = per_inst ? 2 : (mxGetNumberOfDimensions(A) == 3 ? 1 : 0);
+  p.stage_bounds = per_inst_b ? 2 : (mxGetN(lo) > 1 ? 1 : 0);
   if (static_cast<int32_t>(mxGetM(x0)) != p.n) fail("admm:input", "x0 must be n x batch");
   if (static_cast<int32_t>(mxGetM(lo)) != p.n + p.m || static_cast<int32_t>(mxGetM(hi)) != p.n + p.m)
     fail("admm:input", "lo/hi must have m+n rows (u block, then x block)");
-  if (p.stage_bounds && static_cast<int32_t>(mxGetN(lo)) != p.N) fail("admm:input", "per-stage bounds need N columns");
-  if (p.time_varying && static_cast<int32_t>(mxGetDimensions(A)[2]) != p.N) fail("admm:input", "time-varying A needs N pages");
+  if (p.stage_bounds == 1 && static_cast<int32_t>(mxGetN(lo)) != p.N) fail("admm:input", "per-stage bounds need N columns");
+  if (p.stage_bounds == 2 && mxGetNumberOfElements(lo) != static_cast<size_t>(p.n + p.m) * p.N * p.batch)
+    fail("admm:input", "per-instance bounds must be (m+n) x N x batch");
+  if (p.time_varying == 1 && static_cast<int32_t>(mxGetDimensions(A)[2]) != p.N) fail("admm:input", "time-varying A needs N pages");
+  if (p.time_varying == 2 && (mxGetNumberOfElements(A) != static_cast<size_t>(p.n) * p.n * p.N * p.batch ||
+                              mxGetNumberOfElements(B) != static_cast<size_t>(p.n) * p.m * p.N * p.batch))
+    fail("admm:input", "per-instance A / B must be n x n x N x batch / n x m x N x batch");
   p.A = dbl(A, "A"); p.B = dbl(B, "B");
   p.Q = dbl(field(P, "Q", true), "Q"); p.R = dbl(field(P, "R", true), "R"); p.QN = dbl(field(P, "QN", true), "QN");
   p.x0 = dbl(x0, "x0"); p.lo = dbl(lo, "lo"); p.hi = dbl(hi, "hi");
