@@ -43,6 +43,7 @@ struct admm_handle {
   int scan_split = 1;            // split-K factor of the MFMA scan (small batches)
   int device = 0;
   int num_cus = 256;             // hipDeviceProp_t::multiProcessorCount of the handle's device
+  bool xfree = false;            // every state row is unbounded at every stage (XFREE kernel forms, see xfze_kernel)
   bool auto_segments = false;    // the segment count was chosen by admm_setup (and is guarded by scan_growth)
   bool has_q = false;
   bool has_soc = false;          // some stage has a finite thrust-magnitude bound
@@ -120,7 +121,7 @@ using admm::Z_THREADS;
 admm::XLaunch xlaunch_of(const admm_handle* h) {
   admm::XLaunch l{};
   l.stream = h->stream;
-  l.n = h->n; l.m = h->m; l.S = h->S; l.pitch = h->pitch; l.batch = h->batch;
+  l.n = h->n; l.m = h->m; l.S = h->S; l.pitch = h->pitch; l.batch = h->batch; l.xfree = h->xfree;
   l.has_q = h->has_q;
   l.has_soc = h->has_soc;
   l.rho = h->opt.rho; l.alpha = h->opt.alpha;
@@ -592,6 +593,13 @@ void keep_shared(admm_handle* h, const admm_problem* p) {
   if (p->unorm) h->pun.assign(p->unorm, p->unorm + (p->stage_bounds ? p->N : 1));
   h->time_varying = p->time_varying;
   h->stage_bounds = p->stage_bounds;
+  // every STATE row unbounded at EVERY stage: its dual is identically zero, which lets the non-residual kernel forms
+  // skip reading its v (XFREE, xfze_kernel)
+  bool open = std::getenv("ADMM_NO_SKIPV") == nullptr;
+  for (size_t k = 0; open && k < (p->stage_bounds ? (size_t)p->N : 1); ++k)
+    for (int r = h->m; open && r < h->nb; ++r)
+      open = p->lo[k * h->nb + r] == -INFINITY && p->hi[k * h->nb + r] == INFINITY;
+  h->xfree = open;
 }
 
 bool problem_has_soc(const admm_problem* p) {

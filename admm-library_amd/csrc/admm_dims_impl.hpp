@@ -65,16 +65,22 @@ void launch_dim(const XLaunch& l, XKernel k, bool a, bool b) {
         const bool relax = l.alpha != 1.0;
         // the scan's input / output slots are shared by both directions: (tseg, eseg) = (mseg, epsseg),
         // (tin, xin) = (m_in, x_end)
-#define ALT3(RS, RX, HQ, SC)                                                                                    \
+#define ALT4(RS, RX, HQ, SC, XF)                                                                                \
   do {                                                                                                       \
     if (k == XKernel::XFZE)                                                                                  \
-      hipLaunchKernelGGL((xfze_kernel<NX, NU, RS, RX, HQ, SC>), grid, block, 0, l.stream, l.dbuf, l.tin, l.xin,  \
+      hipLaunchKernelGGL((xfze_kernel<NX, NU, RS, RX, HQ, SC, XF>), grid, block, 0, l.stream, l.dbuf, l.tin, l.xin,  \
                          l.recFE, l.seg_start, l.q, l.v, l.mvec, l.tseg, l.eseg, l.part, l.alpha, l.rho,     \
                          l.pitch, l.nsplit, l.split_stride);                                                 \
     else                                                                                                     \
-      hipLaunchKernelGGL((xbze_kernel<NX, NU, RS, RX, HQ, SC>), grid, block, 0, l.stream, l.mvec, l.tin, l.xin,  \
+      hipLaunchKernelGGL((xbze_kernel<NX, NU, RS, RX, HQ, SC, XF>), grid, block, 0, l.stream, l.mvec, l.tin, l.xin,  \
                          l.recBE, l.seg_start, l.q, l.v, l.dbuf, l.tseg, l.eseg, l.part, l.alpha, l.rho,     \
                          l.pitch, l.nsplit, l.split_stride);                                                 \
+  } while (0)
+// XFREE forms (state rows unbounded everywhere: their v is not read) exist for the non-residual, non-relaxed kernels only
+#define ALT3(RS, RX, HQ, SC)                                                                                  \
+  do {                                                                                                       \
+    if constexpr (!(RS) && !(RX)) { if (l.xfree) ALT4(RS, RX, HQ, SC, true); else ALT4(RS, RX, HQ, SC, false); } \
+    else ALT4(RS, RX, HQ, SC, false);                                                                        \
   } while (0)
 #define ALT2(RS, RX, HQ) do { if (l.has_soc) ALT3(RS, RX, HQ, true); else ALT3(RS, RX, HQ, false); } while (0)
 #define ALT1(RS, RX) do { if (l.has_q) ALT2(RS, RX, true); else ALT2(RS, RX, false); } while (0)
@@ -82,6 +88,7 @@ void launch_dim(const XLaunch& l, XKernel k, bool a, bool b) {
         else   { if (relax) ALT1(false, true); else ALT1(false, false); }
 #undef ALT2
 #undef ALT3
+#undef ALT4
 #undef ALT1
       }
       break;

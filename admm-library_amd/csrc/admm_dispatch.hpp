@@ -11,6 +11,7 @@ struct XLaunch {
   hipStream_t stream;
   int n, m, S, pitch;
   int batch;                    // QPs really present (columns batch .. pitch-1 are padding)
+  bool xfree;                   // every state row is unbounded at every stage: z = v, y = 0 there (XFREE kernel forms)
   bool has_q;
   bool has_soc;                 // thrust-magnitude bound on some stage: SOC kernel forms
   double rho, alpha;

@@ -28,12 +28,15 @@ bool launch_dim(const XLaunch& l, XKernel k, bool resid, bool query_only) {
   const bool nt1 = l.pitch <= 128;
   const dim3 grid((l.pitch + mf_cols(nt1 ? 1 : 2) - 1) / mf_cols(nt1 ? 1 : 2), l.S), block(MF_THREADS);
   const bool relax = l.alpha != 1.0;
-#define FWD1(NT_, TS, TE, RS, RX, EL)                                                                                   \
-  hipLaunchKernelGGL((xfzem_kernel<NX, NU, NT_, TS, TE, RS, RX, EL>), grid, block, 0, l.stream, l.dbuf, l.tin, l.xin, l.recMF, \
+#define FWD0(NT_, TS, TE, RS, RX, EL, XF)                                                                               \
+  hipLaunchKernelGGL((xfzem_kernel<NX, NU, NT_, TS, TE, RS, RX, EL, XF>), grid, block, 0, l.stream, l.dbuf, l.tin, l.xin, l.recMF, \
                      l.seg_start, l.v, l.mvec, l.tseg, l.eseg, l.part, l.alpha, l.rho, l.pitch, l.nsplit, l.split_stride, l.batch)
-#define BWD1(NT_, TS, TE, RS, RX, SB)                                                                                   \
-  hipLaunchKernelGGL((xbzem_kernel<NX, NU, NT_, TS, TE, RS, RX, SB>), grid, block, 0, l.stream, l.mvec, l.tin, l.xin, l.recMB, \
+#define BWD0(NT_, TS, TE, RS, RX, SB, XF)                                                                               \
+  hipLaunchKernelGGL((xbzem_kernel<NX, NU, NT_, TS, TE, RS, RX, SB, XF>), grid, block, 0, l.stream, l.mvec, l.tin, l.xin, l.recMB, \
                      l.seg_start, l.v, l.dbuf, l.tseg, l.eseg, l.part, l.alpha, l.rho, l.pitch, l.nsplit, l.split_stride, l.batch)
+// XFREE forms for the non-residual, non-relaxed kernels that update v (not the plain path's backward sweep)
+#define FWD1(NT_, TS, TE, RS, RX, EL) do { if constexpr (!(RS) && !(RX)) { if (l.xfree) FWD0(NT_, TS, TE, RS, RX, EL, true); else FWD0(NT_, TS, TE, RS, RX, EL, false); } else FWD0(NT_, TS, TE, RS, RX, EL, false); } while (0)
+#define BWD1(NT_, TS, TE, RS, RX, SB) do { if constexpr (!(RS) && !(RX) && (SB)) { if (l.xfree) BWD0(NT_, TS, TE, RS, RX, SB, true); else BWD0(NT_, TS, TE, RS, RX, SB, false); } else BWD0(NT_, TS, TE, RS, RX, SB, false); } while (0)
 #define FWD(TS, TE, RS, RX, EL) do { if (nt1) FWD1(1, TS, TE, RS, RX, EL); else FWD1(2, TS, TE, RS, RX, EL); } while (0)
 #define BWD(TS, TE, RS, RX, SB) do { if (nt1) BWD1(1, TS, TE, RS, RX, SB); else BWD1(2, TS, TE, RS, RX, SB); } while (0)
 #define BY_FLAGS(CALL, TS, TE, LAST)                                                      \
@@ -50,6 +53,8 @@ bool launch_dim(const XLaunch& l, XKernel k, bool resid, bool query_only) {
   }
 #undef FWD1
 #undef BWD1
+#undef FWD0
+#undef BWD0
 #undef BY_FLAGS
 #undef BWD
 #undef FWD

@@ -157,7 +157,7 @@ __device__ __forceinline__ double mf_colsum(double x) {
 //     ELIM_F:  [mu+ ; deps ; db_k] = M [mu ; g^x ; g^u],  eps += deps,  db_k -> dbb          (ELIM only)
 // and on exit mu -> mseg[s], eps -> epsseg[s] (ELIM), residual partials -> part (RESID).
 // ---------------------------------------------------------------------------
-template <int NX, int NU, int NT, class TS, class TE, bool RESID, bool RELAX, bool ELIM>
+template <int NX, int NU, int NT, class TS, class TE, bool RESID, bool RELAX, bool ELIM, bool XFREE = false>
 __global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void xfzem_kernel(
     const double* __restrict__ dbuf, const double* __restrict__ tin, const double* __restrict__ xin,
     const unsigned char* __restrict__ recMF, const int* __restrict__ seg_start_, double* __restrict__ v,
@@ -209,6 +209,9 @@ __global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
   // a wave all of whose columns lie beyond the batch (pad columns of the last 64, or the unused waves of a small
   // batch) takes part in the record staging and the barriers only
   const bool wave_active = blockIdx.x * mf_cols(NT) + wave * NT * 16 < batch;
+  // XFREE: the state rows are unbounded at every stage and neither residuals nor over-relaxation need z_old: their v is
+  // not read (xfze_kernel explains why that is exact)
+  static_assert(!XFREE || (!RESID && !RELAX), "XFREE needs z_old of no row");
 
   TS X[NT][NR], Tin[NT][NR];
   TE Mu[NT][NR], Eps[NT][NR];
@@ -235,7 +238,7 @@ __global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     const int kk = k < k1 ? k : k1 - 1;
     const unsigned r0 = (unsigned)(kk - k0) * NB * PB;
 #pragma unroll
-    for (int r = 0; r < NR; ++r) pv[j][nt][r] = vv.load(lbl[nt], r0 + (unsigned)(NU + 4 * r) * PB);
+    for (int r = 0; r < NR; ++r) pv[j][nt][r] = XFREE ? 0.0 : vv.load(lbl[nt], r0 + (unsigned)(NU + 4 * r) * PB);
     pv[j][nt][3] = vv.load(lbl[nt], r0);
     pv[j][nt][4] = XT ? vv.load(lbl[nt], r0 + 4u * PB) : 0.0;
     const unsigned d0 = (unsigned)(kk - k0) * NU * PB;
@@ -393,7 +396,7 @@ __global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 //     ELIM_B:  [t+ ; de ; d0_k] = M [g^x + t ; g^u],  e += de,  d0_k -> dbuf
 // and on exit t -> tseg[s], e -> eseg[s]: what xb_kernel / xbze_kernel leave for the plain scan.
 // ---------------------------------------------------------------------------
-template <int NX, int NU, int NT, class TS, class TE, bool RESID, bool RELAX, bool SUBST>
+template <int NX, int NU, int NT, class TS, class TE, bool RESID, bool RELAX, bool SUBST, bool XFREE = false>
 __global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void xbzem_kernel(
     const double* __restrict__ dbb, const double* __restrict__ min_, const double* __restrict__ xend,
     const unsigned char* __restrict__ recMB, const int* __restrict__ seg_start_, double* __restrict__ v,
@@ -444,6 +447,9 @@ __global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
   // a wave all of whose columns lie beyond the batch (pad columns of the last 64, or the unused waves of a small
   // batch) takes part in the record staging and the barriers only
   const bool wave_active = blockIdx.x * mf_cols(NT) + wave * NT * 16 < batch;
+  // XFREE: the state rows are unbounded at every stage and neither residuals nor over-relaxation need z_old: their v is
+  // not read (xfze_kernel explains why that is exact)
+  static_assert(!XFREE || (!RESID && !RELAX), "XFREE needs z_old of no row");
 
   TS X[NT][NR], Min[NT][NR];
   TE Tt[NT][NR], Ee[NT][NR];
@@ -474,7 +480,7 @@ __global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     const int kk = k > k0 ? k : k0;
     const unsigned r0 = (unsigned)(kk - k0) * NB * PB;
 #pragma unroll
-    for (int r = 0; r < NR; ++r) pv[j][nt][r] = vv.load(lbl[nt], r0 + (unsigned)(NU + 4 * r) * PB);
+    for (int r = 0; r < NR; ++r) pv[j][nt][r] = XFREE ? 0.0 : vv.load(lbl[nt], r0 + (unsigned)(NU + 4 * r) * PB);
     pv[j][nt][3] = vv.load(lbl[nt], r0);
     pv[j][nt][4] = XT ? vv.load(lbl[nt], r0 + 4u * PB) : 0.0;
     if (SUBST) {

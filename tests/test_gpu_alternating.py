@@ -223,3 +223,27 @@ def test_alternating_properties_at_full_size(gpu):
     Ad, Bd = np.asarray(p.A).reshape(p.n, p.n), np.asarray(p.B).reshape(p.n, p.m)
     defect = x[:, 1:] - (x[:, :-1] @ Ad.T + u @ Bd.T)
     assert np.abs(defect).max() <= 1e-10 * max(1.0, np.abs(x).max())
+
+
+@pytest.mark.parametrize("make", [lambda: pkg.cw_rendezvous(N=200, batch=300), lambda: pkg.cw_formation(N=120, batch=300),
+                                  lambda: pkg.cw_rendezvous(N=64, batch=5, thrust_norm=True)],
+                         ids=["one_lane_6_3", "mfma_12_6", "thrust_magnitude"])
+def test_skipping_v_of_unbounded_state_rows_is_exact(gpu, make, monkeypatch):
+    """XFREE kernel forms: where every state row is unbounded at every stage, the iterations that evaluate
+    no residuals do not read v of those rows (y = 0 identically there).  Same iterates, BIT for bit, as with the skip
+    disabled (ADMM_NO_SKIPV), through a mix of residual and non-residual iterations and both kernel families."""
+    p = make()
+    out = []
+    for skip in (True, False):
+        if skip:
+            monkeypatch.delenv("ADMM_NO_SKIPV", raising=False)
+        else:
+            monkeypatch.setenv("ADMM_NO_SKIPV", "1")
+        with pkg.Solver(p, pkg.Options(rho=0.05)) as s:
+            s.run(23, residual_every=5)
+            s.iterate(4)
+            out.append(s.get() + s.residuals())
+    for a, b in zip(*out):
+        np.testing.assert_array_equal(a, b)
+    ref = oc.solve(p, rho=0.05, max_iter=27, stop=False)
+    assert _close(out[0][0], ref["w"]) and _close(out[0][1], ref["z"]) and _close(out[0][2], ref["y"])
