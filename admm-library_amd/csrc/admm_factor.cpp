@@ -5,15 +5,83 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <thread>
 
 namespace admm {
 namespace {
 
 using Mat = std::vector<double>;  // row-major
 
+// The stage recursions (Riccati sweep, filter covariance) are sequential, but most of the work per rho -- the gains and
+// folded operators of each stage, the segment transfer matrices, the MFMA fragment packing -- is independent per stage or
+// per segment: those loops run on a few host threads (ADMM_FACTOR_THREADS, default min(cores, 16)).  Every stage is
+// computed by exactly one thread with the same arithmetic, so the result does not depend on the thread count.
+int factor_threads() {
+  static const int n = [] {
+    const char* e = std::getenv("ADMM_FACTOR_THREADS");
+    int v = e ? std::atoi(e) : (int)std::thread::hardware_concurrency();
+    return v < 1 ? 1 : (v > 16 ? 16 : v);
+  }();
+  return n;
+}
+#ifdef ADMM_FACTOR_TIMING          // phase timing on stderr (build with -DADMM_FACTOR_TIMING; tools only)
+}  // namespace
+}  // namespace admm
+#include <chrono>
+#include <cstdio>
+namespace admm {
+namespace {
+struct PhaseTimer {
+  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+  void lap(const char* what) {
+    const auto n = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "  [factor] %-28s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
+    t = n;
+  }
+};
+#else
+struct PhaseTimer { void lap(const char*) {} };
+#endif
+
+template <class F>
+void parallel_for(int count, F&& fn) {          // fn(begin, end) over a partition of [0, count)
+  const int nt = std::min(factor_threads(), count);
+  if (nt <= 1) { fn(0, count); return; }
+  std::vector<std::thread> th;
+  th.reserve(nt - 1);
+  for (int t = 1; t < nt; ++t)
+    th.emplace_back([&fn, t, nt, count] { fn((int)((int64_t)count * t / nt), (int)((int64_t)count * (t + 1) / nt)); });
+  fn(0, count / nt);
+  for (auto& x : th) x.join();
+}
+
+// c (p x r) = a (p x q) b (q x r).  Every output element is summed over k in ascending order from 0.0, whatever the
+// instantiation.  The inner dimension is a template parameter for the sizes that occur (n, m <= 16): the output row then
+// lives in registers across the k loop, which is worth 4-5x on the ~50 000 small products of one factorisation.
+template <int R>
+void mul_rows(const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ c, int p, int q) {
+  for (int i = 0; i < p; ++i) {
+    double acc[R];
+    for (int j = 0; j < R; ++j) acc[j] = 0.0;
+    for (int k = 0; k < q; ++k) {
+      const double aik = a[(size_t)i * q + k];
+      for (int j = 0; j < R; ++j) acc[j] += aik * b[(size_t)k * R + j];
+    }
+    for (int j = 0; j < R; ++j) c[(size_t)i * R + j] = acc[j];
+  }
+}
 Mat mul(const Mat& a, const Mat& b, int p, int q, int r) {
   Mat c((size_t)p * r, 0.0);
+  switch (r) {
+#define ADMM_MUL_CASE(R) case R: mul_rows<R>(a.data(), b.data(), c.data(), p, q); return c;
+    ADMM_MUL_CASE(1) ADMM_MUL_CASE(2) ADMM_MUL_CASE(3) ADMM_MUL_CASE(4) ADMM_MUL_CASE(5) ADMM_MUL_CASE(6) ADMM_MUL_CASE(7) ADMM_MUL_CASE(8)
+    ADMM_MUL_CASE(9) ADMM_MUL_CASE(10) ADMM_MUL_CASE(11) ADMM_MUL_CASE(12) ADMM_MUL_CASE(13) ADMM_MUL_CASE(14) ADMM_MUL_CASE(15) ADMM_MUL_CASE(16)
+#undef ADMM_MUL_CASE
+    default: break;
+  }
   for (int i = 0; i < p; ++i)
     for (int k = 0; k < q; ++k) {
       const double aik = a[(size_t)i * q + k];
@@ -285,21 +353,45 @@ void build_alternating(Factor& f, const std::vector<Mat>& A, const std::vector<M
   if (!spd_inverse(Qr, n, Qi) || !spd_inverse(QNr, n, QNi)) return;
 
   std::vector<Mat> Fm(N), Gam(N), Pi(N), DK(N), DG(N), Kb(N), Ai(N), AiB(N), Jb(N);
-  Mat C((size_t)n * n, 0.0);
-  for (int k = 0; k < N; ++k) {
-    const Mat At = tr(A[k], n, n), Bt = tr(B[k], n, m);
+  PhaseTimer timer;
+  // (1) the covariance recursion, sequential: Pm_k, G_{k+1}
+  std::vector<Mat> Pmk(N), Gk(N);
+  {
+    Mat C((size_t)n * n, 0.0);
+    Mat BRB;                                                  // B Rr^{-1} B' (the same at every stage unless time varying)
+    for (int k = 0; k < N; ++k) {
+      const Mat At = tr(A[k], n, n);
+      if (k == 0 || B[k] != B[k - 1]) {
+        const Mat Bt = tr(B[k], n, m);
+        BRB = mul(mul(B[k], Ri, n, m, m), Bt, n, m, n);
+      }
+      Mat Pm = add(mul(mul(A[k], C, n, n, n), At, n, n, n), BRB);
+      symmetrise(Pm, n);
+      const Mat& Qin = (k + 1 == N) ? QNi : Qi;
+      Mat D = add(Pm, Qin);
+      symmetrise(D, n);
+      Mat Di;
+      if (!spd_inverse(D, n, Di)) return;
+      Gk[k] = mul(Pm, Di, n, n, n);
+      C = sub(Pm, mul(Gk[k], Pm, n, n, n));
+      symmetrise(C, n);
+      Pmk[k] = std::move(Pm);
+    }
+  }
+  timer.lap("  alt: covariance recursion");
+  // (2) gains, folded operators and records of each stage, independent given (Pm_k, G_{k+1})
+  std::atomic<bool> bad{false};
+  parallel_for(N, [&](int k_begin, int k_end) {
+  for (int k = k_begin; k < k_end && !bad; ++k) {
+    const Mat Bt = tr(B[k], n, m);
     const Mat BRi = mul(B[k], Ri, n, m, m);
-    Mat Pm = add(mul(mul(A[k], C, n, n, n), At, n, n, n), mul(BRi, Bt, n, m, n));
-    symmetrise(Pm, n);
+    const Mat& Pm = Pmk[k];
+    const Mat& G = Gk[k];
     const Mat& Qin = (k + 1 == N) ? QNi : Qi;
-    Mat D = add(Pm, Qin);
-    symmetrise(D, n);
-    Mat Di;
-    if (!spd_inverse(D, n, Di)) return;
-    const Mat G = mul(Pm, Di, n, n, n);
     const Mat ImG = sub(I, G);
     Kb[k] = neg(mul(mul(Ri, Bt, m, m, n), pinv_psd(Pm, n, 1e-13), m, n, n));
-    if (!general_inverse(A[k], n, Ai[k])) return;
+    if (k > k_begin && A[k] == A[k - 1]) Ai[k] = Ai[k - 1];
+    else if (!general_inverse(A[k], n, Ai[k])) { bad = true; return; }
     AiB[k] = mul(Ai[k], B[k], n, n, m);
     Jb[k] = mul(Ai[k], add(I, mul(B[k], Kb[k], n, m, n)), n, n, n);       // x_k = Jb x_{k+1} + AiB db_k
     Fm[k] = mul(ImG, A[k], n, n, n);
@@ -307,8 +399,6 @@ void build_alternating(Factor& f, const std::vector<Mat>& A, const std::vector<M
     Pi[k] = neg(mul(G, Qin, n, n, n));
     DK[k] = neg(mul(Kb[k], A[k], m, n, n));
     DG[k] = add(Ri, mul(Kb[k], BRi, m, n, m));                            // Rr^{-1} - Kb (-B Rr^{-1})
-    C = sub(Pm, mul(G, Pm, n, n, n));
-    symmetrise(C, n);
     // stage-local blocks; the rollout / elimination blocks are copied from the plain records
     double* rfe = &f.recFE[(size_t)k * f.RFE];
     double* rbe = &f.recBE[(size_t)k * f.RBE];
@@ -336,13 +426,17 @@ void build_alternating(Factor& f, const std::vector<Mat>& A, const std::vector<M
     rfe[lfe.UB] = rf[lf.UB];
     rbe[lbe.UB] = rb[lb.UB];
   }
+  });
+  if (bad) return;
+  timer.lap("  alt: stage operators");
 
   // ---- segment algebra (a = segment start, b = end) ----
   //   mu_k  = mu0_k + (F_{k-1} ... F_a) m_in              =>  db_k = db0_k + Psb_k m_in,  Psb_k = DK_k F_{k-1} ... F_a
   //   x_a   = (Jb_a ... Jb_{b-1}) x_b + sum_k Omb_k db_k,      Omb_k = (Jb_a ... Jb_{k-1}) A_k^{-1} B_k
   //   m_out = mseg + Phs m_in;    x_end(s-1) = ebseg(s) + Thb(s) x_end(s) + Xib(s) m_in(s),   ebseg = sum_k Omb_k db0_k
   std::vector<Mat> Phs(S), Thb(S), Xib(S);
-  for (int s = 0; s < S; ++s) {
+  parallel_for(S, [&](int s_begin, int s_end) {
+  for (int s = s_begin; s < s_end; ++s) {
     const int a = f.seg_start[s], b = f.seg_start[s + 1];
     Mat P = I, Jp = I, Xi((size_t)n * n, 0.0);
     for (int k = a; k < b; ++k) {
@@ -358,11 +452,13 @@ void build_alternating(Factor& f, const std::vector<Mat>& A, const std::vector<M
     Thb[s] = Jp;
     Xib[s] = Xi;
   }
+  });
   for (int k = 0; k < N; ++k) {                       // (the box blocks may hold +-inf: matrices only)
     for (int i = 0; i < lfe.LO; ++i) if (!std::isfinite(f.recFE[(size_t)k * f.RFE + i])) return;
     for (int i = 0; i < lbe.LO; ++i) if (!std::isfinite(f.recBE[(size_t)k * f.RBE + i])) return;
   }
 
+  timer.lap("  alt: segment algebra");
   // ---- scan matrix, same shape and layout as scanW ----
   //   in rows:  mseg(0..S-1) | x0 | ebseg(0..S-1)          out rows:  m_in(0..S-1) | x_end(0..S-1)
   const int Sn = S * n, Mt = f.scanMt, M = f.scanM, K = f.scanK;
@@ -379,6 +475,7 @@ void build_alternating(Factor& f, const std::vector<Mat>& A, const std::vector<M
     rowblock_step(f.scanWB, K, n, r_x + (s - 1) * n, &Thb[s], r_x + s * n, &Xib[s], r_m + s * n, c_e + s * n);
   for (double v : f.scanWB) if (!std::isfinite(v)) return;
 
+  timer.lap("  alt: scan matrix");
   // ---- verification against the Riccati form (one QP, random linear term, the scan as the dense product) ----
   {
     const int nb = n + m;
@@ -468,29 +565,41 @@ void build_alternating(Factor& f, const std::vector<Mat>& A, const std::vector<M
     // tools/stress_alt.py: max 2.5e-11), inside the 1e-10 parity tolerance with margin
     if (!(f.alt_check <= 5e-12)) return;
   }
+  timer.lap("  alt: verification");
   pack_scan(f.scanWB, M, K, f.scanWpB, f.scanRangeB);
   f.alt_ok = true;
+  timer.lap("  alt: pack scan");
 }
 
 
 // ---- MFMA form of the fused stage operators (admm_mfma_layout.hpp) ----
-struct Frags {
-  std::vector<double> v;     // values in consumption order; cast to the element type when a record is written
-};
-
 // One product: M (R x C, row-major) -> ks * ot fragments of 64 values.  out_row(ot, r, g) / in_col(ks, g) give the
-// matrix row / column a slot stands for (-1 = padding).  hw_row(i) -> (r, g) is the accumulator-row map of the
-// element type.
+// matrix row / column a slot stands for (-1 = padding).  The map from fragment element to matrix element is the same
+// at every stage, so it is built once (offsets into M, -1 = zero) and each stage is a gather.
 template <class OutRow, class InCol>
-void pack_product(Frags& fr, const Mat& M, int C, int ks_n, int ot_n, bool f32, OutRow out_row, InCol in_col) {
+std::vector<int32_t> product_map(int C, int ks_n, int ot_n, bool f32, OutRow out_row, InCol in_col) {
+  std::vector<int32_t> map;
+  map.reserve((size_t)ks_n * ot_n * 64);
   for (int ks = 0; ks < ks_n; ++ks)
     for (int ot = 0; ot < ot_n; ++ot)
       for (int lane = 0; lane < 64; ++lane) {
         const int i = lane & 15, kk = lane >> 4;
         const int g = f32 ? (i >> 2) : (i & 3), r = f32 ? (i & 3) : (i >> 2);   // slot (r, g) of hardware row i
         const int row = out_row(ot, r, g), col = in_col(ks, kk);
-        fr.v.push_back((row >= 0 && col >= 0) ? M[(size_t)row * C + col] : 0.0);
+        map.push_back((row >= 0 && col >= 0) ? row * C + col : -1);
       }
+  return map;
+}
+
+unsigned char* write_product(unsigned char* dst, const std::vector<int32_t>& map, const Mat& M, int elem) {
+  if (elem == 8) {
+    double* o = reinterpret_cast<double*>(dst);
+    for (size_t i = 0; i < map.size(); ++i) o[i] = map[i] < 0 ? 0.0 : M[map[i]];
+  } else {
+    float* o = reinterpret_cast<float*>(dst);
+    for (size_t i = 0; i < map.size(); ++i) o[i] = map[i] < 0 ? 0.0f : (float)M[map[i]];
+  }
+  return dst + map.size() * elem;
 }
 
 Mat block(const double* rec, int off, int r, int c) { return Mat(rec + off, rec + off + (size_t)r * c); }
@@ -500,23 +609,27 @@ void put_block(Mat& M, int C, int r0, int c0, const Mat& B, int r, int c, double
     for (int j = 0; j < c; ++j) M[(size_t)(r0 + i) * C + c0 + j] = sgn * B[(size_t)i * c + j];
 }
 
-unsigned char* write_frags(unsigned char* dst, const Frags& fr, int elem) {
-  if (elem == 8) {
-    std::memcpy(dst, fr.v.data(), fr.v.size() * 8);
-  } else {
-    float* o = reinterpret_cast<float*>(dst);
-    for (size_t i = 0; i < fr.v.size(); ++i) o[i] = (float)fr.v[i];
-  }
-  return dst + fr.v.size() * elem;
-}
-
-void build_mfma(Factor& f, int mode, std::vector<unsigned char>& recMF, std::vector<unsigned char>& recMB, int& RMF, int& RMB) {
+// One pass over the stages folds the operators and writes the records of `mode`; for mode 1 (mixed) the all-fp64
+// records the refinement phase needs (recMF64 / recMB64) are written from the same folded matrices.
+void build_mfma(Factor& f, int mode) {
   const int N = f.N, n = f.n, m = f.m;
   const MfmaLayout L = mfma_layout(n, m);
-  RMF = mfma_rec_bytes_fwd(n, m, mode);
-  RMB = mfma_rec_bytes_bwd(n, m, mode);
-  recMF.assign((size_t)N * RMF, 0);
-  recMB.assign((size_t)N * RMB, 0);
+  struct Out {
+    int mode, RMF, RMB;
+    std::vector<unsigned char>*recMF, *recMB;
+    std::vector<int32_t> sub_f, elim_f, sub_b, elim_b;
+  };
+  std::vector<Out> outs;
+  outs.push_back(Out{mode, 0, 0, &f.recMF, &f.recMB, {}, {}, {}, {}});
+  if (mode == 1) outs.push_back(Out{2, 0, 0, &f.recMF64, &f.recMB64, {}, {}, {}, {}});
+  for (Out& o : outs) {
+    o.RMF = mfma_rec_bytes_fwd(n, m, o.mode);
+    o.RMB = mfma_rec_bytes_bwd(n, m, o.mode);
+    o.recMF->assign((size_t)N * o.RMF, 0);
+    o.recMB->assign((size_t)N * o.RMB, 0);
+  }
+  f.RMF = outs[0].RMF; f.RMB = outs[0].RMB;
+  if (mode == 1) { f.RMF64 = outs[1].RMF; f.RMB64 = outs[1].RMB; }
   const RecBLayout lb = rec_b_layout(n, m);
   const RecFLayout lf = rec_f_layout(n, m);
   const RecFELayout lfe = rec_fe_layout(n, m);
@@ -553,7 +666,15 @@ void build_mfma(Factor& f, int mode, std::vector<unsigned char>& recMF, std::vec
     return j < m ? n + j : -1;
   };
   const Mat Im = eye(m);
-  for (int k = 0; k < N; ++k) {
+  const int C3 = 2 * n + m, C2 = n + m;
+  for (Out& o : outs) {
+    o.sub_f = product_map(C3, L.ks_sub, 1, mfma_es_sub_f(o.mode) == 4, sub_out, sub_in);
+    o.elim_f = product_map(C3, L.ks_elim_f, 2, mfma_es_elim_f(o.mode) == 4, elim_out, sub_in);
+    o.sub_b = product_map(C3, L.ks_sub, 1, mfma_es_sub_b(o.mode) == 4, sub_out, sub_in);
+    o.elim_b = product_map(C2, L.ks_elim_b, 2, mfma_es_elim_b(o.mode) == 4, elim_out, elimb_in);
+  }
+  parallel_for(N, [&](int k_begin, int k_end) {
+  for (int k = k_begin; k < k_end; ++k) {
     const double* rf = &f.recF[(size_t)k * f.RF];
     const double* rb = &f.recB[(size_t)k * f.RB];
     const Mat K = block(rf, lf.K, m, n), Psi = block(rf, lf.PSI, m, n), A = block(rf, lf.A, n, n), B = block(rf, lf.B, n, m);
@@ -570,9 +691,7 @@ void build_mfma(Factor& f, int mode, std::vector<unsigned char>& recMF, std::vec
         lohi[r * 4 + g] = row < 0 ? -INFINITY : rb[lb.LO + row];
         lohi[20 + r * 4 + g] = row < 0 ? INFINITY : rb[lb.HI + row];
       }
-    const int C3 = 2 * n + m;
     {  // ---------------- forward record: SUB_F, ELIM_F ----------------
-      Frags fr, fe;
       Mat Ms((size_t)(n + m) * C3, 0.0);
       const Mat BK = mul(B, K, n, m, n), BPsi = mul(B, Psi, n, m, n);
       put_block(Ms, C3, 0, 0, sub(A, BK), n, n, 1.0);        // x+ = (A - B K) x - B Psi t - B d
@@ -581,7 +700,6 @@ void build_mfma(Factor& f, int mode, std::vector<unsigned char>& recMF, std::vec
       put_block(Ms, C3, n, 0, K, m, n, -1.0);                // u  = -K x - Psi t - d
       put_block(Ms, C3, n, n, Psi, m, n, -1.0);
       put_block(Ms, C3, n, 2 * n, Im, m, m, -1.0);
-      pack_product(fr, Ms, C3, L.ks_sub, 1, mfma_es_sub_f(mode) == 4, sub_out, sub_in);
       std::vector<double> urow((size_t)L.urows * L.ks_sub * 4 + 1, 0.0);
       urow_table(Ms, C3, urow.data());
       Mat Me((size_t)(2 * n + m) * C3, 0.0);                 // rows [mu+ ; deps ; db], cols [mu ; g^x ; g^u]
@@ -597,14 +715,14 @@ void build_mfma(Factor& f, int mode, std::vector<unsigned char>& recMF, std::vec
         put_block(Me, C3, 2 * n, 0, DK, m, n, 1.0);
         put_block(Me, C3, 2 * n, 2 * n, DG, m, m, 1.0);
       }
-      pack_product(fe, Me, C3, L.ks_elim_f, 2, mfma_es_elim_f(mode) == 4, elim_out, sub_in);
-      unsigned char* o = write_frags(&recMF[(size_t)k * RMF], fr, mfma_es_sub_f(mode));
-      o = write_frags(o, fe, mfma_es_elim_f(mode));
-      std::memcpy(o, lohi, 40 * 8);
-      std::memcpy(o + 40 * 8, urow.data(), (size_t)L.urows * L.ks_sub * 4 * 8);
+      for (const Out& w : outs) {
+        unsigned char* o = write_product(&(*w.recMF)[(size_t)k * w.RMF], w.sub_f, Ms, mfma_es_sub_f(w.mode));
+        o = write_product(o, w.elim_f, Me, mfma_es_elim_f(w.mode));
+        std::memcpy(o, lohi, 40 * 8);
+        std::memcpy(o + 40 * 8, urow.data(), (size_t)L.urows * L.ks_sub * 4 * 8);
+      }
     }
     {  // ---------------- backward record: SUB_B, ELIM_B ----------------
-      Frags fr, fe;
       Mat Ms((size_t)(n + m) * C3, 0.0);                     // rows [x_k ; u], cols [x_{k+1} ; m_in ; db]
       if (f.alt_ok) {
         const double* rbe = &f.recBE[(size_t)k * f.RBE];
@@ -617,10 +735,8 @@ void build_mfma(Factor& f, int mode, std::vector<unsigned char>& recMF, std::vec
         put_block(Ms, C3, n, n, PSB, m, n, -1.0);
         put_block(Ms, C3, n, 2 * n, Im, m, m, -1.0);
       }
-      pack_product(fr, Ms, C3, L.ks_sub, 1, mfma_es_sub_b(mode) == 4, sub_out, sub_in);
       std::vector<double> urow((size_t)L.urows * L.ks_sub * 4 + 1, 0.0);
       urow_table(Ms, C3, urow.data());
-      const int C2 = n + m;
       Mat Me((size_t)(2 * n + m) * C2, 0.0);                 // rows [t+ ; de ; d0], cols [p ; g^u]
       const Mat SIBT = mul(SI, BT, m, m, n);
       put_block(Me, C2, 0, 0, sub(AT, mul(KT, BT, n, m, n)), n, n, 1.0);        // t+ = A' p - K' (B' p + g^u)
@@ -629,13 +745,15 @@ void build_mfma(Factor& f, int mode, std::vector<unsigned char>& recMF, std::vec
       put_block(Me, C2, n, n, mul(OM, SI, n, m, m), n, m, 1.0);
       put_block(Me, C2, 2 * n, 0, SIBT, m, n, 1.0);                             // d0 = Si (B' p + g^u)
       put_block(Me, C2, 2 * n, n, SI, m, m, 1.0);
-      pack_product(fe, Me, C2, L.ks_elim_b, 2, mfma_es_elim_b(mode) == 4, elim_out, elimb_in);
-      unsigned char* o = write_frags(&recMB[(size_t)k * RMB], fr, mfma_es_sub_b(mode));
-      o = write_frags(o, fe, mfma_es_elim_b(mode));
-      std::memcpy(o, lohi, 40 * 8);
-      std::memcpy(o + 40 * 8, urow.data(), (size_t)L.urows * L.ks_sub * 4 * 8);
+      for (const Out& w : outs) {
+        unsigned char* o = write_product(&(*w.recMB)[(size_t)k * w.RMB], w.sub_b, Ms, mfma_es_sub_b(w.mode));
+        o = write_product(o, w.elim_b, Me, mfma_es_elim_b(w.mode));
+        std::memcpy(o, lohi, 40 * 8);
+        std::memcpy(o + 40 * 8, urow.data(), (size_t)L.urows * L.ks_sub * 4 * 8);
+      }
     }
   }
+  });
 }
 
 }  // namespace
@@ -670,6 +788,7 @@ int factorise(const admm_problem& p, double rho, int segments, Factor& f, std::s
   const Mat Q = from_colmajor(p.Q, n, n), R = from_colmajor(p.R, m, m), QN = from_colmajor(p.QN, n, n);
   std::vector<Mat> A(N), B(N), Acl(N);
 
+  PhaseTimer timer;
   // ---- Riccati sweep ----
   Mat P = QN;
   for (int i = 0; i < n; ++i) P[(size_t)i * n + i] += rho;
@@ -739,8 +858,11 @@ int factorise(const admm_problem& p, double rho, int segments, Factor& f, std::s
     rf[lf.UB] = ub;
   }
 
+  timer.lap("riccati sweep");
   // ---- segment algebra ----
-  for (int s = 0; s < S; ++s) {
+  std::atomic<bool> seg_overflow{false};
+  parallel_for(S, [&](int s_begin, int s_end) {
+  for (int s = s_begin; s < s_end; ++s) {
     const int a = f.seg_start[s], b = f.seg_start[s + 1];
     Mat Lam = eye(n);             // Lambda_k = Acl_{b-1} ... Acl_{k+1}
     Mat Xi((size_t)n * n, 0.0);
@@ -766,9 +888,12 @@ int factorise(const admm_problem& p, double rho, int segments, Factor& f, std::s
     for (size_t i = 0; i < Xi.size(); ++i) rs[(size_t)n * n + i] = Xi[i];
     for (size_t i = 0; i < Lam.size(); ++i) rs[(size_t)2 * n * n + i] = Lam[i];
     for (int i = 0; i < f.RS; ++i)
-      if (!std::isfinite(rs[i])) { err = "segment transfer matrices overflowed; use more segments"; return ADMM_ERR_NUMERIC; }
+      if (!std::isfinite(rs[i])) seg_overflow = true;
   }
+  });
+  if (seg_overflow) { err = "segment transfer matrices overflowed; use more segments"; return ADMM_ERR_NUMERIC; }
 
+  timer.lap("segment algebra");
   // ---- scan matrix ----
   {
     const int Sn = S * n;
@@ -799,14 +924,16 @@ int factorise(const admm_problem& p, double rho, int segments, Factor& f, std::s
     pack_scan(f.scanW, M, K, f.scanWp, f.scanRange);
   }
 
+  timer.lap("scan matrix");
   build_alternating(f, A, B, Q, R, QN, rho);
+  timer.lap("alternating form");
   f.mfma_mode = mfma_mode;
   f.recMF.clear();
   f.recMB.clear();
   f.recMF64.clear();
   f.recMB64.clear();
-  if (mfma_mode) build_mfma(f, mfma_mode, f.recMF, f.recMB, f.RMF, f.RMB);
-  if (mfma_mode == 1) build_mfma(f, 2, f.recMF64, f.recMB64, f.RMF64, f.RMB64);
+  if (mfma_mode) build_mfma(f, mfma_mode);
+  timer.lap("mfma records");
   return ADMM_OK;
 }
 

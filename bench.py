@@ -415,6 +415,11 @@ def main():
         plain_path = {"batch_iterations_per_s": a.steps / dtp, "ms_per_step": dtp / a.steps * 1e3,
                       "iteration_bytes_per_element": b_xb + b_xfz, "roofline_xfz": roofline_xfz}
 
+    # iterations that evaluate no residuals: where every state row is unbounded at every stage (all the CW workloads) the
+    # kernels do not read v of the state rows (XFREE forms): v of the m input rows + v+ of all rows + d + db
+    xfree = (prof_alt is not None and not full.per_instance
+             and bool(np.all(np.asarray(full.lo)[..., m_:] == -np.inf) and np.all(np.asarray(full.hi)[..., m_:] == np.inf)))
+    b_iter_plain = (8.0 + 24.0 * m_ / (n_ + m_) + (8.0 if full.q is not None else 0.0)) if xfree else b_iter
     # mixed mode a solver would normally run: residuals every 10th iteration
     warm(solver, 0.25 * a.warm_seconds, every=10)
     dt10 = float(np.median(timed_blocks(solver, 10)))
@@ -532,7 +537,10 @@ def main():
             "iters_to_eps_adaptive_rho": iters_to_eps_adaptive,
             "iters_to_eps_adaptive_rho_alpha_1p6": iters_to_eps_relaxed,
             "check_interval_10": {"batch_iterations_per_s": a.steps / dt10,
-                                  "QP_iterations_per_s": gbatch * a.steps / dt10},
+                                  "QP_iterations_per_s": gbatch * a.steps / dt10,
+                                  "state_rows_unbounded_v_not_read": xfree,
+                                  "bytes_per_element_without_residuals": b_iter_plain,
+                                  "iteration_GBs": (0.9 * b_iter_plain + 0.1 * b_iter) * elems / (dt10 / a.steps) / 1e9},
         }
         if cpu_base is not None:
             out["cpu_baseline"] = cpu_base
