@@ -10,7 +10,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/admm_hip.h"
@@ -37,6 +39,17 @@ int fail(int code, const std::string& msg) {
 
 }  // namespace
 
+// A factorisation for a rho the adaptive rule may ask for next, computed on a background thread while the GPU iterates
+// (or the factor of the previous rho, kept).  See spec_start().
+struct SpecFactor {
+  double rho = 0.0;
+  admm::Factor f;
+  std::string err;
+  int rc = 0;
+  std::thread th;
+  ~SpecFactor() { if (th.joinable()) th.join(); }
+};
+
 struct admm_handle {
   int N = 0, n = 0, m = 0, nb = 0, batch = 0, pitch = 0, L = 0;
   int S = 0, zrows = 0, zchunks = 0;
@@ -53,6 +66,9 @@ struct admm_handle {
   std::vector<double> pA, pB, pQ, pR, pQN, plo, phi, pun;
   int time_varying = 0, stage_bounds = 0;
   int rho_updates = 0;
+  std::vector<std::unique_ptr<SpecFactor>> spec;        // candidates of the adaptive rule (rho tau, rho / tau)
+  std::vector<std::unique_ptr<SpecFactor>> spec_stale;  // no longer candidates; their threads are joined lazily
+  int spec_hits = 0, spec_misses = 0;
   int solve_it = 0, solve_nconv = 0;     // admm_solve_begin / _step / _end state
   std::chrono::steady_clock::time_point solve_t0;
   hipStream_t stream = nullptr;
@@ -484,6 +500,8 @@ void destroy_graph(admm_handle* h) {
 
 void release(admm_handle* h) {
   if (!h) return;
+  h->spec.clear();               // joins the background factorisations (they read the handle's problem copy)
+  h->spec_stale.clear();
   (void)hipSetDevice(h->device);
   destroy_graph(h);
   double** bufs[] = {&h->w, &h->z, &h->y, &h->v, &h->q, &h->dbuf, &h->scan_in, &h->scan_out, &h->scanWp,
@@ -1084,6 +1102,86 @@ int admm_update_instances(admm_handle* h, const double* x0, const double* q) {
   return ADMM_OK;
 }
 
+static admm_problem shared_problem(const admm_handle* h) {
+  admm_problem p{};
+  p.N = h->N; p.n = h->n; p.m = h->m; p.batch = h->batch;
+  p.time_varying = h->time_varying; p.stage_bounds = h->stage_bounds;
+  p.A = h->pA.data(); p.B = h->pB.data(); p.Q = h->pQ.data(); p.R = h->pR.data(); p.QN = h->pQN.data();
+  p.lo = h->plo.data(); p.hi = h->phi.data();
+  p.unorm = h->pun.empty() ? nullptr : h->pun.data();
+  return p;
+}
+
+// ---- background refactors for the adaptive-rho rule ----
+// The rule can only move rho to rho * tau or rho / tau, and a host factorisation costs as much as tens of iterations
+// (n = 12: as much as 100+).  While admm_solve iterates, both candidates are factorised on background host threads from
+// the handle's own copy of the problem; when the rule fires, set_rho_internal finds the factor ready (or waits for the
+// rest of it).  The factor of the rho being left is kept as a candidate too.  Same code, same inputs: the factor -- and
+// so every iterate -- is the one a synchronous refactor would produce.  ADMM_NO_SPECULATE=1 turns this off.
+static bool spec_enabled(const admm_handle* h) {
+  const bool off = std::getenv("ADMM_NO_SPECULATE") != nullptr;     // read per call: tests switch it within a process
+  return !off && !h->pinst && h->opt.adapt_interval > 0 && h->rho_updates < h->opt.adapt_max;
+}
+
+static void spec_reap(admm_handle* h, bool all) {          // drop stale entries whose thread has finished (all: join them)
+  if (all) { h->spec_stale.clear(); return; }
+  // a finished thread is recognised by rc having been published; unfinished ones stay until the next reap
+  for (size_t i = 0; i < h->spec_stale.size();)
+    if (!h->spec_stale[i]->th.joinable() || __atomic_load_n(&h->spec_stale[i]->rc, __ATOMIC_ACQUIRE) != INT32_MIN)
+      h->spec_stale.erase(h->spec_stale.begin() + i);
+    else ++i;
+}
+
+static std::unique_ptr<SpecFactor> spec_take(admm_handle* h, double rho) {
+  for (size_t i = 0; i < h->spec.size(); ++i)
+    if (h->spec[i]->rho == rho) {
+      std::unique_ptr<SpecFactor> sp = std::move(h->spec[i]);
+      h->spec.erase(h->spec.begin() + i);
+      if (sp->th.joinable()) sp->th.join();
+      return sp;
+    }
+  return nullptr;
+}
+
+static void spec_start(admm_handle* h) {
+  spec_reap(h, false);
+  if (!spec_enabled(h)) {
+    for (auto& s : h->spec) h->spec_stale.push_back(std::move(s));
+    h->spec.clear();
+    return;
+  }
+  const double cand[2] = {h->opt.rho * h->opt.adapt_tau, h->opt.rho / h->opt.adapt_tau};   // as admm_solve_adapt forms them
+  for (size_t i = 0; i < h->spec.size();)
+    if (h->spec[i]->rho != cand[0] && h->spec[i]->rho != cand[1]) {
+      h->spec_stale.push_back(std::move(h->spec[i]));
+      h->spec.erase(h->spec.begin() + i);
+    } else {
+      ++i;
+    }
+  for (double rho : cand) {
+    if (!(rho > 0.0) || !std::isfinite(rho)) continue;
+    bool have = false;
+    for (auto& s : h->spec) have = have || s->rho == rho;
+    if (have) continue;
+    std::unique_ptr<SpecFactor> sp(new SpecFactor);
+    sp->rho = rho;
+    sp->rc = INT32_MIN;                                     // "not finished" (read only after join, or by spec_reap)
+    SpecFactor* s = sp.get();
+    const admm_handle* hc = h;
+    s->th = std::thread([hc, s] {
+      admm::set_factor_thread_cap(6);                       // two of these run beside the thread that launches kernels
+      const admm_problem p = shared_problem(hc);
+      admm::Factor f;
+      std::string err;
+      const int rc = admm::factorise(p, s->rho, hc->S, f, err, hc->mfma_mode);
+      s->f = std::move(f);
+      s->err = std::move(err);
+      __atomic_store_n(&s->rc, rc, __ATOMIC_RELEASE);
+    });
+    h->spec.push_back(std::move(sp));
+  }
+}
+
 // Refactor for a new rho, re-upload the records, rescale the scaled dual.  The state is
 // switched to (z, y) form so that y *= rho_old / rho_new is applied to the very numbers the
 // iteration produced (bit-identical to the oracle); the next iteration reads z, y directly.
@@ -1109,15 +1207,28 @@ static int set_rho_internal(admm_handle* h, double rho_new) {
     h->opt.rho = rho_new;
     return ADMM_OK;
   }
-  admm_problem p{};
-  p.N = h->N; p.n = h->n; p.m = h->m; p.batch = h->batch;
-  p.time_varying = h->time_varying; p.stage_bounds = h->stage_bounds;
-  p.A = h->pA.data(); p.B = h->pB.data(); p.Q = h->pQ.data(); p.R = h->pR.data(); p.QN = h->pQN.data();
-  p.lo = h->plo.data(); p.hi = h->phi.data();
-  p.unorm = h->pun.empty() ? nullptr : h->pun.data();
+  const admm_problem p = shared_problem(h);
   admm::Factor f;
   std::string err;
-  int rc = admm::factorise(p, rho_new, h->S, f, err, h->mfma_mode);
+  int rc;
+  static const bool debug = std::getenv("ADMM_SPEC_DEBUG") != nullptr;
+  auto t0 = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!debug) return;
+    const auto t1 = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[admm] set_rho %-22s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+    t0 = t1;
+  };
+  if (std::unique_ptr<SpecFactor> sp = spec_take(h, rho_new)) {   // factorised in the background (or kept from before)
+    rc = sp->rc;
+    err = std::move(sp->err);
+    f = std::move(sp->f);
+    ++h->spec_hits;
+  } else {
+    rc = admm::factorise(p, rho_new, h->S, f, err, h->mfma_mode);
+    ++h->spec_misses;
+  }
+  lap("factor (take / compute)");
   if (rc) return fail(rc, err);
   if (f.recB.size() != h->fac.recB.size() || f.scanWp.size() != h->fac.scanWp.size())
     return fail(ADMM_ERR_NUMERIC, "internal: record sizes changed on refactor");
@@ -1137,8 +1248,17 @@ static int set_rho_internal(admm_handle* h, double rho_new) {
   h->zy_valid = true;
   h->v_valid = false;
   HIP_TRY(hipStreamSynchronize(h->stream));                // kernels of the old rho are done before the records change
+  lap("state to (z, y), sync");
+  if (spec_enabled(h)) {                                   // the rule may come back to the rho it leaves: keep that factor
+    std::unique_ptr<SpecFactor> old(new SpecFactor);
+    old->rho = h->opt.rho;
+    old->f = std::move(h->fac);
+    h->spec.push_back(std::move(old));
+  }
   h->fac = std::move(f);
+  lap("keep / move factor");
   if ((rc = upload_factor(h))) return rc;
+  lap("upload");
   h->opt.rho = rho_new;
   destroy_graph(h);                                        // rho is a captured kernel argument
   return ADMM_OK;
@@ -1189,6 +1309,8 @@ int admm_update_problem(admm_handle* h, const admm_problem* p) {
   h->zy_valid = true;
   h->v_valid = false;
   HIP_TRY(hipStreamSynchronize(h->stream));    // kernels of the old records are done before they change
+  h->spec.clear();                             // background factorisations read the problem copy that changes now
+  h->spec_stale.clear();
   keep_shared(h, p);
   h->fac = std::move(f);
   if ((rc = upload_factor(h))) return rc;
@@ -1337,6 +1459,8 @@ int admm_solve_begin(admm_handle* h, const double* z0, const double* y0) {
   const bool use_graph = (h->opt.flags & ADMM_FLAG_GRAPH) != 0;
   if (use_graph && !h->graph_exec[0] && (rc = capture_iterations(h))) return rc;
   h->rho_updates = 0;
+  h->spec_hits = h->spec_misses = 0;
+  spec_start(h);                               // adaptive rule: factorise rho tau and rho / tau while the GPU iterates
   h->solve_it = 0;
   h->solve_nconv = 0;
   h->mixed_iters = 0;
@@ -1418,10 +1542,12 @@ int admm_solve_adapt(admm_handle* h, double R, double S, int32_t* changed) {
     int rc = set_rho_internal(h, rho_new);
     if (rc == ADMM_ERR_NUMERIC) {          // refused (conditioning guard / factorisation): keep rho, stop adapting
       h->rho_updates = h->opt.adapt_max;
+      spec_start(h);
       return ADMM_OK;
     }
     if (rc) return rc;
     ++h->rho_updates;
+    spec_start(h);                         // the candidates of the new rho
     if (changed) *changed = 1;
   }
   return ADMM_OK;
@@ -1431,6 +1557,8 @@ int admm_solve_end(admm_handle* h, admm_info* info) {
   if (!h) return fail(ADMM_ERR_INVALID, "NULL handle");
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipGetLastError());
+  if (std::getenv("ADMM_SPEC_DEBUG"))
+    std::fprintf(stderr, "[admm] rho changes served by a background / kept factor: %d, factorised on demand: %d\n", h->spec_hits, h->spec_misses);
   HIP_TRY(hipStreamSynchronize(h->stream));
   h->iters_run = h->solve_it;
   if (h->opt.precision_mode == ADMM_PRECISION_MIXED) {

@@ -19,13 +19,14 @@ using Mat = std::vector<double>;  // row-major
 // folded operators of each stage, the segment transfer matrices, the MFMA fragment packing -- is independent per stage or
 // per segment: those loops run on a few host threads (ADMM_FACTOR_THREADS, default min(cores, 16)).  Every stage is
 // computed by exactly one thread with the same arithmetic, so the result does not depend on the thread count.
+thread_local int g_thread_cap = 0;      // set_factor_thread_cap(): limit for factorisations started from this thread
 int factor_threads() {
   static const int n = [] {
     const char* e = std::getenv("ADMM_FACTOR_THREADS");
     int v = e ? std::atoi(e) : (int)std::thread::hardware_concurrency();
     return v < 1 ? 1 : (v > 16 ? 16 : v);
   }();
-  return n;
+  return (g_thread_cap > 0 && g_thread_cap < n) ? g_thread_cap : n;
 }
 #ifdef ADMM_FACTOR_TIMING          // phase timing on stderr (build with -DADMM_FACTOR_TIMING; tools only)
 }  // namespace
@@ -757,6 +758,8 @@ void build_mfma(Factor& f, int mode) {
 }
 
 }  // namespace
+
+void set_factor_thread_cap(int cap) { g_thread_cap = cap; }
 
 int factorise(const admm_problem& p, double rho, int segments, Factor& f, std::string& err, int mfma_mode) {
   if (mfma_mode < 0 || mfma_mode > 2) { err = "mfma_mode must be 0, 1 or 2"; return ADMM_ERR_INVALID; }

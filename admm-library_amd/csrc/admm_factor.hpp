@@ -106,4 +106,9 @@ inline int rec_be_size(int n, int m) { return rec_be_layout(n, m).SIZE; }
 // mfma_mode: 0 = no MFMA records; 1 / 2 = also pack the MFMA form, mixed / fp64 (needs mfma_dims(n, m)).
 int factorise(const admm_problem& p, double rho, int segments, Factor& out, std::string& err, int mfma_mode = 0);
 
+// The per-stage / per-segment loops of factorise run on host threads (ADMM_FACTOR_THREADS, default min(cores, 16)); this
+// caps the count for factorisations started from the calling thread (0 = no cap).  Used by the background refactors of
+// the adaptive-rho rule so that they leave cores to the thread that launches kernels.
+void set_factor_thread_cap(int cap);
+
 }  // namespace admm

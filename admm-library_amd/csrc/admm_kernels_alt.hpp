@@ -260,6 +260,9 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY(NX + NU, HASQ, SOC) 
           double wh = wv[r];
           if (RELAX) wh = fma(alpha, wv[r], (1.0 - alpha) * zo);
           const double vn = wh + yo;
+#ifdef ADMM_ABLATE_NOSTORE          // timing only: a form that also skipped WRITING v+ of the unbounded state rows
+          if (!(XFREE && r >= NU))
+#endif
           vv.store<ADMM_ALT_STORE_AUX>(vn, lb_st, r0 + r * PB);
           const double zn = fmin(fmax(ball ? vn * cs_new : vn, lo_r), hi_r);
           const double yn = vn - zn;
@@ -478,6 +481,9 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY(NX + NU, HASQ, SOC) 
             double wh = wv[r];
             if (RELAX) wh = fma(alpha, wv[r], (1.0 - alpha) * zo);
             const double vn = wh + yo;
+#ifdef ADMM_ABLATE_NOSTORE          // timing only: a form that also skipped WRITING v+ of the unbounded state rows
+            if (!(XFREE && r >= NU))
+#endif
             vv.store<ADMM_ALT_STORE_AUX>(vn, lb_st, r0 + r * PB);
             const double zn = fmin(fmax(ball ? vn * cs_new : vn, lo), hi);
             const double yn = vn - zn;

@@ -413,3 +413,50 @@ def test_clamped_lanes_never_store(gpu, batch):
     for a, b in ((w, ref["w"]), (z, ref["z"]), (y, ref["y"])):
         assert np.abs(a - b).max() <= TOL * max(1.0, np.abs(b).max())
     assert np.abs(z[-1] - ref["z"][-1]).max() <= TOL          # the column the clamped lanes alias
+
+
+@pytest.mark.parametrize("tau", [2.0, 3.0], ids=["tau2", "tau3"])
+def test_background_refactor_is_the_synchronous_one(gpu, tau, monkeypatch):
+    """The adaptive rule's rho changes are served by factorisations run ahead on host threads (and by the kept factor of
+    the rho just left): same iterates, BIT for bit, same rho trajectory and counts as with ADMM_NO_SPECULATE (refactor
+    on demand) -- tau = 3 makes (rho tau) / tau differ from rho in the last bit, so a kept factor must not be reused."""
+    p = pkg.cw_rendezvous(N=200, batch=12)
+    kw = dict(rho=0.05, eps_abs=1e-6, eps_rel=1e-6, max_iter=3000, check_interval=10, adapt_interval=20, adapt_tau=tau)
+    out = []
+    for spec in (True, False):
+        if spec:
+            monkeypatch.delenv("ADMM_NO_SPECULATE", raising=False)
+        else:
+            monkeypatch.setenv("ADMM_NO_SPECULATE", "1")
+        with pkg.Solver(p, pkg.Options(**kw)) as s:
+            info = s.solve()
+            zero = np.zeros((p.batch, p.L))
+            info2 = s.solve(z0=zero, y0=zero)          # second solve on the handle: starts from the rho the first ended at
+            out.append((info.iters_run, info.rho_updates, info.rho, info2.iters_run, info2.rho_updates, info2.rho) + s.get())
+    assert out[0][1] >= 2
+    assert out[0][:6] == out[1][:6]
+    for a, b in zip(out[0][6:], out[1][6:]):
+        np.testing.assert_array_equal(a, b)
+    ref = oc.solve(p, **kw)
+    assert out[0][0] == ref["iters_run"] and out[0][1] == ref["rho_updates"] and out[0][2] == ref["rho"]
+
+
+def test_background_refactor_survives_problem_updates_and_early_release(gpu):
+    """A handle whose background factorisations are still running is (a) given new problem data -- they are joined and
+    dropped, the solve of the new problem equals the oracle's -- and (b) released right after admm_solve_begin."""
+    p1 = pkg.cw_formation(N=400, batch=3)
+    p2 = pkg.cw_formation(N=400, batch=3, u_max=0.15)
+    kw = dict(rho=0.05, eps_abs=1e-6, eps_rel=1e-6, max_iter=600, check_interval=10, adapt_interval=20)
+    ref = oc.solve(p2, **kw)
+    with pkg.Solver(p1, pkg.Options(**kw)) as s:
+        s.solve_begin()                      # starts the two candidate factorisations
+        s.update_problem(p2)                 # ... which read the problem copy this call replaces
+        zero = np.zeros((p2.batch, p2.L))
+        info = s.solve(z0=zero, y0=zero)
+        w, z, y = s.get()
+    assert info.iters_run == ref["iters_run"] and info.rho == ref["rho"] and info.rho_updates == ref["rho_updates"]
+    for a, b in ((w, ref["w"]), (z, ref["z"]), (y, ref["y"])):
+        assert np.abs(a - b).max() <= TOL * max(1.0, np.abs(b).max())
+    s = pkg.Solver(p1, pkg.Options(**kw))
+    s.solve_begin()
+    s.close()
