@@ -1168,16 +1168,26 @@ static void spec_start(admm_handle* h) {
     sp->rc = INT32_MIN;                                     // "not finished" (read only after join, or by spec_reap)
     SpecFactor* s = sp.get();
     const admm_handle* hc = h;
+    try {
     s->th = std::thread([hc, s] {
-      admm::set_factor_thread_cap(6);                       // two of these run beside the thread that launches kernels
+      admm::set_factor_thread_cap(8);                       // two of these run beside the thread that launches kernels
       const admm_problem p = shared_problem(hc);
-      admm::Factor f;
-      std::string err;
-      const int rc = admm::factorise(p, s->rho, hc->S, f, err, hc->mfma_mode);
-      s->f = std::move(f);
-      s->err = std::move(err);
+      int rc;
+      try {
+        admm::Factor f;
+        std::string err;
+        rc = admm::factorise(p, s->rho, hc->S, f, err, hc->mfma_mode);
+        s->f = std::move(f);
+        s->err = std::move(err);
+      } catch (...) {
+        rc = ADMM_ERR_ALLOC;
+        s->err = "background factorisation ran out of memory";
+      }
       __atomic_store_n(&s->rc, rc, __ATOMIC_RELEASE);
     });
+    } catch (...) {                                         // no thread to be had: this candidate is factorised on demand
+      continue;
+    }
     h->spec.push_back(std::move(sp));
   }
 }
@@ -1219,7 +1229,8 @@ static int set_rho_internal(admm_handle* h, double rho_new) {
     std::fprintf(stderr, "[admm] set_rho %-22s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
     t0 = t1;
   };
-  if (std::unique_ptr<SpecFactor> sp = spec_take(h, rho_new)) {   // factorised in the background (or kept from before)
+  std::unique_ptr<SpecFactor> sp = spec_take(h, rho_new);
+  if (sp && sp->rc != ADMM_ERR_ALLOC) {                           // factorised in the background (or kept from before)
     rc = sp->rc;
     err = std::move(sp->err);
     f = std::move(sp->f);

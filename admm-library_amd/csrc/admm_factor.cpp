@@ -53,9 +53,16 @@ void parallel_for(int count, F&& fn) {          // fn(begin, end) over a partiti
   if (nt <= 1) { fn(0, count); return; }
   std::vector<std::thread> th;
   th.reserve(nt - 1);
-  for (int t = 1; t < nt; ++t)
-    th.emplace_back([&fn, t, nt, count] { fn((int)((int64_t)count * t / nt), (int)((int64_t)count * (t + 1) / nt)); });
+  int started = 1;                               // slices [0, started) have an owner (slice 0 = this thread)
+  try {
+    for (int t = 1; t < nt; ++t) {
+      th.emplace_back([&fn, t, nt, count] { fn((int)((int64_t)count * t / nt), (int)((int64_t)count * (t + 1) / nt)); });
+      started = t + 1;
+    }
+  } catch (...) {                                // no more threads to be had: the remaining slices run here
+  }
   fn(0, count / nt);
+  for (int t = started; t < nt; ++t) fn((int)((int64_t)count * t / nt), (int)((int64_t)count * (t + 1) / nt));
   for (auto& x : th) x.join();
 }
 
