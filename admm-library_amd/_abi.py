@@ -12,7 +12,7 @@ import numpy as np
 
 from .problems import Problem
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 ADMM_OK = 0
 STATUS_NAMES = {0: "ADMM_OK", 1: "ADMM_ERR_INVALID", 2: "ADMM_ERR_UNSUPPORTED",

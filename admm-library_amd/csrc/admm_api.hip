@@ -99,6 +99,9 @@ struct admm_handle {
   double *Ad = nullptr, *Bd = nullptr, *Kd = nullptr, *Sd = nullptr, *lod = nullptr, *hid = nullptr;
   double *Qd = nullptr, *Rd = nullptr, *QNd = nullptr;
   int* pfail = nullptr;
+  // per-QP rho (every QP of a per-instance problem has its own factor, so the adaptive rule runs QP by QP on the device)
+  double *rho_d = nullptr, *cscale_d = nullptr;     // [pitch]
+  int *nupd_d = nullptr, *todo_d = nullptr, *nchanged_d = nullptr;
   size_t stage_rows = 0;         // rows the staging buffer holds (L, or N n^2 for the per-instance upload of A)
   bool alt = false;              // the alternating kernels exist for this problem and are enabled
   // what the last kernel left behind for the next x-update:
@@ -160,7 +163,8 @@ admm::PLaunch plaunch_of(const admm_handle* h) {
   l.stream = h->stream;
   l.n = h->n; l.m = h->m; l.N = h->N; l.pitch = h->pitch; l.batch = h->batch;
   l.has_q = h->has_q; l.pbounds = h->pbounds;
-  l.rho = h->opt.rho; l.alpha = h->opt.alpha;
+  l.alpha = h->opt.alpha;
+  l.rhov = h->rho_d; l.todo = nullptr;
   l.Ad = h->Ad; l.Bd = h->Bd; l.Q = h->Qd; l.R = h->Rd; l.QN = h->QNd; l.Kd = h->Kd; l.Sd = h->Sd; l.fail = h->pfail;
   l.lo = h->pbounds ? h->lod : h->lo; l.hi = h->pbounds ? h->hid : h->hi;
   l.z = h->z; l.y = h->y; l.q = h->q; l.x0 = h->x0; l.v = h->v; l.w = h->w; l.dbuf = h->dbuf; l.part = h->part;
@@ -219,6 +223,7 @@ admm::FinArgs fin_args(const admm_handle* h, int it, int nchunks) {
   fa.part = h->part; fa.resid = h->resid; fa.status = h->status; fa.iters = h->iters; fa.nconv = h->nconv;
   fa.rho = h->opt.rho; fa.eps_abs = h->opt.eps_abs; fa.eps_rel = h->opt.eps_rel; fa.sqrtL = std::sqrt((double)h->L);
   fa.nchunks = nchunks; fa.batch = h->batch; fa.it = it;
+  fa.rhov = h->pinst ? h->rho_d : nullptr;
   if (h->mixed_phase1 && it > 0) {              // fp32 phase of a MIXED solve: raised tolerances, scratch status
     fa.eps_abs = std::max(fa.eps_abs, 1e-4);
     fa.eps_rel = std::max(fa.eps_rel, 1e-4);
@@ -514,6 +519,11 @@ void release(admm_handle* h) {
     for (auto b : pb)
       if (*b) { (void)hipFree(*b); *b = nullptr; }
     if (h->pfail) { (void)hipFree(h->pfail); h->pfail = nullptr; }
+    if (h->rho_d) { (void)hipFree(h->rho_d); h->rho_d = nullptr; }
+    if (h->cscale_d) { (void)hipFree(h->cscale_d); h->cscale_d = nullptr; }
+    int** ib[] = {&h->nupd_d, &h->todo_d, &h->nchanged_d};
+    for (auto b : ib)
+      if (*b) { (void)hipFree(*b); *b = nullptr; }
   }
   if (h->recMF) { (void)hipFree(h->recMF); h->recMF = nullptr; }
   if (h->recMB) { (void)hipFree(h->recMB); h->recMB = nullptr; }
@@ -630,16 +640,25 @@ bool problem_has_soc(const admm_problem* p) {
 
 // ---- per-instance dynamics ----
 // Riccati factorisation of every QP on the device; ADMM_ERR_NUMERIC if some S_k is not positive definite.
-int pinst_factor(admm_handle* h, double rho) {
+// `only_marked`: refactor the QPs marked in todo_d (per-QP adaptive rule); rho comes from rho_d either way.
+int pinst_factor(admm_handle* h, bool only_marked = false) {
   HIP_TRY(hipMemsetAsync(h->pfail, 0, sizeof(int), h->stream));
   admm::PLaunch l = plaunch_of(h);
-  l.rho = rho;
+  l.todo = only_marked ? h->todo_d : nullptr;
   if (!admm::launch_pinst(l, admm::PKernel::FACTOR, false)) return fail(ADMM_ERR_UNSUPPORTED, "no per-instance kernel for this (n, m)");
   HIP_TRY(hipGetLastError());
   int bad = 0;
   HIP_TRY(hipMemcpyAsync(&bad, h->pfail, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   if (bad) return fail(ADMM_ERR_NUMERIC, "R + rho I + B'PB is not positive definite for some QP");
+  return ADMM_OK;
+}
+
+// every QP's rho := rho
+int pinst_fill_rho(admm_handle* h, double rho) {
+  std::vector<double> r(h->pitch, rho);
+  HIP_TRY(hipMemcpyAsync(h->rho_d, r.data(), sizeof(double) * r.size(), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
   return ADMM_OK;
 }
 
@@ -710,6 +729,7 @@ int setup_pinst(admm_handle* h, const admm_problem* p) {
   if (h->pbounds) { PD(h->lod, L * P); PD(h->hid, L * P); }
   PD(h->Qd, (size_t)n * n); PD(h->Rd, (size_t)m * m); PD(h->QNd, (size_t)n * n);
   PD(h->pfail, 1); PD(h->status, P); PD(h->iters, P); PD(h->nconv, 1);
+  PD(h->rho_d, P); PD(h->cscale_d, P); PD(h->nupd_d, P); PD(h->todo_d, P); PD(h->nchanged_d, 1);
   h->stage_rows = std::max(L, (size_t)N * n * n);
   if ((rc = dalloc(&h->stage, h->stage_rows * (size_t)h->batch))) return rc;
 #undef PD
@@ -717,7 +737,8 @@ int setup_pinst(admm_handle* h, const admm_problem* p) {
   if ((rc = pinst_upload(h, p))) return rc;
   if ((rc = upload_transposed(h, p->x0, h->x0, n))) return rc;
   if (h->has_q && (rc = upload_transposed(h, p->q, h->q, (int)L))) return rc;
-  if ((rc = pinst_factor(h, o.rho))) return rc;
+  if ((rc = pinst_fill_rho(h, o.rho))) return rc;
+  if ((rc = pinst_factor(h))) return rc;
   HIP_TRY(hipStreamSynchronize(h->stream));
   return ADMM_OK;
 }
@@ -1197,20 +1218,33 @@ static void spec_start(admm_handle* h) {
 // iteration produced (bit-identical to the oracle); the next iteration reads z, y directly.
 static int set_rho_internal(admm_handle* h, double rho_new) {
   if (!(rho_new > 0.0) || !std::isfinite(rho_new)) return fail(ADMM_ERR_INVALID, "rho must be positive and finite");
-  if (rho_new == h->opt.rho) return ADMM_OK;
+  if (rho_new == h->opt.rho && !h->pinst) return ADMM_OK;     // (per-instance: the QPs' own rho may have moved away from it)
   if (h->pinst) {
+    // every QP's rho := rho_new (the per-QP adaptive rule may have moved them apart): y_b *= rho_b / rho_new
     int rc;
     if ((rc = ensure_w(h))) return rc;          // w of the last x-update must be rebuilt with the OLD factor
     if ((rc = ensure_zy(h))) return rc;
-    const double c = h->opt.rho / rho_new;
-    hipLaunchKernelGGL(admm::scale_kernel, dim3(2048), dim3(256), 0, h->stream, h->y, c, (size_t)h->L * h->pitch / 2);
+    const size_t P = h->pitch;
+    std::vector<double> old(P), c(P);
+    HIP_TRY(hipMemcpyAsync(old.data(), h->rho_d, sizeof(double) * P, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    std::vector<int> all(P, 1);
+    for (size_t b = 0; b < P; ++b) c[b] = old[b] / rho_new;
+    HIP_TRY(hipMemcpyAsync(h->cscale_d, c.data(), sizeof(double) * P, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->todo_d, all.data(), sizeof(int) * P, hipMemcpyHostToDevice, h->stream));
+    admm::launch_padapt_scale(h->stream, h->y, h->cscale_d, h->todo_d, h->L, h->pitch);
     HIP_TRY(hipGetLastError());
     h->zy_valid = true;
     h->v_valid = false;
-    if ((rc = pinst_factor(h, rho_new))) {        // refactor in place failed: restore the old factor and the dual
-      hipLaunchKernelGGL(admm::scale_kernel, dim3(2048), dim3(256), 0, h->stream, h->y, 1.0 / c, (size_t)h->L * h->pitch / 2);
+    if ((rc = pinst_fill_rho(h, rho_new))) return rc;
+    if ((rc = pinst_factor(h))) {                 // refactor in place failed: restore the old factors and the dual
       std::string keep = g_err;
-      (void)pinst_factor(h, h->opt.rho);
+      for (size_t b = 0; b < P; ++b) c[b] = rho_new / old[b];
+      (void)hipMemcpyAsync(h->cscale_d, c.data(), sizeof(double) * P, hipMemcpyHostToDevice, h->stream);
+      admm::launch_padapt_scale(h->stream, h->y, h->cscale_d, h->todo_d, h->L, h->pitch);
+      (void)hipMemcpyAsync(h->rho_d, old.data(), sizeof(double) * P, hipMemcpyHostToDevice, h->stream);
+      (void)hipStreamSynchronize(h->stream);
+      (void)pinst_factor(h);
       g_err = keep;
       return rc;
     }
@@ -1304,7 +1338,7 @@ int admm_update_problem(admm_handle* h, const admm_problem* p) {
     if ((rc = pinst_upload(h, p))) return rc;
     if ((rc = upload_transposed(h, p->x0, h->x0, h->n))) return rc;
     if (h->has_q && (rc = upload_transposed(h, p->q, h->q, h->L))) return rc;
-    return pinst_factor(h, h->opt.rho);
+    return pinst_factor(h);                      // every QP with the rho it has
   }
   admm::Factor f;
   std::string err;
@@ -1470,6 +1504,7 @@ int admm_solve_begin(admm_handle* h, const double* z0, const double* y0) {
   const bool use_graph = (h->opt.flags & ADMM_FLAG_GRAPH) != 0;
   if (use_graph && !h->graph_exec[0] && (rc = capture_iterations(h))) return rc;
   h->rho_updates = 0;
+  if (h->pinst) HIP_TRY(hipMemsetAsync(h->nupd_d, 0, sizeof(int) * P, h->stream));
   h->spec_hits = h->spec_misses = 0;
   spec_start(h);                               // adaptive rule: factorise rho tau and rho / tau while the GPU iterates
   h->solve_it = 0;
@@ -1542,10 +1577,33 @@ int admm_solve_adapt(admm_handle* h, double R, double S, int32_t* changed) {
   HIP_TRY(hipSetDevice(h->device));
   if (changed) *changed = 0;
   const int it = h->solve_it;
-  if (!(h->opt.adapt_interval > 0 && it % h->opt.adapt_interval == 0 && h->rho_updates < h->opt.adapt_max &&
+  if (!(h->opt.adapt_interval > 0 && it % h->opt.adapt_interval == 0 && (h->pinst || h->rho_updates < h->opt.adapt_max) &&
         it < h->opt.max_iter))
-    return ADMM_OK;
+    return ADMM_OK;                      // (per-instance: adapt_max is counted per QP, on the device)
   const double mu2 = h->opt.adapt_mu * h->opt.adapt_mu;
+  if (h->pinst) {
+    // Per-instance dynamics: the rule runs QP by QP on the device (csrc/admm_pinst.hpp, padapt_kernel); R and S -- the
+    // batch sums of the shared-factor rule -- are not used, so a sharded solve needs no exchange for it.
+    int rc;
+    HIP_TRY(hipMemsetAsync(h->nchanged_d, 0, sizeof(int), h->stream));
+    admm::launch_padapt(h->stream, h->resid, h->status, h->rho_d, h->nupd_d, h->todo_d, h->cscale_d, h->nchanged_d, mu2,
+                        h->opt.adapt_tau, h->opt.adapt_max, h->pitch, h->batch);
+    HIP_TRY(hipGetLastError());
+    int nchanged = 0;
+    HIP_TRY(hipMemcpyAsync(&nchanged, h->nchanged_d, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (!nchanged) return ADMM_OK;
+    if ((rc = ensure_w(h))) return rc;            // w of the last x-update is rebuilt with the OLD factors (rho is not used)
+    if ((rc = ensure_zy(h))) return rc;
+    admm::launch_padapt_scale(h->stream, h->y, h->cscale_d, h->todo_d, h->L, h->pitch);
+    HIP_TRY(hipGetLastError());
+    h->zy_valid = true;
+    h->v_valid = false;
+    if ((rc = pinst_factor(h, /*only_marked=*/true))) return rc;
+    h->rho_updates += nchanged;
+    if (changed) *changed = 1;
+    return ADMM_OK;
+  }
   double rho_new = h->opt.rho;
   if (R > mu2 * S) rho_new = h->opt.rho * h->opt.adapt_tau;
   else if (S > mu2 * R) rho_new = h->opt.rho / h->opt.adapt_tau;
@@ -1592,6 +1650,11 @@ int admm_solve_end(admm_handle* h, admm_info* info) {
     info->max_s = ms;
     info->solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - h->solve_t0).count();
     info->rho = h->opt.rho;
+    if (h->pinst) {                       // per-QP rho: the largest in force (admm_get_rho returns all of them)
+      std::vector<double> r(h->pitch);
+      HIP_TRY(hipMemcpy(r.data(), h->rho_d, sizeof(double) * r.size(), hipMemcpyDeviceToHost));
+      info->rho = *std::max_element(r.begin(), r.begin() + h->batch);
+    }
     info->rho_updates = h->rho_updates;
     info->mixed_iters = h->opt.precision_mode == ADMM_PRECISION_MIXED ? h->mixed_iters : 0;
   }
@@ -1784,6 +1847,18 @@ int admm_profile(admm_handle* h, int32_t iters, int32_t residuals, int32_t fused
   }
   for (auto& e : ev) (void)hipEventDestroy(e);
   return rc;
+}
+
+int admm_get_rho(admm_handle* h, double* rho) {
+  if (!h || !rho) return fail(ADMM_ERR_INVALID, "NULL argument");
+  HIP_TRY(hipSetDevice(h->device));
+  if (!h->pinst) {
+    for (int b = 0; b < h->batch; ++b) rho[b] = h->opt.rho;
+    return ADMM_OK;
+  }
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipMemcpy(rho, h->rho_d, sizeof(double) * h->batch, hipMemcpyDeviceToHost));
+  return ADMM_OK;
 }
 
 int admm_get_geometry(admm_handle* h, int32_t* pitch, int32_t* segs, int32_t* zrows, int32_t* zchunks) {

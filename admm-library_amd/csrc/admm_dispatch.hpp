@@ -48,7 +48,9 @@ struct PLaunch {
   hipStream_t stream;
   int n, m, N, pitch, batch;
   bool has_q, vform, resid, pbounds;   // vform: state read from v; pbounds: lo / hi per instance ([k][n+m][pitch])
-  double rho, alpha;
+  double alpha;
+  const double* rhov;                  // rho per QP [pitch] (all equal unless the per-QP adaptive rule has moved them)
+  const int* todo;                     // FACTOR only: refactor the marked QPs (NULL = all)
   const double *Ad, *Bd, *Q, *R, *QN;  // Q, R, QN: shared, row-major, on the device
   double *Kd, *Sd;
   int* fail;
@@ -58,6 +60,9 @@ struct PLaunch {
 };
 enum class PKernel { FACTOR, XB, XF, XFZ };
 bool launch_pinst(const PLaunch& l, PKernel k, bool query_only);
+void launch_padapt(hipStream_t stream, const double* resid, const int* status, double* rhov, int* nupd, int* todo,
+                   double* cscale, int* nchanged, double mu2, double tau, int adapt_max, int pitch, int batch);
+void launch_padapt_scale(hipStream_t stream, double* y, const double* cscale, const int* todo, int rows, int pitch);
 void launch_pv_to_zy(hipStream_t stream, const double* v, double* z, double* y, const double* lo, const double* hi, size_t count);
 const char* dims_pinst();
 // " (n,m) (n,m) ..." of a group, for error messages

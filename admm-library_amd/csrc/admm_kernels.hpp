@@ -518,6 +518,7 @@ struct FinArgs {
   int *status, *iters, *nconv;
   double rho, eps_abs, eps_rel, sqrtL;
   int nchunks, batch, it;
+  const double* rhov;     // per-QP rho [pitch] (per-instance dynamics), or NULL: rho above for every QP
 };
 
 template <int GROUPS>
@@ -525,6 +526,8 @@ __device__ __forceinline__ void finalize_body(double (*red)[5][FIN_COLS], const 
   const int lane = threadIdx.x & (FIN_COLS - 1), g = threadIdx.x / FIN_COLS;
   const int col = block * FIN_COLS + lane;      // pitch is a multiple of 64
   const size_t P = (size_t)pitch;
+  double rho = fa.rho;
+  if (fa.rhov != nullptr && g == 0) rho = fa.rhov[col];
   double a[5] = {0, 0, 0, 0, 0};
   for (int c = g; c < fa.nchunks; c += GROUPS) {
     const size_t o = (size_t)c * 5 * P + col;
@@ -542,8 +545,8 @@ __device__ __forceinline__ void finalize_body(double (*red)[5][FIN_COLS], const 
     for (int gg = 1; gg < GROUPS; ++gg) t += red[gg][v][lane];
     a[v] = t;
   }
-  const double r = sqrt(a[0]), s = fa.rho * sqrt(a[1]);
-  const double nw = sqrt(a[2]), nz = sqrt(a[3]), ny = fa.rho * sqrt(a[4]);
+  const double r = sqrt(a[0]), s = rho * sqrt(a[1]);
+  const double nw = sqrt(a[2]), nz = sqrt(a[3]), ny = rho * sqrt(a[4]);
   fa.resid[0 * P + col] = r;
   fa.resid[1 * P + col] = s;
   fa.resid[2 * P + col] = nw;

@@ -22,13 +22,13 @@ void launch_dim(const PLaunch& l, PKernel k) {
   const bool relax = l.alpha != 1.0;
   switch (k) {
     case PKernel::FACTOR:
-      hipLaunchKernelGGL((pfactor_kernel<NX, NU>), grid, block, 0, l.stream, l.Ad, l.Bd, l.Q, l.R, l.QN, l.rho, l.Kd, l.Sd,
+      hipLaunchKernelGGL((pfactor_kernel<NX, NU>), grid, block, 0, l.stream, l.Ad, l.Bd, l.Q, l.R, l.QN, l.rhov, l.todo, l.Kd, l.Sd,
                          l.fail, l.N, l.pitch, l.batch);
       break;
     case PKernel::XB: {
 #define XB(HQ, VF, PB_)                                                                                               \
   hipLaunchKernelGGL((pxb_kernel<NX, NU, HQ, VF, PB_>), grid, block, 0, l.stream, l.vform ? l.v : l.z, l.y, l.q, l.Ad, \
-                     l.Bd, l.Kd, l.Sd, l.lo, l.hi, l.dbuf, l.rho, l.N, l.pitch)
+                     l.Bd, l.Kd, l.Sd, l.lo, l.hi, l.dbuf, l.rhov, l.N, l.pitch)
 #define XB2(HQ, VF) do { if (l.pbounds) XB(HQ, VF, true); else XB(HQ, VF, false); } while (0)
       if (l.has_q) { if (l.vform) XB2(true, true); else XB2(true, false); }
       else         { if (l.vform) XB2(false, true); else XB2(false, false); }
@@ -67,6 +67,16 @@ bool launch_pinst(const PLaunch& l, PKernel k, bool query_only) {
   ADMM_PINST_DIMS(X)
 #undef X
   return false;
+}
+
+void launch_padapt(hipStream_t stream, const double* resid, const int* status, double* rhov, int* nupd, int* todo,
+                   double* cscale, int* nchanged, double mu2, double tau, int adapt_max, int pitch, int batch) {
+  hipLaunchKernelGGL(padapt_kernel, dim3((pitch + 255) / 256), dim3(256), 0, stream, resid, status, rhov, nupd, todo, cscale,
+                     nchanged, mu2, tau, adapt_max, pitch, batch);
+}
+
+void launch_padapt_scale(hipStream_t stream, double* y, const double* cscale, const int* todo, int rows, int pitch) {
+  hipLaunchKernelGGL(padapt_scale_kernel, dim3((pitch + 255) / 256, 64), dim3(256), 0, stream, y, cscale, todo, rows, pitch);
 }
 
 void launch_pv_to_zy(hipStream_t stream, const double* v, double* z, double* y, const double* lo, const double* hi, size_t count) {

@@ -36,10 +36,13 @@ constexpr int PI_THREADS = 64;      // one wave per workgroup: small batches sti
 template <int NX, int NU>
 __global__ __launch_bounds__(PI_THREADS) void pfactor_kernel(
     const double* __restrict__ Ad, const double* __restrict__ Bd, const double* __restrict__ Qm,
-    const double* __restrict__ Rm, const double* __restrict__ QNm, double rho,
-    double* __restrict__ Kd, double* __restrict__ Sd, int* __restrict__ fail, int N, int pitch, int batch) {
+    const double* __restrict__ Rm, const double* __restrict__ QNm, const double* __restrict__ rhov,
+    const int* __restrict__ todo, double* __restrict__ Kd, double* __restrict__ Sd, int* __restrict__ fail, int N, int pitch,
+    int batch) {
   const int col = blockIdx.x * PI_THREADS + threadIdx.x;
   if (col >= pitch) return;
+  if (todo && !todo[col]) return;           // per-QP adaptive rho: only the QPs whose rho has just changed are refactored
+  const double rho = rhov[col];             // every QP carries its own rho (all equal unless the adaptive rule is on)
   const size_t P_ = (size_t)pitch;
   const bool real = col < batch;            // pad columns hold zero dynamics: factor them like the rest (finite), never flag them
   double P[NX][NX];
@@ -239,11 +242,12 @@ __global__ __launch_bounds__(PI_THREADS) void pxb_kernel(
     const double* __restrict__ z, const double* __restrict__ y, const double* __restrict__ q,
     const double* __restrict__ Ad, const double* __restrict__ Bd, const double* __restrict__ Kd,
     const double* __restrict__ Sd, const double* __restrict__ lo, const double* __restrict__ hi,
-    double* __restrict__ dbuf, double rho, int N, int pitch) {
+    double* __restrict__ dbuf, const double* __restrict__ rhov, int N, int pitch) {
   constexpr int NB = NX + NU;
   typedef PiStage<NX, NU, true, HASQ, !VFORM, PB, VFORM, false> Stage;
   const int col = blockIdx.x * PI_THREADS + threadIdx.x;
   if (col >= pitch) return;
+  const double rho = rhov[col];
   const size_t P_ = (size_t)pitch;
   double t[NX];
 #pragma unroll
@@ -393,6 +397,49 @@ __global__ __launch_bounds__(PI_THREADS) void pxfz_kernel(
 }
 
 // v -> (z, y) with per-instance bounds (read-out, mode switches)
+// ---- per-QP adaptive rho: residual balancing QP by QP, entirely on the device ----
+// With per-instance dynamics nothing is shared, so the rule of DESIGN.md §2.6 applies to each QP alone -- exactly what
+// the one-QP oracle does: at a checked iteration that is a multiple of adapt_interval, a QP that has not converged and
+// has changed rho fewer than adapt_max times compares R = r^2 with S = s^2:  R > mu^2 S -> rho tau;  S > mu^2 R -> rho / tau.
+// The kernel records the QPs that change (todo), the factor rho_old / rho_new their scaled dual is multiplied by, and
+// how many changed; padapt_scale_kernel rescales y, the masked pfactor_kernel refactors those QPs.
+static __global__ __launch_bounds__(256) void padapt_kernel(
+    const double* __restrict__ resid, const int* __restrict__ status, double* __restrict__ rhov, int* __restrict__ nupd,
+    int* __restrict__ todo, double* __restrict__ cscale, int* __restrict__ nchanged, double mu2, double tau, int adapt_max,
+    int pitch, int batch) {
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= pitch) return;
+  int change = 0;
+  double c = 1.0;
+  if (col < batch && !status[col] && nupd[col] < adapt_max) {
+    const double r = resid[col], s_ = resid[(size_t)pitch + col];
+    const double R = r * r, S = s_ * s_;
+    const double rho = rhov[col];
+    double rho_new = rho;
+    if (R > mu2 * S) rho_new = rho * tau;
+    else if (S > mu2 * R) rho_new = rho / tau;
+    if (rho_new != rho) {
+      change = 1;
+      c = rho / rho_new;
+      rhov[col] = rho_new;
+      nupd[col] += 1;
+    }
+  }
+  todo[col] = change;
+  cscale[col] = c;
+  if (change) atomicAdd(nchanged, 1);
+}
+
+// y[row][col] *= cscale[col] for the columns marked in todo (cscale = 1 elsewhere: those columns are not touched, so
+// their y keeps its bits)
+static __global__ __launch_bounds__(256) void padapt_scale_kernel(double* __restrict__ y, const double* __restrict__ cscale,
+                                                                  const int* __restrict__ todo, int rows, int pitch) {
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= pitch || !todo[col]) return;
+  const double c = cscale[col];
+  for (int r = blockIdx.y; r < rows; r += gridDim.y) y[(size_t)r * pitch + col] *= c;
+}
+
 static __global__ __launch_bounds__(256) void pv_to_zy_kernel(const double* __restrict__ v, double* __restrict__ z,
                                                               double* __restrict__ y, const double* __restrict__ lo,
                                                               const double* __restrict__ hi, size_t count) {

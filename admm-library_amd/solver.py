@@ -60,6 +60,7 @@ _SIGNATURES = {
     "admm_get_info": (C.c_int, [C.c_void_p, c_int32_p, c_int32_p, c_double_p, c_double_p]),
     "admm_profile": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, c_double_p]),
     "admm_get_geometry": (C.c_int, [C.c_void_p] + [c_int32_p] * 4),
+    "admm_get_rho": (C.c_int, [C.c_void_p, c_double_p]),
     "admm_free": (None, [C.c_void_p]),
     "admm_last_error": (C.c_char_p, []),
     "admm_abi_version": (C.c_int, []),
@@ -294,6 +295,13 @@ class Solver:
             return {"xb_ms": ms[0], "xscan_ms": ms[1], "xfz_ms": ms[2], "finalize_ms": ms[4], "iter_ms": ms[5]}
         return {"xb_ms": ms[0], "xscan_ms": ms[1], "xf_ms": ms[2], "zdual_ms": ms[3], "finalize_ms": ms[4],
                 "iter_ms": ms[5]}
+
+    def rho_per_qp(self) -> np.ndarray:
+        """rho of every QP: the handle's rho for batch-shared dynamics; with per-instance dynamics each QP's own
+        (the adaptive rule runs per QP there)."""
+        out = np.empty(self.problem.batch)
+        _check(self._lib, self._lib.admm_get_rho(self._h, dptr(out)))
+        return out
 
     def geometry(self):
         v = [C.c_int32() for _ in range(4)]

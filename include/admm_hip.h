@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ADMM_HIP_ABI_VERSION 4
+#define ADMM_HIP_ABI_VERSION 5
 
 typedef enum admm_status {
   ADMM_OK = 0,
@@ -91,7 +91,11 @@ typedef struct admm_options {
    * R = sum r_b^2 and S = sum s_b^2 over the QPs that have not converged yet:
    *   R > adapt_mu^2 S  ->  rho *= adapt_tau;     S > adapt_mu^2 R  ->  rho /= adapt_tau
    * then the scaled dual is rescaled (y *= rho_old / rho_new), the KKT system is refactored on
-   * the host and the records re-uploaded.  adapt_interval = 0 disables (default). */
+   * the host and the records re-uploaded.  adapt_interval = 0 disables (default).
+   * With per-instance dynamics (time_varying = 2) every QP has its own factor, and the rule runs PER QP, on the
+   * device (ABI v5): QP b compares R = r_b^2 with S = s_b^2, its rho, dual rescale and refactor are its own, adapt_max
+   * counts its changes; admm_info.rho is then the largest rho in force, admm_info.rho_updates the number of changes
+   * summed over the batch, and admm_get_rho returns every QP's rho. */
   int32_t adapt_interval; /* iterations between adaptation tests; 0 = fixed rho; must be a multiple of check_interval */
   int32_t adapt_max;      /* at most this many rho changes per admm_solve */
   double adapt_mu;        /* > 1 */
@@ -254,6 +258,10 @@ int admm_get_info(admm_handle* h, int32_t* iters, int32_t* status, double* r, do
  * with z/dual/residual.  `residuals` selects the residual-evaluating kernel
  * forms (+ the finalise kernel). */
 int admm_profile(admm_handle* h, int32_t iters, int32_t residuals, int32_t fused_path, double ms[6]);
+
+/* rho of every QP (batch entries): the handle's rho for batch-shared dynamics, each QP's own with per-instance
+ * dynamics (where the adaptive rule moves them apart; admm_set_rho sets them all).  ABI v5. */
+int admm_get_rho(admm_handle* h, double* rho);
 
 /* Geometry chosen at setup, for roofline accounting: pitch = padded batch,
  * segs = x-update segments, zrows = rows per z-kernel chunk, zchunks. */

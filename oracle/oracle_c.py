@@ -52,7 +52,8 @@ def solve(p: pkg.Problem, rho=0.1, alpha=1.0, eps_abs=1e-6, eps_rel=1e-6, max_it
     """Returns dict(w, z, y, iters_run, iters, status, r, s, rho, rho_updates)."""
     if p.per_instance:
         return _solve_per_instance(p, rho=rho, alpha=alpha, eps_abs=eps_abs, eps_rel=eps_rel, max_iter=max_iter,
-                                   check_interval=check_interval, z0=z0, y0=y0, stop=stop, adapt_interval=adapt_interval)
+                                   check_interval=check_interval, z0=z0, y0=y0, stop=stop, adapt_interval=adapt_interval,
+                                   adapt_max=adapt_max, adapt_mu=adapt_mu, adapt_tau=adapt_tau)
     lib = load()
     if nthreads == 0:
         # never more threads than QPs: idle OpenMP threads spin at every barrier, and on a box whose CPU
@@ -91,12 +92,12 @@ def _one_instance(p: pkg.Problem, b: int) -> pkg.Problem:
                                x0=p.x0[b:b + 1].copy(), q=None if p.q is None else p.q[b:b + 1].copy())
 
 
-def _solve_per_instance(p, z0=None, y0=None, stop=True, adapt_interval=0, **kw):
+def _solve_per_instance(p, z0=None, y0=None, stop=True, **kw):
     """Per-instance dynamics (admm_problem.time_varying = 2): the QPs share nothing, so the oracle for this class IS the
     one-QP oracle above applied QP by QP -- first with the stopping rule (per-QP first-converged iterations), then, as
-    the batch loop of DESIGN.md §2.5 prescribes, for the number of iterations the slowest QP needed."""
-    if adapt_interval:
-        raise NotImplementedError("the oracle for per-instance dynamics has no batch-level adaptive rho")
+    the batch loop of DESIGN.md §2.5 prescribes, for the number of iterations the slowest QP needed.  The adaptive-rho
+    rule is then per QP by construction (R = r_b^2, S = s_b^2 of the one QP; a QP that has converged stops adapting):
+    `rho` and `rho_updates` of the result are arrays over the batch."""
     B, L = p.batch, p.L
     subs = [_one_instance(p, b) for b in range(B)]
     st0 = lambda a, b: None if a is None else np.asarray(a, np.float64).reshape(B, L)[b:b + 1]
@@ -105,7 +106,10 @@ def _solve_per_instance(p, z0=None, y0=None, stop=True, adapt_interval=0, **kw):
     kw2 = dict(kw, max_iter=run)
     fin = [solve(subs[b], z0=st0(z0, b), y0=st0(y0, b), stop=False, nthreads=1, **kw2) for b in range(B)]
     cat = lambda k: np.concatenate([f[k] for f in fin])
-    out = dict(w=cat("w"), z=cat("z"), y=cat("y"), iters_run=run, r=cat("r"), s=cat("s"), rho=kw["rho"], rho_updates=0)
+    out = dict(w=cat("w"), z=cat("z"), y=cat("y"), iters_run=run, r=cat("r"), s=cat("s"),
+               rho=np.array([f["rho"] for f in fin]), rho_updates=np.array([f["rho_updates"] for f in fin]))
+    if not kw.get("adapt_interval"):
+        out["rho"], out["rho_updates"] = kw["rho"], 0
     src = first if stop else fin
     out["iters"] = np.concatenate([f["iters"] for f in src]).astype(np.int32)
     out["status"] = np.concatenate([f["status"] for f in src]).astype(np.int32)

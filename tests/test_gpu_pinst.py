@@ -101,3 +101,52 @@ def test_validation_and_unsupported(gpu):
     with pytest.raises(pkg.AdmmError) as e:
         pkg.Solver(ind, pkg.Options(rho=0.01))
     assert e.value.code == inv["ADMM_ERR_NUMERIC"]
+
+
+@pytest.mark.parametrize("case", [dict(N=30, n=6, m=3, batch=70, seed=31), dict(N=25, n=4, m=2, batch=9, seed=32, instance_bounds=False)],
+                         ids=["6_3_batch70", "4_2_shared_box"])
+@pytest.mark.parametrize("alpha", [1.0, 1.6])
+def test_adaptive_rho_is_per_qp(gpu, case, alpha):
+    """With per-instance dynamics the residual-balancing rule runs QP by QP on the device (padapt_kernel: each QP's own
+    rho, dual rescale and refactor).  Against the one-QP oracle with the same options applied QP by QP: every QP's rho
+    trajectory end point and change count, its first-converged iteration, and the iterates."""
+    p = pkg.random_instances(**case)
+    kw = dict(rho=0.3, alpha=alpha, eps_abs=1e-7, eps_rel=1e-7, max_iter=2000, check_interval=10, adapt_interval=20,
+              adapt_mu=1.5, adapt_tau=2.0, adapt_max=8)
+    ref = oc.solve(p, **kw)
+    assert len(set(ref["rho"].tolist())) >= 3 and ref["rho_updates"].max() >= 3       # the QPs really end at different rho
+    with pkg.Solver(p, pkg.Options(**kw)) as s:
+        info = s.solve()
+        rho = s.rho_per_qp()
+        got = s.get()
+        np.testing.assert_array_equal(rho, ref["rho"])
+        assert int(info.iters_run) == ref["iters_run"]
+        assert int(info.rho_updates) == int(ref["rho_updates"].sum()) and float(info.rho) == float(ref["rho"].max())
+        np.testing.assert_array_equal(info.status, ref["status"])
+        np.testing.assert_array_equal(info.iters, ref["iters"])
+        assert _close(got, ref)
+        # admm_set_rho puts every QP back on one rho (each dual rescaled by its own rho_b / rho_new)
+        s.set_rho(0.5)
+        np.testing.assert_array_equal(s.rho_per_qp(), np.full(p.batch, 0.5))
+        s.iterate(5)
+        y0 = ref["y"] * (ref["rho"] / 0.5)[:, None]
+        ref2 = oc.solve(p, rho=0.5, alpha=alpha, max_iter=5, stop=False, z0=ref["z"], y0=y0)
+        assert _close(s.get(), ref2)
+
+
+def test_adaptive_rho_per_qp_through_the_pieces_api(gpu):
+    """admm_solve_begin / _step / _adapt / _end (the sharded solve's loop): the per-QP rule ignores the batch sums R, S."""
+    p = pkg.random_instances(N=20, n=6, m=3, batch=12, seed=33)
+    kw = dict(rho=0.3, eps_abs=1e-7, eps_rel=1e-7, max_iter=1500, check_interval=10, adapt_interval=20, adapt_mu=1.5, adapt_max=8)
+    ref = oc.solve(p, **kw)
+    with pkg.Solver(p, pkg.Options(**kw)) as s:
+        s.solve_begin()
+        while True:
+            it, nconv, _, _ = s.solve_step()
+            if nconv == p.batch or it >= kw["max_iter"]:
+                break
+            s.solve_adapt(float("nan"), float("nan"))
+        info = s.solve_end()
+        np.testing.assert_array_equal(s.rho_per_qp(), ref["rho"])
+        assert int(info.iters_run) == ref["iters_run"]
+        assert _close(s.get(), ref)
