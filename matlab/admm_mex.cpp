@@ -176,8 +176,13 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     admm_info info;
     check(admm_solve(h, z0, y0, &info));
     const char* names[] = {"iters_run", "n_converged", "max_r", "max_s", "solve_ms", "iters", "status", "r", "s",
-                           "rho", "rho_updates", "mixed_iters"};
-    plhs[0] = mxCreateStructMatrix(1, 1, 12, names);
+                           "rho", "rho_updates", "mixed_iters", "rho_per_qp"};
+    plhs[0] = mxCreateStructMatrix(1, 1, 13, names);
+    {
+      mxArray* rq = mxCreateDoubleMatrix(d->batch, 1, mxREAL);      // per-instance dynamics: each QP's own rho (ABI v5)
+      check(admm_get_rho(h, mxGetPr(rq)));
+      mxSetField(plhs[0], 0, "rho_per_qp", rq);
+    }
     mxSetField(plhs[0], 0, "mixed_iters", mxCreateDoubleScalar(info.mixed_iters));
     mxSetField(plhs[0], 0, "rho", mxCreateDoubleScalar(info.rho));
     mxSetField(plhs[0], 0, "rho_updates", mxCreateDoubleScalar(info.rho_updates));

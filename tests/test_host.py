@@ -283,3 +283,30 @@ def test_no_spills_at_headline_shapes(built):
     # the whole compiled set: scratch only in a handful of small non-headline forms (listed in DESIGN.md §4.8)
     spilled = [r["name"] for r in rows if r["scratch"] > 0]
     assert len(spilled) <= 12, spilled
+
+
+def test_host_factor_does_not_depend_on_the_thread_count(built):
+    """csrc/admm_factor.cpp runs its per-stage / per-segment loops on host threads (ADMM_FACTOR_THREADS, read once per
+    process): every stage is computed by exactly one thread with the same arithmetic, so the records -- plain, alternating
+    form, scan matrices, MFMA fragments of both modes -- are the same bytes for 1, 3 and 8 threads."""
+    import hashlib
+    import subprocess
+    code = (
+        "import sys, hashlib; sys.path.insert(0, %r); import numpy as np\n"
+        "import admm_library_amd as pkg; from admm_library_amd import solver as sv\n"
+        "h = hashlib.sha256()\n"
+        "for p, S in ((pkg.cw_formation(N=150, batch=1), 7), (pkg.random_ltv(N=61, n=6, m=3, batch=1, seed=5), 4)):\n"
+        "    f = sv.host_factor(p, 0.07, S)\n"
+        "    for k in sorted(f):\n"
+        "        if isinstance(f[k], np.ndarray): h.update(np.ascontiguousarray(f[k]).tobytes())\n"
+        "    if (p.n, p.m) == (12, 6):\n"
+        "        for mode in (1, 2):\n"
+        "            a, b, ok = sv.host_factor_mfma(p, 0.07, S, mode); h.update(a.tobytes()); h.update(b.tobytes())\n"
+        "print(h.hexdigest())\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    digests = set()
+    for nt in ("1", "3", "8"):
+        env = dict(os.environ, ADMM_FACTOR_THREADS=nt)
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        digests.add(out.stdout.strip().splitlines()[-1])
+    assert len(digests) == 1, digests
