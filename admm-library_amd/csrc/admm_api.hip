@@ -79,6 +79,11 @@ struct admm_handle {
   double *recB = nullptr, *recF = nullptr, *recS = nullptr;
   double *scan_in = nullptr, *scan_out = nullptr, *scanWp = nullptr;   // tseg|x0|eseg and t_in|x_in live inside these
   int* scan_range = nullptr;
+  // batches of up to SCAN_GEMV_MAXCOLS QPs: the scan as a matrix-vector product per column (xscan_gemv_kernel) on the
+  // dense row-major matrices, with each row's non-zero column range
+  bool scan_gemv = false;
+  double *scanWd = nullptr, *scanWBd = nullptr;
+  int *scan_rows = nullptr, *scan_rowsB = nullptr;
   // alternating-direction iteration
   double *recFE = nullptr, *recBE = nullptr, *mvec = nullptr, *scanWpB = nullptr;
   int* scan_rangeB = nullptr;
@@ -237,6 +242,20 @@ admm::FinArgs fin_args(const admm_handle* h, int it, int nchunks) {
 // with_finalize: one extra row of workgroups finalises the previous iteration's residual partials
 // (S chunks, it = 0: no stopping rule -- checked iterations of admm_solve finalise standalone).
 int launch_xscan_mfma(admm_handle* h, bool forward_form = false, bool with_finalize = false) {
+  if (h->scan_gemv) {                           // a handful of QPs: matrix-vector form (admm_kernels.hpp)
+    const int M = h->fac.scanM;
+    dim3 grid((M + 3) / 4, with_finalize ? 2 : 1), block(256);
+    const double* W = forward_form ? h->scanWBd : h->scanWd;
+    const int* rows = forward_form ? h->scan_rowsB : h->scan_rows;
+    const admm::FinArgs fa = fin_args(h, 0, h->S);
+#define GEMV(NC) hipLaunchKernelGGL((admm::xscan_gemv_kernel<NC>), grid, block, 0, h->stream, W, rows, h->scan_in, h->scan_out, \
+                                    M, h->fac.scanK, h->pitch, fa)
+    if (h->batch == 1) GEMV(1);
+    else if (h->batch == 2) GEMV(2);
+    else GEMV(4);
+#undef GEMV
+    return ADMM_OK;
+  }
   const int mtiles = h->fac.scanM / 16, ngroups = mtiles / admm::SCAN_MT;
   dim3 grid(h->pitch / 64, ngroups + (with_finalize ? 1 : 0), h->scan_split), block(256);
   hipLaunchKernelGGL((admm::xscan_mfma_kernel<admm::SCAN_MT>), grid, block, 0, h->stream,
@@ -525,6 +544,10 @@ void release(admm_handle* h) {
     for (auto b : ib)
       if (*b) { (void)hipFree(*b); *b = nullptr; }
   }
+  if (h->scanWd) { (void)hipFree(h->scanWd); h->scanWd = nullptr; }
+  if (h->scanWBd) { (void)hipFree(h->scanWBd); h->scanWBd = nullptr; }
+  if (h->scan_rows) { (void)hipFree(h->scan_rows); h->scan_rows = nullptr; }
+  if (h->scan_rowsB) { (void)hipFree(h->scan_rowsB); h->scan_rowsB = nullptr; }
   if (h->recMF) { (void)hipFree(h->recMF); h->recMF = nullptr; }
   if (h->recMB) { (void)hipFree(h->recMB); h->recMB = nullptr; }
   if (h->recMF64) { (void)hipFree(h->recMF64); h->recMF64 = nullptr; }
@@ -564,12 +587,30 @@ int capture_iterations(admm_handle* h) {
 }
 
 // device copies of everything in h->fac (records, scan matrices; the alternating set if enabled)
+// dense scan matrix + each row's non-zero column range [begin, end) for xscan_gemv_kernel
+int upload_scan_dense(const std::vector<double>& W, int M, int K, double* Wd, int* rows_d) {
+  std::vector<int32_t> rr((size_t)2 * M);
+  for (int r = 0; r < M; ++r) {
+    int kb = K, ke = 0;
+    const double* row = &W[(size_t)r * K];
+    for (int k = 0; k < K; ++k)
+      if (row[k] != 0.0) { if (k < kb) kb = k; ke = k + 1; }
+    if (ke < kb) { kb = 0; ke = 0; }
+    rr[2 * r] = kb; rr[2 * r + 1] = ke;
+  }
+  HIP_TRY(hipMemcpy(Wd, W.data(), sizeof(double) * W.size(), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(rows_d, rr.data(), sizeof(int32_t) * rr.size(), hipMemcpyHostToDevice));
+  return ADMM_OK;
+}
+
 int upload_factor(admm_handle* h) {
   HIP_TRY(hipMemcpy(h->recB, h->fac.recB.data(), sizeof(double) * h->fac.recB.size(), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(h->recF, h->fac.recF.data(), sizeof(double) * h->fac.recF.size(), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(h->recS, h->fac.recS.data(), sizeof(double) * h->fac.recS.size(), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(h->scanWp, h->fac.scanWp.data(), sizeof(double) * h->fac.scanWp.size(), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(h->scan_range, h->fac.scanRange.data(), sizeof(int32_t) * h->fac.scanRange.size(), hipMemcpyHostToDevice));
+  int rc;
+  if (h->scan_gemv && (rc = upload_scan_dense(h->fac.scanW, h->fac.scanM, h->fac.scanK, h->scanWd, h->scan_rows))) return rc;
   h->alt_state = admm_handle::ALT_NONE;
   if (!h->fac.alt_ok) { h->alt = false; h->alt_allowed = false; }   // the forward-elimination form did not survive the refactor
   if (h->mfma_mode) {
@@ -585,6 +626,7 @@ int upload_factor(admm_handle* h) {
     HIP_TRY(hipMemcpy(h->recBE, h->fac.recBE.data(), sizeof(double) * h->fac.recBE.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->scanWpB, h->fac.scanWpB.data(), sizeof(double) * h->fac.scanWpB.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->scan_rangeB, h->fac.scanRangeB.data(), sizeof(int32_t) * h->fac.scanRangeB.size(), hipMemcpyHostToDevice));
+    if (h->scan_gemv && (rc = upload_scan_dense(h->fac.scanWB, h->fac.scanM, h->fac.scanK, h->scanWBd, h->scan_rowsB))) return rc;
   }
   return ADMM_OK;
 }
@@ -1001,6 +1043,8 @@ int admm_setup(admm_handle** out, const admm_problem* p, const admm_options* o_i
   {  // scan operands: in = tseg | x0 | eseg | pad,  out = t_in | pad | x_in | pad  (admm_factor.hpp)
     const size_t Sn = (size_t)h->S * h->n;
     TRY_RELEASE(dalloc(&h->scan_in, (size_t)h->fac.scanK * P));
+    h->scan_gemv = h->batch <= admm::SCAN_GEMV_MAXCOLS && !(o.flags & ADMM_FLAG_SCAN_CHAIN) &&
+                   std::getenv("ADMM_NO_GEMV_SCAN") == nullptr;
     {  // split-K of the scan when the grid would be small: aim at >= 256 workgroups, <= 8 slices
       const int wgs = (h->pitch / 64) * (h->fac.scanM / 16 / admm::SCAN_MT);
       int sp = 1;
@@ -1011,6 +1055,7 @@ int admm_setup(admm_handle** out, const admm_problem* p, const admm_options* o_i
         const int v = std::atoi(e);
         if (v == 1 || v == 2 || v == 4 || v == 8) sp = v;
       }
+      if (h->scan_gemv) sp = 1;                        // the matrix-vector form writes whole sums
       h->scan_split = sp;
     }
     TRY_RELEASE(dalloc(&h->scan_out, (size_t)h->scan_split * h->fac.scanM * P));
@@ -1023,6 +1068,12 @@ int admm_setup(admm_handle** out, const admm_problem* p, const admm_options* o_i
     h->xin = h->scan_out + (size_t)h->fac.scanMt * P;
     TRY_RELEASE(dalloc(&h->scanWp, h->fac.scanWp.size()));
     TRY_RELEASE(dalloc(&h->scan_range, h->fac.scanRange.size()));
+    if (h->scan_gemv) {
+      TRY_RELEASE(dalloc(&h->scanWd, h->fac.scanW.size()));
+      TRY_RELEASE(dalloc(&h->scanWBd, h->fac.scanW.size()));
+      TRY_RELEASE(dalloc(&h->scan_rows, (size_t)2 * h->fac.scanM));
+      TRY_RELEASE(dalloc(&h->scan_rowsB, (size_t)2 * h->fac.scanM));
+    }
   }
   // alternating-direction iteration: compiled for this (n, m), buildable for this problem, not disabled
   h->alt_allowed = h->fac.alt_ok && fused(h) &&
@@ -1096,6 +1147,10 @@ int admm_setup(admm_handle** out, const admm_problem* p, const admm_options* o_i
   HIP_TRY_RELEASE(hipMemcpy(h->scanWp, h->fac.scanWp.data(), sizeof(double) * h->fac.scanWp.size(), hipMemcpyHostToDevice));
   HIP_TRY_RELEASE(hipMemcpy(h->scan_range, h->fac.scanRange.data(), sizeof(int32_t) * h->fac.scanRange.size(), hipMemcpyHostToDevice));
   HIP_TRY_RELEASE(hipMemcpy(h->seg_start, h->fac.seg_start.data(), sizeof(int32_t) * h->fac.seg_start.size(), hipMemcpyHostToDevice));
+  if (h->scan_gemv) {
+    TRY_RELEASE(upload_scan_dense(h->fac.scanW, h->fac.scanM, h->fac.scanK, h->scanWd, h->scan_rows));
+    if (h->alt_allowed) TRY_RELEASE(upload_scan_dense(h->fac.scanWB, h->fac.scanM, h->fac.scanK, h->scanWBd, h->scan_rowsB));
+  }
   TRY_RELEASE(upload_transposed(h, p->x0, h->x0, h->n));
   if (h->has_q) TRY_RELEASE(upload_transposed(h, p->q, h->q, h->L));
   HIP_TRY_RELEASE(hipStreamSynchronize(h->stream));

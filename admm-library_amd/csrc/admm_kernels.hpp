@@ -688,6 +688,63 @@ __global__ __launch_bounds__(256) void xscan_mfma_kernel(
 }
 
 // ---------------------------------------------------------------------------
+// Segment scan for a handful of QPs (batch <= SCAN_GEMV_MAXCOLS): the same product out = W in as a matrix-VECTOR
+// product per column.  With one QP the MFMA form above wastes 15 of its 16 panel columns and walks each M-group's k range
+// in dependent load -> LDS -> MFMA rounds (10.5 us at S = 64 even with split-K: 40 % of a one-QP iteration; this form:
+// configs[1] 26.0 -> 22.2 us per iteration with residuals, 25.0 -> 18.8 us without).  Here one wave
+// owns one output row: its lanes stride over the row's non-zero k range (W dense row-major, coalesced; the range comes
+// from the host), every load of the row is issued before the first use, and the 64 partial sums are combined with a
+// fixed xor-shuffle tree (bitwise reproducible).  The matrix (2.4 MB non-zero at S = 64, n = 6) stays in the infinity cache.
+// blockIdx.y == 1: the finalise role, as in xscan_mfma_kernel.
+// ---------------------------------------------------------------------------
+constexpr int SCAN_GEMV_MAXCOLS = 4;     // measured: 8 columns run as fast on the MFMA form (11.9 vs 10.7 us)
+
+template <int NC>
+__global__ __launch_bounds__(256) void xscan_gemv_kernel(
+    const double* __restrict__ W, const int* __restrict__ rowrange_, const double* __restrict__ in, double* __restrict__ out,
+    int M, int K, int pitch, FinArgs fa) {
+  __shared__ double red[4][5][FIN_COLS];
+  if (blockIdx.y == 1) {                                // finalise role (workgroup-uniform): one workgroup per 64 QPs
+    if ((int)blockIdx.x * FIN_COLS < pitch) finalize_body<4>(red, fa, blockIdx.x, pitch);
+    return;
+  }
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (row >= M) return;
+  cint_p rowrange = as_const(rowrange_);
+  const int kb = rowrange[2 * row], ke = rowrange[2 * row + 1];
+  const size_t P = (size_t)pitch;
+  const double* wr = W + (size_t)row * K;
+  double acc[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) acc[c] = 0.0;
+  constexpr int UN = 4;                                 // 4 x 64 = 256 columns of W per round, all loads in flight together
+  for (int k0 = kb; k0 < ke; k0 += 64 * UN) {
+    double wv[UN], xv[UN][NC];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int k = k0 + 64 * u + lane;
+      const bool ok = k < ke;
+      const int kc = ok ? k : kb;                       // clamped: loads only
+      wv[u] = ok ? wr[kc] : 0.0;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) xv[u][c] = in[(size_t)kc * P + c];
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u)
+#pragma unroll
+      for (int c = 0; c < NC; ++c) acc[c] = fma(wv[u], xv[u][c], acc[c]);
+  }
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    double a = acc[c];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
+    if (lane == 0) out[(size_t)row * P + c] = a;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // x-update, forward rollout (segment-local, exact once t_in/x_in are known).
 //     d   = d0_k + Psi_k t_in
 //     u   = -K_k x - d
