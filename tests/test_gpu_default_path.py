@@ -107,3 +107,27 @@ def test_config2_full_batch_slice_many_iterations(gpu):
         _close(a[lo:lo + 64], ref[name], name)
     assert np.abs(r[lo:lo + 64] - ref["r"]).max() <= 1e-10
     assert np.abs(sd[lo:lo + 64] - ref["s"]).max() <= 1e-10
+
+
+@pytest.mark.parametrize("batch", [1, 2, 3, 4])
+def test_matrix_vector_scan_of_tiny_batches(gpu, batch, monkeypatch):
+    """Batches of up to 4 QPs run the segment scan as a matrix-vector product per column (xscan_gemv_kernel, DESIGN.md
+    §4.9) instead of the 16-column MFMA panel: same iterates as with ADMM_NO_GEMV_SCAN within the parity tolerance, both within 1e-10 of
+    the oracle, through residual and non-residual iterations (the finalise role rides in either scan launch)."""
+    p = pkg.cw_rendezvous(N=600, batch=batch)
+    ref = oc.solve(p, rho=0.05, max_iter=63, check_interval=7, stop=False)
+    got = []
+    for gemv in (True, False):
+        if gemv:
+            monkeypatch.delenv("ADMM_NO_GEMV_SCAN", raising=False)
+        else:
+            monkeypatch.setenv("ADMM_NO_GEMV_SCAN", "1")
+        with pkg.Solver(p, pkg.Options(rho=0.05)) as s:
+            assert s.geometry()["segments"] > 8
+            s.run(63, residual_every=7)
+            got.append(s.get() + s.residuals()[:2])
+    for a, b in zip(*got):        # (rounding of the scan differs; the early-stage gains of the forward-elimination form amplify it, §4.8)
+        assert np.abs(a - b).max() <= TOL * max(1.0, np.abs(b).max()), np.abs(a - b).max()
+    for name, a in zip(("w", "z", "y"), got[0][:3]):
+        _close(a, ref[name], (batch, name))
+    assert np.abs(got[0][3] - ref["r"]).max() <= 1e-10 and np.abs(got[0][4] - ref["s"]).max() <= 1e-10
