@@ -226,8 +226,11 @@ def test_alternating_properties_at_full_size(gpu):
 
 
 @pytest.mark.parametrize("make", [lambda: pkg.cw_rendezvous(N=200, batch=300), lambda: pkg.cw_formation(N=120, batch=300),
-                                  lambda: pkg.cw_rendezvous(N=64, batch=5, thrust_norm=True)],
-                         ids=["one_lane_6_3", "mfma_12_6", "thrust_magnitude"])
+                                  lambda: pkg.cw_rendezvous(N=64, batch=5, thrust_norm=True),
+                                  lambda: pkg.random_ltv(N=70, n=6, m=3, batch=67, seed=77, state_bounds=False),
+                                  lambda: pkg.random_ltv(N=45, n=4, m=2, batch=9, seed=78, state_bounds=False, thrust_norm=True),
+                                  lambda: pkg.random_ltv(N=45, n=8, m=4, batch=130, seed=79, with_q=False, state_bounds=False)],
+                         ids=["one_lane_6_3", "mfma_12_6", "thrust_magnitude", "ltv_q_stage_bounds", "ltv_q_stage_thrust_bounds", "ltv_8_4"])
 def test_skipping_v_of_unbounded_state_rows_is_exact(gpu, make, monkeypatch):
     """XFREE kernel forms: where every state row is unbounded at every stage, the iterations that evaluate
     no residuals do not read v of those rows (y = 0 identically there).  Same iterates, BIT for bit, as with the skip
