@@ -104,6 +104,9 @@ struct admm_handle {
   double *Ad = nullptr, *Bd = nullptr, *Kd = nullptr, *Sd = nullptr, *lod = nullptr, *hid = nullptr;
   double *Qd = nullptr, *Rd = nullptr, *QNd = nullptr;
   int* pfail = nullptr;
+  // segments in time of the per-instance path (S > 1; csrc/admm_pinst.hpp, pseg_kernel): per-QP transfer matrices
+  double *Omd = nullptr, *Psd = nullptr, *Segd = nullptr;
+  int* pgrow = nullptr;
   // per-QP rho (every QP of a per-instance problem has its own factor, so the adaptive rule runs QP by QP on the device)
   double *rho_d = nullptr, *cscale_d = nullptr;     // [pitch]
   int *nupd_d = nullptr, *todo_d = nullptr, *nchanged_d = nullptr;
@@ -170,6 +173,8 @@ admm::PLaunch plaunch_of(const admm_handle* h) {
   l.has_q = h->has_q; l.pbounds = h->pbounds;
   l.alpha = h->opt.alpha;
   l.rhov = h->rho_d; l.todo = nullptr;
+  l.S = h->S; l.seg_start = h->seg_start; l.Omd = h->Omd; l.Psd = h->Psd; l.Segd = h->Segd;
+  l.tseg = h->tseg; l.eseg = h->eseg; l.tin = h->tin; l.xin = h->xin; l.grow = h->pgrow;
   l.Ad = h->Ad; l.Bd = h->Bd; l.Q = h->Qd; l.R = h->Rd; l.QN = h->QNd; l.Kd = h->Kd; l.Sd = h->Sd; l.fail = h->pfail;
   l.lo = h->pbounds ? h->lod : h->lo; l.hi = h->pbounds ? h->hid : h->hi;
   l.z = h->z; l.y = h->y; l.q = h->q; l.x0 = h->x0; l.v = h->v; l.w = h->w; l.dbuf = h->dbuf; l.part = h->part;
@@ -266,7 +271,11 @@ int launch_xscan_mfma(admm_handle* h, bool forward_form = false, bool with_final
 }
 
 int launch_xscan(admm_handle* h) {
-  if (h->pinst) return ADMM_OK;                 // one segment: nothing to couple
+  if (h->pinst) {                               // per-QP segment scan (nothing to couple with one segment)
+    if (h->S > 1 && !admm::launch_pinst(plaunch_of(h), admm::PKernel::SCAN, false))
+      return fail(ADMM_ERR_UNSUPPORTED, "no per-instance kernel for this (n, m)");
+    return ADMM_OK;
+  }
   if (!(h->opt.flags & ADMM_FLAG_SCAN_CHAIN)) return launch_xscan_mfma(h);
   return launch_x(h, admm::XKernel::XSCAN_CHAIN, false, false);
 }
@@ -539,6 +548,10 @@ void release(admm_handle* h) {
       if (*b) { (void)hipFree(*b); *b = nullptr; }
     if (h->pfail) { (void)hipFree(h->pfail); h->pfail = nullptr; }
     if (h->rho_d) { (void)hipFree(h->rho_d); h->rho_d = nullptr; }
+    double** sb[] = {&h->Omd, &h->Psd, &h->Segd};
+    for (auto b : sb)
+      if (*b) { (void)hipFree(*b); *b = nullptr; }
+    if (h->pgrow) { (void)hipFree(h->pgrow); h->pgrow = nullptr; }
     if (h->cscale_d) { (void)hipFree(h->cscale_d); h->cscale_d = nullptr; }
     int** ib[] = {&h->nupd_d, &h->todo_d, &h->nchanged_d};
     for (auto b : ib)
@@ -689,10 +702,21 @@ int pinst_factor(admm_handle* h, bool only_marked = false) {
   l.todo = only_marked ? h->todo_d : nullptr;
   if (!admm::launch_pinst(l, admm::PKernel::FACTOR, false)) return fail(ADMM_ERR_UNSUPPORTED, "no per-instance kernel for this (n, m)");
   HIP_TRY(hipGetLastError());
-  int bad = 0;
+  int bad = 0, grown = 0;
+  if (h->S > 1) {                                  // transfer matrices of the segments, from the new factor
+    HIP_TRY(hipMemsetAsync(h->pgrow, 0, sizeof(int), h->stream));
+    admm::launch_pinst(l, admm::PKernel::SEGMENTS, false);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(&grown, h->pgrow, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  }
   HIP_TRY(hipMemcpyAsync(&bad, h->pfail, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   if (bad) return fail(ADMM_ERR_NUMERIC, "R + rho I + B'PB is not positive definite for some QP");
+  // the conditioning bound of admm_setup, per QP; the per-QP adaptive rule (only_marked) refactors without it -- a
+  // refused change of one QP could not be undone without the factor it has just overwritten
+  if (grown && !only_marked)
+    return fail(ADMM_ERR_NUMERIC, "the segment transfer matrices of some QP grow beyond the conditioning bound (max entry > 100) "
+                                  "with " + std::to_string(h->S) + " segments; use options.segments = 1");
   return ADMM_OK;
 }
 
@@ -741,7 +765,26 @@ int setup_pinst(admm_handle* h, const admm_problem* p) {
   }
   h->pinst = true;
   h->pbounds = p->stage_bounds == 2;
-  h->S = 1;
+  // Segments in time (csrc/admm_pinst.hpp): one lane sweeps one segment of one QP, so an iteration takes N / S dependent
+  // stage round trips instead of N.  Automatic count: enough (64-QP wave, segment) pairs for one wave per SIMD, segments
+  // of at least 8 stages, at most 32 (the scan is S sequential steps per QP); large batches fill the chip alone (S = 1).
+  h->auto_segments = o.segments == 0;
+  {
+    int S = o.segments;
+    if (S == 0) {
+      const int waves = h->pitch / 64;
+      // (measured, N = 1000, n = 6: 64 QPs 2.26 -> 0.27 ms per iteration, 4096 QPs 3.04 -> 1.60 ms; from 8192 QPs the batch
+      //  alone reaches the HBM roofline and the segments' extra operands -- Omega_k, Psi_k: +16 % bytes -- only cost)
+      S = waves <= 64 ? (4 * h->num_cus) / std::max(1, waves) : 1;
+      if (S > h->N / 8) S = h->N / 8;
+      if (S > 32) S = 32;
+      if (std::getenv("ADMM_PI_NO_SEGMENTS")) S = 1;
+    }
+    if (S > h->N) S = h->N;
+    if (S < 1) S = 1;
+    if (S > 32) return fail(ADMM_ERR_INVALID, "options.segments: at most 32 with per-instance dynamics");
+    h->S = S;
+  }
   h->alt = h->alt_allowed = false;
   h->time_varying = 2;
   h->stage_bounds = p->stage_bounds;
@@ -761,9 +804,28 @@ int setup_pinst(admm_handle* h, const admm_problem* p) {
   PD(h->w, L * P); PD(h->z, L * P); PD(h->y, L * P); PD(h->v, L * P);
   if (h->has_q) PD(h->q, L * P);
   PD(h->dbuf, (size_t)N * m * P);
-  PD(h->scan_in, (size_t)n * P);                 // only x0 lives here
-  h->x0 = h->scan_in;
-  PD(h->part, (size_t)std::max(h->zchunks, 1) * 5 * P);
+  {  // scan_in = x0 | tseg | eseg,  scan_out = t_in | x_in   ([S][n][pitch] each; only x0 with one segment)
+    const size_t Sn = (size_t)h->S * n;
+    PD(h->scan_in, (size_t)(n + 2 * Sn) * P);
+    PD(h->scan_out, 2 * Sn * P);
+    h->x0 = h->scan_in;
+    h->tseg = h->scan_in + (size_t)n * P;
+    h->eseg = h->tseg + Sn * P;
+    h->tin = h->scan_out;
+    h->xin = h->scan_out + Sn * P;
+    std::vector<int32_t> ss(h->S + 1);
+    for (int sgm = 0; sgm <= h->S; ++sgm) ss[sgm] = (int32_t)(((int64_t)sgm * N) / h->S);
+    PD(h->seg_start, (size_t)h->S + 1);
+    HIP_TRY(hipMemcpyAsync(h->seg_start, ss.data(), sizeof(int32_t) * ss.size(), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    PD(h->pgrow, 1);
+    if (h->S > 1) {
+      PD(h->Omd, (size_t)N * n * m * P);
+      PD(h->Psd, (size_t)N * m * n * P);
+      PD(h->Segd, (size_t)h->S * 3 * n * n * P);
+    }
+  }
+  PD(h->part, (size_t)std::max(h->zchunks, h->S) * 5 * P);
   PD(h->resid, 5 * P);
   PD(h->lo, L); PD(h->hi, L); PD(h->ub, (size_t)N);
   PD(h->Ad, (size_t)N * n * n * P); PD(h->Bd, (size_t)N * n * m * P);
@@ -780,7 +842,12 @@ int setup_pinst(admm_handle* h, const admm_problem* p) {
   if ((rc = upload_transposed(h, p->x0, h->x0, n))) return rc;
   if (h->has_q && (rc = upload_transposed(h, p->q, h->q, (int)L))) return rc;
   if ((rc = pinst_fill_rho(h, o.rho))) return rc;
-  if ((rc = pinst_factor(h))) return rc;
+  rc = pinst_factor(h);
+  if (rc == ADMM_ERR_NUMERIC && h->S > 1 && h->auto_segments) {      // conditioning bound hit: sweep the whole horizon per lane
+    h->S = 1;
+    rc = pinst_factor(h);
+  }
+  if (rc) return rc;
   HIP_TRY(hipStreamSynchronize(h->stream));
   return ADMM_OK;
 }

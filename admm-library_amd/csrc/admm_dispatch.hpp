@@ -57,8 +57,14 @@ struct PLaunch {
   const double *lo, *hi;
   const double *z, *y, *q, *x0;
   double *v, *w, *dbuf, *part;
+  // segments in time (S > 1; admm_pinst.hpp, pseg_kernel): per-QP transfer matrices and the segment vectors
+  int S;
+  const int* seg_start;                // [S + 1], device
+  double *Omd, *Psd, *Segd;            // Omega_k [N][n*m], Psi_k [N][m*n], (Phi, Xi, Th) [S][3][n*n], all x pitch
+  double *tseg, *eseg, *tin, *xin;     // [S][n][pitch]
+  int* grow;                           // SEGMENTS: set if a transfer matrix exceeds the conditioning bound
 };
-enum class PKernel { FACTOR, XB, XF, XFZ };
+enum class PKernel { FACTOR, XB, XF, XFZ, SEGMENTS, SCAN };
 bool launch_pinst(const PLaunch& l, PKernel k, bool query_only);
 void launch_padapt(hipStream_t stream, const double* resid, const int* status, double* rhov, int* nupd, int* todo,
                    double* cscale, int* nchanged, double mu2, double tau, int adapt_max, int pitch, int batch);

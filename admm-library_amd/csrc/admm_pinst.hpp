@@ -195,15 +195,21 @@ __global__ __launch_bounds__(PI_THREADS) void pfactor_kernel(
 // was used: ~100 dependent round trips per stage, 18-30 us per stage; batched: one round trip).  The sweeps keep TWO of
 // these in registers and ping-pong: the loads of stage k -+ 1 are in flight while stage k is computed.
 // ---------------------------------------------------------------------------
-template <int NX, int NU, bool BACKWARD, bool HASQ, bool TWO /* second state array (z, y form) */, bool PB, bool BOUNDS, bool DIN>
+template <int NX, int NU, bool BACKWARD, bool HASQ, bool TWO /* second state array (z, y form) */, bool PB, bool BOUNDS, bool DIN,
+          bool SEG = false /* segment operand: Omega_k [n][m] (backward) / Psi_k [m][n] (forward) */>
 struct PiStage {
   static constexpr int NB = NX + NU;
   double A[NX * NX], B[NX * NU], K[NU * NX];
   double S[BACKWARD ? NU * NU : 1];
+  double G[SEG ? NX * NU : 1];
   double s0[NB], s1[TWO ? NB : 1], q[HASQ ? NB : 1], lo[BOUNDS ? NB : 1], hi[BOUNDS ? NB : 1], d[DIN ? NU : 1];
   __device__ __forceinline__ void load(int k, const double* Ad, const double* Bd, const double* Kd, const double* Sd,
                                        const double* st0, const double* st1, const double* qd, const double* lod,
-                                       const double* hid, const double* dd, size_t P_, int col) {
+                                       const double* hid, const double* dd, size_t P_, int col, const double* segd = nullptr) {
+    if (SEG) {
+#pragma unroll
+      for (int e = 0; e < NX * NU; ++e) G[e] = segd[((size_t)k * NX * NU + e) * P_ + col];
+    }
 #pragma unroll
     for (int e = 0; e < NX * NX; ++e) A[e] = Ad[((size_t)k * NX * NX + e) * P_ + col];
 #pragma unroll
@@ -237,21 +243,29 @@ struct PiStage {
 //     g = q - rho (z - y);  p = g^x + t;  h = B'p + g^u;  d_k = Si h -> dbuf;  t = A'p - K'h
 // A, B are column-major per stage: A[i][l] = A[l * NX + i], B[i][j] = B[j * NX + i]; K row-major [j][i].
 // ---------------------------------------------------------------------------
-template <int NX, int NU, bool HASQ, bool VFORM, bool PB>
+// SEG (segments in time, see pseg_kernel): blockIdx.y = segment s, stages seg_start[s] .. seg_start[s+1]-1, zero tail;
+// the segment also accumulates e = sum_k Omega_k d0_k and leaves (t, e) in tseg / eseg [s][n][pitch] for pscan_kernel.
+template <int NX, int NU, bool HASQ, bool VFORM, bool PB, bool SEG = false>
 __global__ __launch_bounds__(PI_THREADS) void pxb_kernel(
     const double* __restrict__ z, const double* __restrict__ y, const double* __restrict__ q,
     const double* __restrict__ Ad, const double* __restrict__ Bd, const double* __restrict__ Kd,
     const double* __restrict__ Sd, const double* __restrict__ lo, const double* __restrict__ hi,
-    double* __restrict__ dbuf, const double* __restrict__ rhov, int N, int pitch) {
+    double* __restrict__ dbuf, const double* __restrict__ rhov, int N, int pitch,
+    const double* __restrict__ Omd = nullptr, const int* __restrict__ seg_start = nullptr, double* __restrict__ tseg = nullptr,
+    double* __restrict__ eseg = nullptr) {
   constexpr int NB = NX + NU;
-  typedef PiStage<NX, NU, true, HASQ, !VFORM, PB, VFORM, false> Stage;
+  typedef PiStage<NX, NU, true, HASQ, !VFORM, PB, VFORM, false, SEG> Stage;
   const int col = blockIdx.x * PI_THREADS + threadIdx.x;
   if (col >= pitch) return;
   const double rho = rhov[col];
   const size_t P_ = (size_t)pitch;
-  double t[NX];
+  const int sg = SEG ? (int)blockIdx.y : 0;
+  const int ka = SEG ? seg_start[sg] : 0, kb = SEG ? seg_start[sg + 1] : N;
+  double t[NX], es[SEG ? NX : 1];
 #pragma unroll
   for (int i = 0; i < NX; ++i) t[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < (SEG ? NX : 1); ++i) es[i] = 0.0;
   auto body = [&](const Stage& s, int k) {
     double g[NB];
 #pragma unroll
@@ -276,12 +290,23 @@ __global__ __launch_bounds__(PI_THREADS) void pxb_kernel(
       for (int i = 0; i < NX; ++i) a = fma(s.B[j * NX + i], p[i], a);
       h[j] = a;
     }
+    double dv[NU];
 #pragma unroll
     for (int j = 0; j < NU; ++j) {
       double a = 0.0;
 #pragma unroll
       for (int l = 0; l < NU; ++l) a = fma(s.S[j * NU + l], h[l], a);
+      dv[j] = a;
       dbuf[((size_t)k * NU + j) * P_ + col] = a;
+    }
+    if (SEG) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+        double a = es[i];
+#pragma unroll
+        for (int j = 0; j < NU; ++j) a = fma(s.G[i * NU + j], dv[j], a);
+        es[i] = a;
+      }
     }
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
@@ -295,13 +320,20 @@ __global__ __launch_bounds__(PI_THREADS) void pxb_kernel(
   };
   const double* st0 = z;
   Stage sa, sb;
-  sa.load(N - 1, Ad, Bd, Kd, Sd, st0, y, q, lo, hi, nullptr, P_, col);
-  for (int k = N - 1; k >= 0; k -= 2) {
-    sb.load(k - 1 >= 0 ? k - 1 : 0, Ad, Bd, Kd, Sd, st0, y, q, lo, hi, nullptr, P_, col);
+  sa.load(kb - 1, Ad, Bd, Kd, Sd, st0, y, q, lo, hi, nullptr, P_, col, Omd);
+  for (int k = kb - 1; k >= ka; k -= 2) {
+    sb.load(k - 1 >= ka ? k - 1 : ka, Ad, Bd, Kd, Sd, st0, y, q, lo, hi, nullptr, P_, col, Omd);
     body(sa, k);
-    if (k - 1 < 0) break;
-    sa.load(k - 2 >= 0 ? k - 2 : 0, Ad, Bd, Kd, Sd, st0, y, q, lo, hi, nullptr, P_, col);
+    if (k - 1 < ka) break;
+    sa.load(k - 2 >= ka ? k - 2 : ka, Ad, Bd, Kd, Sd, st0, y, q, lo, hi, nullptr, P_, col, Omd);
     body(sb, k - 1);
+  }
+  if (SEG) {
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      tseg[((size_t)sg * NX + i) * P_ + col] = t[i];
+      eseg[((size_t)sg * NX + i) * P_ + col] = es[i];
+    }
   }
 }
 
@@ -310,28 +342,40 @@ __global__ __launch_bounds__(PI_THREADS) void pxb_kernel(
 //     u = -K x - d;  x <- A x + B u;   ZUP: v+ = wh + y_old -> v, partials -> part[5][pitch]
 // ZUP = false, STOREW = true is the read-out kernel (w of the last x-update).
 // ---------------------------------------------------------------------------
-template <int NX, int NU, bool ZUP, bool RESID, bool RELAX, bool VIN, bool PB, bool STOREW>
+// SEG: blockIdx.y = segment s; the rollout starts from x_in(s) with d_k = d0_k + Psi_k t_in(s) (xin / tin [s][n][pitch] from
+// pscan_kernel); residual partials go to part[s][5][pitch] and are summed over the segments by the finalise kernel.
+template <int NX, int NU, bool ZUP, bool RESID, bool RELAX, bool VIN, bool PB, bool STOREW, bool SEG = false>
 __global__ __launch_bounds__(PI_THREADS) void pxfz_kernel(
     const double* __restrict__ dbuf, const double* __restrict__ x0, const double* __restrict__ Ad,
     const double* __restrict__ Bd, const double* __restrict__ Kd, const double* __restrict__ lo,
     const double* __restrict__ hi, const double* __restrict__ zin, const double* __restrict__ yin,
-    double* __restrict__ v, double* __restrict__ w, double* __restrict__ part, double alpha, int N, int pitch) {
+    double* __restrict__ v, double* __restrict__ w, double* __restrict__ part, double alpha, int N, int pitch,
+    const double* __restrict__ Psd = nullptr, const int* __restrict__ seg_start = nullptr, const double* __restrict__ tin = nullptr,
+    const double* __restrict__ xin = nullptr) {
   constexpr int NB = NX + NU;
   constexpr bool NEEDZ = RESID || RELAX;
   // state operands: VIN: s0 = v;  else s0 = y and (NEEDZ) s1 = z
-  typedef PiStage<NX, NU, false, false, ZUP && !VIN && NEEDZ, PB, ZUP, true> Stage;
+  typedef PiStage<NX, NU, false, false, ZUP && !VIN && NEEDZ, PB, ZUP, true, SEG> Stage;
   const int col = blockIdx.x * PI_THREADS + threadIdx.x;
   if (col >= pitch) return;
   const size_t P_ = (size_t)pitch;
-  double x[NX];
+  const int sg = SEG ? (int)blockIdx.y : 0;
+  const int ka = SEG ? seg_start[sg] : 0, kb = SEG ? seg_start[sg + 1] : N;
+  double x[NX], ti[SEG ? NX : 1];
 #pragma unroll
-  for (int i = 0; i < NX; ++i) x[i] = x0[(size_t)i * P_ + col];
+  for (int i = 0; i < NX; ++i) x[i] = SEG ? xin[((size_t)sg * NX + i) * P_ + col] : x0[(size_t)i * P_ + col];
+#pragma unroll
+  for (int i = 0; i < (SEG ? NX : 1); ++i) ti[i] = SEG ? tin[((size_t)sg * NX + i) * P_ + col] : 0.0;
   double a_r = 0, a_s = 0, a_w = 0, a_z = 0, a_y = 0;
   auto body = [&](const Stage& s, int k) {
     double wv[NB];
 #pragma unroll
     for (int j = 0; j < NU; ++j) {
       double a = s.d[j];
+      if (SEG) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) a = fma(s.G[j * NX + i], ti[i], a);
+      }
 #pragma unroll
       for (int i = 0; i < NX; ++i) a = fma(s.K[j * NX + i], x[i], a);
       wv[j] = -a;
@@ -379,20 +423,244 @@ __global__ __launch_bounds__(PI_THREADS) void pxfz_kernel(
   };
   const double* st0 = ZUP ? (VIN ? v : yin) : dbuf;      // (!ZUP: the state operands are unused; any valid array)
   Stage sa, sb;
-  sa.load(0, Ad, Bd, Kd, nullptr, st0, zin, nullptr, lo, hi, dbuf, P_, col);
-  for (int k = 0; k < N; k += 2) {
-    sb.load(k + 1 < N ? k + 1 : N - 1, Ad, Bd, Kd, nullptr, st0, zin, nullptr, lo, hi, dbuf, P_, col);
+  sa.load(ka, Ad, Bd, Kd, nullptr, st0, zin, nullptr, lo, hi, dbuf, P_, col, Psd);
+  for (int k = ka; k < kb; k += 2) {
+    sb.load(k + 1 < kb ? k + 1 : kb - 1, Ad, Bd, Kd, nullptr, st0, zin, nullptr, lo, hi, dbuf, P_, col, Psd);
     body(sa, k);
-    if (k + 1 >= N) break;
-    sa.load(k + 2 < N ? k + 2 : N - 1, Ad, Bd, Kd, nullptr, st0, zin, nullptr, lo, hi, dbuf, P_, col);
+    if (k + 1 >= kb) break;
+    sa.load(k + 2 < kb ? k + 2 : kb - 1, Ad, Bd, Kd, nullptr, st0, zin, nullptr, lo, hi, dbuf, P_, col, Psd);
     body(sb, k + 1);
   }
   if (ZUP && RESID) {
-    part[0 * P_ + col] = a_r;
-    part[1 * P_ + col] = a_s;
-    part[2 * P_ + col] = a_w;
-    part[3 * P_ + col] = a_z;
-    part[4 * P_ + col] = a_y;
+    double* pp = part + (size_t)sg * 5 * P_;
+    pp[0 * P_ + col] = a_r;
+    pp[1 * P_ + col] = a_s;
+    pp[2 * P_ + col] = a_w;
+    pp[3 * P_ + col] = a_z;
+    pp[4 * P_ + col] = a_y;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Segments in time for per-instance dynamics (the segment algebra of DESIGN.md §4.2 with PER-QP transfer matrices, computed
+// on the device).  One lane = one (QP, segment): stages b-1 .. a of the segment, Lam = Acl_{b-1} ... Acl_{k+1} (I at k = b-1),
+// Acl = A - B K:
+//     Omega_k = -Lam B_k  [n][m] -> Omd      Psi_k = Si_k B_k' Lam' = -Si_k Omega_k'  [m][n] -> Psd      Xi += Omega_k Psi_k
+// and per segment Phi = Lam_a', Xi, Th = Lam_a (Lam_a = Acl_{b-1} ... Acl_a) -> Segd [s][3][n*n], row-major.
+// *grow is set if an entry of a transfer matrix exceeds 100 in magnitude (the conditioning bound of admm_setup).
+// ---------------------------------------------------------------------------
+template <int NX, int NU>
+__global__ __launch_bounds__(PI_THREADS) void pseg_kernel(
+    const double* __restrict__ Ad, const double* __restrict__ Bd, const double* __restrict__ Kd, const double* __restrict__ Sd,
+    const int* __restrict__ seg_start, const int* __restrict__ todo, double* __restrict__ Omd, double* __restrict__ Psd,
+    double* __restrict__ Segd, int* __restrict__ grow, int pitch, int batch) {
+  const int col = blockIdx.x * PI_THREADS + threadIdx.x;
+  if (col >= pitch) return;
+  if (todo && !todo[col]) return;
+  const size_t P_ = (size_t)pitch;
+  const int sg = blockIdx.y, ka = seg_start[sg], kb = seg_start[sg + 1];
+  double Lam[NX][NX], Xi[NX][NX];
+#pragma unroll
+  for (int i = 0; i < NX; ++i)
+#pragma unroll
+    for (int l = 0; l < NX; ++l) { Lam[i][l] = (i == l) ? 1.0 : 0.0; Xi[i][l] = 0.0; }
+  for (int k = kb - 1; k >= ka; --k) {
+    double A[NX][NX], B[NX][NU], K[NU][NX], Si[NU][NU];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+#pragma unroll
+      for (int l = 0; l < NX; ++l) A[i][l] = Ad[((size_t)k * NX * NX + l * NX + i) * P_ + col];
+#pragma unroll
+      for (int j = 0; j < NU; ++j) B[i][j] = Bd[((size_t)k * NX * NU + j * NX + i) * P_ + col];
+    }
+#pragma unroll
+    for (int j = 0; j < NU; ++j) {
+#pragma unroll
+      for (int l = 0; l < NX; ++l) K[j][l] = Kd[((size_t)k * NU * NX + j * NX + l) * P_ + col];
+#pragma unroll
+      for (int t = 0; t < NU; ++t) Si[j][t] = Sd[((size_t)k * NU * NU + j * NU + t) * P_ + col];
+    }
+    double Om[NX][NU], Ps[NU][NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i)
+#pragma unroll
+      for (int j = 0; j < NU; ++j) {
+        double a = 0.0;
+#pragma unroll
+        for (int l = 0; l < NX; ++l) a = fma(Lam[i][l], B[l][j], a);
+        Om[i][j] = -a;
+      }
+#pragma unroll
+    for (int j = 0; j < NU; ++j)
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+        double a = 0.0;
+#pragma unroll
+        for (int t = 0; t < NU; ++t) a = fma(Si[j][t], Om[i][t], a);
+        Ps[j][i] = -a;
+      }
+#pragma unroll
+    for (int i = 0; i < NX; ++i)
+#pragma unroll
+      for (int l = 0; l < NX; ++l) {
+        double a = Xi[i][l];
+#pragma unroll
+        for (int j = 0; j < NU; ++j) a = fma(Om[i][j], Ps[j][l], a);
+        Xi[i][l] = a;
+      }
+#pragma unroll
+    for (int i = 0; i < NX; ++i)
+#pragma unroll
+      for (int j = 0; j < NU; ++j) {
+        Omd[((size_t)k * NX * NU + i * NU + j) * P_ + col] = Om[i][j];
+        Psd[((size_t)k * NU * NX + j * NX + i) * P_ + col] = Ps[j][i];
+      }
+    // Lam <- Lam (A - B K)
+    double Acl[NX][NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i)
+#pragma unroll
+      for (int l = 0; l < NX; ++l) {
+        double a = A[i][l];
+#pragma unroll
+        for (int j = 0; j < NU; ++j) a = fma(-B[i][j], K[j][l], a);
+        Acl[i][l] = a;
+      }
+    double Ln[NX][NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i)
+#pragma unroll
+      for (int l = 0; l < NX; ++l) {
+        double a = 0.0;
+#pragma unroll
+        for (int r = 0; r < NX; ++r) a = fma(Lam[i][r], Acl[r][l], a);
+        Ln[i][l] = a;
+      }
+#pragma unroll
+    for (int i = 0; i < NX; ++i)
+#pragma unroll
+      for (int l = 0; l < NX; ++l) Lam[i][l] = Ln[i][l];
+  }
+  double big = 0.0;
+  double* sd = Segd + (size_t)sg * 3 * NX * NX * P_;
+#pragma unroll
+  for (int i = 0; i < NX; ++i)
+#pragma unroll
+    for (int l = 0; l < NX; ++l) {
+      sd[((size_t)0 * NX * NX + i * NX + l) * P_ + col] = Lam[l][i];     // Phi = Lam'
+      sd[((size_t)1 * NX * NX + i * NX + l) * P_ + col] = Xi[i][l];
+      sd[((size_t)2 * NX * NX + i * NX + l) * P_ + col] = Lam[i][l];     // Th
+      big = fmax(big, fmax(fabs(Lam[i][l]), fabs(Xi[i][l])));
+    }
+  if (col < batch && !(big <= 100.0)) atomicOr(grow, 1);
+}
+
+// Segment scan, per QP (both chains are S sequential n x n mat-vecs with the QP's own matrices):
+//     t_in(S-1) = 0;  t_in(s-1) = tseg(s) + Phi_s t_in(s)          x_in(0) = x0;  x_in(s+1) = c(s) + Th_s x_in(s),  c(s) = eseg(s) + Xi_s t_in(s)
+// Workgroup = 64 QPs x n rows: wave i forms ROW i of every mat-vec, so a lane loads n doubles per step (not n^2) and the
+// operands of the next PSCAN_D steps wait in registers; the vector passes between the waves through a double-buffered LDS
+// slab with ONE barrier per step -- a barrier that waits for LDS traffic only (lds_barrier): __syncthreads also drains the
+// vector-memory queue, i.e. every step would wait for the prefetches and for its own store of t_in / x_in (measured: 3 us
+// per step, the scan of 32 segments cost 188 us against 50 us for each sweep).  c(s) does not depend on the x chain: all S - 1
+// of them are formed in one pass of independent loads between the two chains (and overwrite eseg).
+constexpr int PSCAN_D = 8;        // steps whose operands are prefetched as one group
+constexpr int PSCAN_SMAX = 32;    // segments (the automatic choice caps at this; admm_setup refuses more)
+
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int NX>
+__global__ __launch_bounds__(PI_THREADS * NX) void pscan_kernel(
+    const double* __restrict__ Segd, const double* __restrict__ tseg, double* eseg,
+    const double* __restrict__ x0, double* tin, double* __restrict__ xin, int S, int pitch) {
+  constexpr int D = PSCAN_D, SM = PSCAN_SMAX;
+  __shared__ double vec[2][NX][PI_THREADS];
+  const int lane = threadIdx.x & (PI_THREADS - 1);
+  const int i = __builtin_amdgcn_readfirstlane(threadIdx.x / PI_THREADS);     // this wave's row
+  const int col = blockIdx.x * PI_THREADS + lane;                             // pitch is a multiple of 64
+  const size_t P_ = (size_t)pitch;
+  const double* rowp = Segd + (size_t)i * NX * P_ + col;                      // row i of block (sg, which): + ((sg * 3 + which) * NX * NX + l) * P_
+  int cur = 0;
+  // ---- t chain: step u = 0 .. S-2 handles segment sg = S-1-u and produces t_in(sg-1) ----
+  vec[0][i][lane] = 0.0;
+  tin[((size_t)(S - 1) * NX + i) * P_ + col] = 0.0;
+  {
+    double M[2][D][NX], ts[2][D];
+    auto load = [&](int buf, int u0) {
+#pragma unroll
+      for (int u = 0; u < D; ++u) {
+        const int sg = (S - 1 - (u0 + u)) >= 1 ? S - 1 - (u0 + u) : 1;        // clamped: loads only
+#pragma unroll
+        for (int l = 0; l < NX; ++l) M[buf][u][l] = rowp[(((size_t)sg * 3 + 0) * NX * NX + l) * P_];
+        ts[buf][u] = tseg[((size_t)sg * NX + i) * P_ + col];
+      }
+    };
+    load(0, 0);
+    lds_barrier();
+#pragma unroll
+    for (int g = 0; g < (SM - 1 + D - 1) / D; ++g) {
+      if (g * D < S - 1) {                                  // workgroup-uniform
+        if ((g + 1) * D < S - 1) load((g + 1) & 1, (g + 1) * D);
+#pragma unroll
+        for (int u = 0; u < D; ++u) {
+          if (g * D + u < S - 1) {
+            const int sg = S - 1 - (g * D + u);
+            double a = ts[g & 1][u];
+#pragma unroll
+            for (int l = 0; l < NX; ++l) a = fma(M[g & 1][u][l], vec[cur][l][lane], a);
+            vec[cur ^ 1][i][lane] = a;
+            tin[((size_t)(sg - 1) * NX + i) * P_ + col] = a;
+            lds_barrier();
+            cur ^= 1;
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();                 // t_in of every segment is in memory (written by this workgroup)
+  // ---- c(s) = eseg(s) + Xi_s t_in(s), s = 0 .. S-2: independent of each other; written over eseg(s) (this lane's own element) ----
+#pragma unroll 4
+  for (int sg = 0; sg < S - 1; ++sg) {
+    double a = eseg[((size_t)sg * NX + i) * P_ + col];
+#pragma unroll
+    for (int l = 0; l < NX; ++l) a = fma(rowp[(((size_t)sg * 3 + 1) * NX * NX + l) * P_], tin[((size_t)sg * NX + l) * P_ + col], a);
+    eseg[((size_t)sg * NX + i) * P_ + col] = a;
+  }
+  // ---- x chain: step sg = 0 .. S-2 produces x_in(sg+1) ----
+  {
+    const double xv = x0[(size_t)i * P_ + col];
+    vec[cur][i][lane] = xv;
+    xin[(size_t)i * P_ + col] = xv;
+    double Tm[2][D][NX], cs[2][D];
+    auto load = [&](int buf, int u0) {
+#pragma unroll
+      for (int u = 0; u < D; ++u) {
+        const int sg = (u0 + u) <= S - 2 ? u0 + u : 0;
+#pragma unroll
+        for (int l = 0; l < NX; ++l) Tm[buf][u][l] = rowp[(((size_t)sg * 3 + 2) * NX * NX + l) * P_];
+        cs[buf][u] = eseg[((size_t)sg * NX + i) * P_ + col];
+      }
+    };
+    load(0, 0);
+    lds_barrier();
+#pragma unroll
+    for (int g = 0; g < (SM - 1 + D - 1) / D; ++g) {
+      if (g * D < S - 1) {
+        if ((g + 1) * D < S - 1) load((g + 1) & 1, (g + 1) * D);
+#pragma unroll
+        for (int u = 0; u < D; ++u) {
+          if (g * D + u < S - 1) {
+            const int sg = g * D + u;
+            double a = cs[g & 1][u];
+#pragma unroll
+            for (int l = 0; l < NX; ++l) a = fma(Tm[g & 1][u][l], vec[cur][l][lane], a);
+            vec[cur ^ 1][i][lane] = a;
+            xin[((size_t)(sg + 1) * NX + i) * P_ + col] = a;
+            lds_barrier();
+            cur ^= 1;
+          }
+        }
+      }
+    }
   }
 }
 

@@ -27,12 +27,16 @@ def _close(got, ref):
     return all(np.abs(a - ref[k]).max() <= TOL * max(1.0, np.abs(ref[k]).max()) for a, k in zip(got, ("w", "z", "y")))
 
 
+@pytest.mark.parametrize("segments", [0, 1, 5], ids=["auto_segments", "one_segment", "five_segments"])
 @pytest.mark.parametrize("alpha", [1.0, 1.5])
 @pytest.mark.parametrize("idx", range(len(CASES)))
-def test_iterates_match_the_oracle(gpu, idx, alpha):
+def test_iterates_match_the_oracle(gpu, idx, alpha, segments):
+    """segments: 0 = the library's choice (N / 8 at these sizes), 1 = one lane sweeps the whole horizon, 5 = segments in
+    time with per-QP transfer matrices computed on the device (pseg_kernel, pscan_kernel; capped at N)."""
     p = pkg.random_instances(**CASES[idx])
-    with pkg.Solver(p, pkg.Options(rho=0.3, alpha=alpha)) as s:
-        assert s.geometry()["segments"] == 1
+    with pkg.Solver(p, pkg.Options(rho=0.3, alpha=alpha, segments=segments)) as s:
+        want = {0: max(1, min(32, p.N // 8)), 1: 1, 5: min(5, p.N)}[segments]
+        assert s.geometry()["segments"] == want
         done = 0
         for upto in (1, 2, 3, 10, 40):
             s.run(upto - done, residual_every=2)
