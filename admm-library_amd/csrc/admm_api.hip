@@ -714,7 +714,7 @@ int pinst_factor(admm_handle* h, bool only_marked = false) {
   if (bad) return fail(ADMM_ERR_NUMERIC, "R + rho I + B'PB is not positive definite for some QP");
   // the conditioning bound of admm_setup, per QP; the per-QP adaptive rule (only_marked) refactors without it -- a
   // refused change of one QP could not be undone without the factor it has just overwritten
-  if (grown && !only_marked)
+  if (grown && !only_marked && h->auto_segments)   // (a segment count the caller fixed is the caller's responsibility, as with shared dynamics)
     return fail(ADMM_ERR_NUMERIC, "the segment transfer matrices of some QP grow beyond the conditioning bound (max entry > 100) "
                                   "with " + std::to_string(h->S) + " segments; use options.segments = 1");
   return ADMM_OK;

@@ -10,8 +10,9 @@
 //   Ad [k][n*n] A_k and Bd [k][n*m] B_k, COLUMN-major per stage (the ABI's own order: the upload is one transposition
 //   of the caller's array)      Kd [k][m*n] row-major      Sd [k][m*m] = (R + rho I + B'PB)^-1
 //   lod / hid [k][m+n]  (stage_bounds = 2; otherwise the shared expanded arrays lo / hi [L])
-// Iteration = the plain path without segments (one lane sweeps the whole horizon; the batch is the only parallelism):
-//     pxb_kernel  backward sweep (d rows -> dbuf)      pxfz_kernel  forward rollout + z-update + dual + residuals
+// Iteration = the plain path: pxb_kernel  backward sweep (d rows -> dbuf)      pxfz_kernel  forward rollout + z-update + dual
+// + residuals; one lane sweeps one SEGMENT of one QP's horizon (pseg_kernel / pscan_kernel below: per-QP transfer matrices,
+// computed on the device), the whole horizon when the batch alone fills the chip.
 // Algorithmic HBM bytes per stacked element and iteration (n = 6, m = 3, fp64, v-form):
 //     factor operands  A 36 + B 18 + K 18 + S 9 = 81 doubles (backward), K + A + B = 72 (forward)  -> 153 x 8 / 9 = 136 B
 //     state            v 8 + d 2.67 (pxb), d 2.67 + v 8 + v+ 8 (pxfz)                              ->  29.33 B

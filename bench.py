@@ -167,8 +167,9 @@ def bench_perinstance(a, pkg, np, world, rank, dev_index, lo_i, hi_i, gbatch, ba
         prof = sv.profile(min(a.profile_launches, 50), residuals=True, fused=True)
     dt = float(np.median(blocks))
     elems = full.L * geo["pitch"]
-    ops_b = (n_ * n_ + n_ * m_ + m_ * n_ + m_ * m_) * 8.0 / nb          # A, B, K, Si per stage -> per stacked element
-    ops_f = (m_ * n_ + n_ * n_ + n_ * m_) * 8.0 / nb                     # K, A, B
+    seg_ops = n_ * m_ * 8.0 / nb if geo["segments"] > 1 else 0.0        # Omega_k (backward) / Psi_k (forward) with segments in time
+    ops_b = (n_ * n_ + n_ * m_ + m_ * n_ + m_ * m_) * 8.0 / nb + seg_ops   # A, B, K, Si per stage -> per stacked element
+    ops_f = (m_ * n_ + n_ * n_ + n_ * m_) * 8.0 / nb + seg_ops              # K, A, B
     b_xb = 8.0 + 16.0 + ops_b + 8.0 * m_ / nb                            # v, lo, hi read; operands; d written
     b_xfz = 8.0 * m_ / nb + 8.0 + 16.0 + ops_f + 8.0                     # d, v, lo, hi read; operands; v+ written
     ms = prof["xb_ms"] + prof["xfz_ms"]
@@ -186,8 +187,8 @@ def bench_perinstance(a, pkg, np, world, rank, dev_index, lo_i, hi_i, gbatch, ba
                          "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "traffic": None, "bytes_per_element": b_xb + b_xfz, "bytes_per_launch_pair": (b_xb + b_xfz) * elems,
                          "avg_launch_ms": {"pxb": prof["xb_ms"], "pxfz": prof["xfz_ms"]},
-                         "note": "latency-bound, not bandwidth-bound, at this batch: pitch / 64 waves for 1024 SIMDs, each stage one "
-                                 "dependent round trip to HBM (DESIGN.md §4.10)"}}))
+                         "note": "one lane sweeps one segment of one QP (segments in time with per-QP transfer matrices, DESIGN.md "
+                                 "§4.10); xscan = the per-QP segment scan", "xscan_ms": prof.get("xscan_ms")}}))
 
 
 def main():

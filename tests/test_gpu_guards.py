@@ -76,3 +76,31 @@ def test_adaptive_rule_stops_adapting_when_a_change_is_refused(gpu):
         info = s.solve()
         assert np.isfinite(s.get()[0]).all()
     assert info.rho >= 5e-3          # 0.1 -> 0.01 is admissible (max |W| = 24.8); 1e-3 (248) is refused
+
+
+def test_per_instance_segments_keep_the_conditioning_bound(gpu):
+    """Per-instance dynamics with segments in time (per-QP transfer matrices from pseg_kernel): the automatic segment count
+    falls back to one segment when some QP's transfer matrices exceed the bound at setup, a rho change that would break it
+    is refused with the handle unchanged, and a segment count fixed by the caller is not guarded."""
+    import dataclasses
+    base = _rho_sensitive_plant(batch=5)
+    A = np.broadcast_to(base.A, (5, base.N, 2, 2)).copy()
+    A[:, :, 0, 1] += 0.01 * np.arange(5)[:, None]                  # five different plants
+    B = np.broadcast_to(base.B, (5, base.N, 2, 1)).copy()
+    p = dataclasses.replace(base, A=A, B=B)
+    assert p.per_instance
+    with pkg.Solver(p, pkg.Options(rho=1e-4)) as s:
+        assert s.geometry()["segments"] == 1                        # backed off at setup
+    with pkg.Solver(p, pkg.Options(rho=0.1)) as s:
+        assert s.geometry()["segments"] == 8
+        s.iterate(5)
+        with pytest.raises(pkg.AdmmError) as e:
+            s.set_rho(1e-4)
+        assert e.value.code == _code("ADMM_ERR_NUMERIC") and "segment" in str(e.value)
+        np.testing.assert_array_equal(s.rho_per_qp(), np.full(5, 0.1))
+        s.iterate(5)
+        w, z, y = s.get()
+    ref = oc.solve(p, rho=0.1, max_iter=10, stop=False)
+    assert np.abs(z - ref["z"]).max() <= 1e-10 and np.abs(w - ref["w"]).max() <= 1e-10
+    with pkg.Solver(p, pkg.Options(rho=0.1, segments=4)) as s:
+        s.set_rho(1e-4)
