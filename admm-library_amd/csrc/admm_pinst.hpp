@@ -565,61 +565,70 @@ __global__ __launch_bounds__(PI_THREADS) void pseg_kernel(
 // per step, the scan of 32 segments cost 188 us against 50 us for each sweep).  c(s) does not depend on the x chain: all S - 1
 // of them are formed in one pass of independent loads between the two chains (and overwrite eseg).
 constexpr int PSCAN_D = 8;        // steps whose operands are prefetched as one group
-constexpr int PSCAN_SMAX = 32;    // segments (the automatic choice caps at this; admm_setup refuses more)
 
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <int NX>
 __global__ __launch_bounds__(PI_THREADS * NX) void pscan_kernel(
-    const double* __restrict__ Segd, const double* __restrict__ tseg, double* eseg,
-    const double* __restrict__ x0, double* tin, double* __restrict__ xin, int S, int pitch) {
-  constexpr int D = PSCAN_D, SM = PSCAN_SMAX;
+    const double* __restrict__ Segd, const double* __restrict__ tseg, double* __restrict__ eseg,
+    const double* __restrict__ x0, double* __restrict__ tin, double* __restrict__ xin, int S, int pitch) {
+  // (eseg and tin are each read and written here, through these pointers only; no two of the arrays overlap)
+  constexpr int D = PSCAN_D;
+  static_assert(D % 2 == 0, "the LDS slab index returns to its start after a group");
   __shared__ double vec[2][NX][PI_THREADS];
   const int lane = threadIdx.x & (PI_THREADS - 1);
   const int i = __builtin_amdgcn_readfirstlane(threadIdx.x / PI_THREADS);     // this wave's row
   const int col = blockIdx.x * PI_THREADS + lane;                             // pitch is a multiple of 64
   const size_t P_ = (size_t)pitch;
   const double* rowp = Segd + (size_t)i * NX * P_ + col;                      // row i of block (sg, which): + ((sg * 3 + which) * NX * NX + l) * P_
-  int cur = 0;
+  const int nsteps = S - 1, ngroups = (nsteps + D - 1) / D;
+  // Both chains run as groups of D steps with straight-line code inside a group: a step beyond the chain's end repeats the
+  // lane's value and stores nothing (its operand loads are clamped to valid addresses), so every barrier is reached by every wave
+  // and the compiler's wait counts see one path.
+  struct Ops { double M[D][NX], c[D]; };
+  double mine = 0.0;
   // ---- t chain: step u = 0 .. S-2 handles segment sg = S-1-u and produces t_in(sg-1) ----
   vec[0][i][lane] = 0.0;
   tin[((size_t)(S - 1) * NX + i) * P_ + col] = 0.0;
   {
-    double M[2][D][NX], ts[2][D];
-    auto load = [&](int buf, int u0) {
+    auto load = [&](Ops& o, int u0) {
 #pragma unroll
       for (int u = 0; u < D; ++u) {
-        const int sg = (S - 1 - (u0 + u)) >= 1 ? S - 1 - (u0 + u) : 1;        // clamped: loads only
+        const int sg = (u0 + u < nsteps) ? S - 1 - (u0 + u) : 1;
 #pragma unroll
-        for (int l = 0; l < NX; ++l) M[buf][u][l] = rowp[(((size_t)sg * 3 + 0) * NX * NX + l) * P_];
-        ts[buf][u] = tseg[((size_t)sg * NX + i) * P_ + col];
+        for (int l = 0; l < NX; ++l) o.M[u][l] = rowp[(((size_t)sg * 3 + 0) * NX * NX + l) * P_];
+        o.c[u] = tseg[((size_t)sg * NX + i) * P_ + col];
       }
     };
-    load(0, 0);
-    lds_barrier();
+    auto steps = [&](const Ops& o, int u0) {
 #pragma unroll
-    for (int g = 0; g < (SM - 1 + D - 1) / D; ++g) {
-      if (g * D < S - 1) {                                  // workgroup-uniform
-        if ((g + 1) * D < S - 1) load((g + 1) & 1, (g + 1) * D);
+      for (int u = 0; u < D; ++u) {
+        const bool valid = u0 + u < nsteps;
+        const int sg = S - 1 - (u0 + u);
+        double a = o.c[u];
 #pragma unroll
-        for (int u = 0; u < D; ++u) {
-          if (g * D + u < S - 1) {
-            const int sg = S - 1 - (g * D + u);
-            double a = ts[g & 1][u];
-#pragma unroll
-            for (int l = 0; l < NX; ++l) a = fma(M[g & 1][u][l], vec[cur][l][lane], a);
-            vec[cur ^ 1][i][lane] = a;
-            tin[((size_t)(sg - 1) * NX + i) * P_ + col] = a;
-            lds_barrier();
-            cur ^= 1;
-          }
-        }
+        for (int l = 0; l < NX; ++l) a = fma(o.M[u][l], vec[u & 1][l][lane], a);
+        a = valid ? a : mine;
+        mine = a;
+        vec[(u & 1) ^ 1][i][lane] = a;
+        if (valid) tin[((size_t)(sg - 1) * NX + i) * P_ + col] = a;
+        lds_barrier();
       }
+    };
+    Ops A, B;
+    load(A, 0);
+    lds_barrier();
+    for (int g = 0; g < ngroups; g += 2) {
+      if (g + 1 < ngroups) load(B, (g + 1) * D);
+      steps(A, g * D);
+      if (g + 1 >= ngroups) break;
+      if (g + 2 < ngroups) load(A, (g + 2) * D);
+      steps(B, (g + 1) * D);
     }
   }
   __syncthreads();                 // t_in of every segment is in memory (written by this workgroup)
   // ---- c(s) = eseg(s) + Xi_s t_in(s), s = 0 .. S-2: independent of each other; written over eseg(s) (this lane's own element) ----
-#pragma unroll 4
+#pragma unroll 8
   for (int sg = 0; sg < S - 1; ++sg) {
     double a = eseg[((size_t)sg * NX + i) * P_ + col];
 #pragma unroll
@@ -628,39 +637,42 @@ __global__ __launch_bounds__(PI_THREADS * NX) void pscan_kernel(
   }
   // ---- x chain: step sg = 0 .. S-2 produces x_in(sg+1) ----
   {
-    const double xv = x0[(size_t)i * P_ + col];
-    vec[cur][i][lane] = xv;
-    xin[(size_t)i * P_ + col] = xv;
-    double Tm[2][D][NX], cs[2][D];
-    auto load = [&](int buf, int u0) {
+    mine = x0[(size_t)i * P_ + col];
+    vec[0][i][lane] = mine;
+    xin[(size_t)i * P_ + col] = mine;
+    auto load = [&](Ops& o, int u0) {
 #pragma unroll
       for (int u = 0; u < D; ++u) {
-        const int sg = (u0 + u) <= S - 2 ? u0 + u : 0;
+        const int sg = (u0 + u < nsteps) ? u0 + u : 0;
 #pragma unroll
-        for (int l = 0; l < NX; ++l) Tm[buf][u][l] = rowp[(((size_t)sg * 3 + 2) * NX * NX + l) * P_];
-        cs[buf][u] = eseg[((size_t)sg * NX + i) * P_ + col];
+        for (int l = 0; l < NX; ++l) o.M[u][l] = rowp[(((size_t)sg * 3 + 2) * NX * NX + l) * P_];
+        o.c[u] = eseg[((size_t)sg * NX + i) * P_ + col];
       }
     };
-    load(0, 0);
-    lds_barrier();
+    auto steps = [&](const Ops& o, int u0) {
 #pragma unroll
-    for (int g = 0; g < (SM - 1 + D - 1) / D; ++g) {
-      if (g * D < S - 1) {
-        if ((g + 1) * D < S - 1) load((g + 1) & 1, (g + 1) * D);
+      for (int u = 0; u < D; ++u) {
+        const bool valid = u0 + u < nsteps;
+        const int sg = u0 + u;
+        double a = o.c[u];
 #pragma unroll
-        for (int u = 0; u < D; ++u) {
-          if (g * D + u < S - 1) {
-            const int sg = g * D + u;
-            double a = cs[g & 1][u];
-#pragma unroll
-            for (int l = 0; l < NX; ++l) a = fma(Tm[g & 1][u][l], vec[cur][l][lane], a);
-            vec[cur ^ 1][i][lane] = a;
-            xin[((size_t)(sg + 1) * NX + i) * P_ + col] = a;
-            lds_barrier();
-            cur ^= 1;
-          }
-        }
+        for (int l = 0; l < NX; ++l) a = fma(o.M[u][l], vec[u & 1][l][lane], a);
+        a = valid ? a : mine;
+        mine = a;
+        vec[(u & 1) ^ 1][i][lane] = a;
+        if (valid) xin[((size_t)(sg + 1) * NX + i) * P_ + col] = a;
+        lds_barrier();
       }
+    };
+    Ops A, B;
+    load(A, 0);
+    lds_barrier();
+    for (int g = 0; g < ngroups; g += 2) {
+      if (g + 1 < ngroups) load(B, (g + 1) * D);
+      steps(A, g * D);
+      if (g + 1 >= ngroups) break;
+      if (g + 2 < ngroups) load(A, (g + 2) * D);
+      steps(B, (g + 1) * D);
     }
   }
 }
