@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Per-instance dynamics: cost of a device refactor (admm_set_rho = pfactor_kernel + pseg_kernel over every QP) and of
+admm_update_problem (upload + refactor).    python tools/pinst_refactor_time.py [N=1000] [batches="64 1024 4096"]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import admm_library_amd as pkg  # noqa: E402
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+for batch in [int(b) for b in (sys.argv[2].split() if len(sys.argv) > 2 else "64 1024 4096".split())]:
+    p = pkg.cw_rendezvous_instances(N=N, batch=batch)
+    with pkg.Solver(p, pkg.Options(rho=0.05)) as s:
+        s.iterate(3)
+        ts = []
+        for r in (0.1, 0.05, 0.2, 0.05):
+            s.sync()
+            t = time.perf_counter()
+            s.set_rho(r)
+            s.sync()
+            ts.append((time.perf_counter() - t) * 1e3)
+        t = time.perf_counter()
+        s.update_problem(p)
+        s.sync()
+        tu = (time.perf_counter() - t) * 1e3
+        print(f"batch {batch} N {N} segments {s.geometry()['segments']}: set_rho {min(ts):.2f} ms (of {' '.join('%.2f' % x for x in ts)}), "
+              f"update_problem {tu:.1f} ms", flush=True)
