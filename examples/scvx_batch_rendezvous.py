@@ -29,7 +29,10 @@ solves = []
 
 
 def timed_solver():
-    inner = sc.gpu_qp_solver(rho=0.5, eps_abs=1e-8, eps_rel=1e-8, max_iter=20000, check_interval=25)
+    # per-QP residual balancing on the device; SCVX_ADAPT=0 for fixed rho
+    every = int(os.environ.get("SCVX_ADAPT", "100"))
+    adapt = dict(adapt_interval=every, adapt_mu=5.0) if every > 0 else {}
+    inner = sc.gpu_qp_solver(rho=0.5, eps_abs=1e-8, eps_rel=1e-8, max_iter=20000, check_interval=25, **adapt)
 
     def solve(p):
         t = time.perf_counter()
