@@ -562,8 +562,8 @@ __global__ __launch_bounds__(PI_THREADS) void pseg_kernel(
 // operands of the next PSCAN_D steps wait in registers; the vector passes between the waves through a double-buffered LDS
 // slab with ONE barrier per step -- a barrier that waits for LDS traffic only (lds_barrier): __syncthreads also drains the
 // vector-memory queue, i.e. every step would wait for the prefetches and for its own store of t_in / x_in (measured: 3 us
-// per step, the scan of 32 segments cost 188 us against 50 us for each sweep).  c(s) does not depend on the x chain: all S - 1
-// of them are formed in one pass of independent loads between the two chains (and overwrite eseg).
+// per step, the scan of 32 segments cost 188 us against 50 us for each sweep).  c(s) does not depend on the x chain: it is
+// formed in the t chain, at the step that has t_in(s) in the slab anyway, and overwrites eseg(s).
 constexpr int PSCAN_D = 8;        // steps whose operands are prefetched as one group
 
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -587,54 +587,61 @@ __global__ __launch_bounds__(PI_THREADS * NX) void pscan_kernel(
   // and the compiler's wait counts see one path.
   struct Ops { double M[D][NX], c[D]; };
   double mine = 0.0;
-  // ---- t chain: step u = 0 .. S-2 handles segment sg = S-1-u and produces t_in(sg-1) ----
+  // ---- t chain: step u = 0 .. S-1 handles segment sg = S-1-u: t_in(sg) is in the slab; it produces t_in(sg-1) (sg >= 1) and,
+  //      from the same LDS reads, c(sg) = eseg(sg) + Xi_sg t_in(sg), which overwrites eseg(sg) (this lane's own element) ----
   vec[0][i][lane] = 0.0;
   tin[((size_t)(S - 1) * NX + i) * P_ + col] = 0.0;
   {
-    auto load = [&](Ops& o, int u0) {
+    constexpr int DT = D / 2;                        // two rows of operands per step: half the steps per group
+    static_assert(DT % 2 == 0, "the LDS slab index returns to its start after a group");
+    struct OpsT { double M[DT][NX], X[DT][NX], ts[DT], es[DT]; };
+    const int nst = S, ngt = (nst + DT - 1) / DT;
+    auto load = [&](OpsT& o, int u0) {
 #pragma unroll
-      for (int u = 0; u < D; ++u) {
-        const int sg = (u0 + u < nsteps) ? S - 1 - (u0 + u) : 1;
+      for (int u = 0; u < DT; ++u) {
+        const int sg = (u0 + u < nst) ? S - 1 - (u0 + u) : 0;
 #pragma unroll
-        for (int l = 0; l < NX; ++l) o.M[u][l] = rowp[(((size_t)sg * 3 + 0) * NX * NX + l) * P_];
-        o.c[u] = tseg[((size_t)sg * NX + i) * P_ + col];
+        for (int l = 0; l < NX; ++l) {
+          o.M[u][l] = rowp[(((size_t)sg * 3 + 0) * NX * NX + l) * P_];
+          o.X[u][l] = rowp[(((size_t)sg * 3 + 1) * NX * NX + l) * P_];
+        }
+        o.ts[u] = tseg[((size_t)sg * NX + i) * P_ + col];
+        o.es[u] = eseg[((size_t)sg * NX + i) * P_ + col];
       }
     };
-    auto steps = [&](const Ops& o, int u0) {
+    auto steps = [&](const OpsT& o, int u0) {
 #pragma unroll
-      for (int u = 0; u < D; ++u) {
-        const bool valid = u0 + u < nsteps;
+      for (int u = 0; u < DT; ++u) {
+        const bool valid = u0 + u < nst;
         const int sg = S - 1 - (u0 + u);
-        double a = o.c[u];
+        double a = o.ts[u], c = o.es[u];
 #pragma unroll
-        for (int l = 0; l < NX; ++l) a = fma(o.M[u][l], vec[u & 1][l][lane], a);
-        a = valid ? a : mine;
+        for (int l = 0; l < NX; ++l) {
+          const double v = vec[u & 1][l][lane];
+          a = fma(o.M[u][l], v, a);
+          c = fma(o.X[u][l], v, c);
+        }
+        const bool chain = valid && sg >= 1;           // (sg = 0: only c(0) is left to form)
+        a = chain ? a : mine;
         mine = a;
         vec[(u & 1) ^ 1][i][lane] = a;
-        if (valid) tin[((size_t)(sg - 1) * NX + i) * P_ + col] = a;
+        if (chain) tin[((size_t)(sg - 1) * NX + i) * P_ + col] = a;
+        if (valid) eseg[((size_t)sg * NX + i) * P_ + col] = c;
         lds_barrier();
       }
     };
-    Ops A, B;
+    OpsT A, B;
     load(A, 0);
     lds_barrier();
-    for (int g = 0; g < ngroups; g += 2) {
-      if (g + 1 < ngroups) load(B, (g + 1) * D);
-      steps(A, g * D);
-      if (g + 1 >= ngroups) break;
-      if (g + 2 < ngroups) load(A, (g + 2) * D);
-      steps(B, (g + 1) * D);
+    for (int g = 0; g < ngt; g += 2) {
+      if (g + 1 < ngt) load(B, (g + 1) * DT);
+      steps(A, g * DT);
+      if (g + 1 >= ngt) break;
+      if (g + 2 < ngt) load(A, (g + 2) * DT);
+      steps(B, (g + 1) * DT);
     }
   }
-  __syncthreads();                 // t_in of every segment is in memory (written by this workgroup)
-  // ---- c(s) = eseg(s) + Xi_s t_in(s), s = 0 .. S-2: independent of each other; written over eseg(s) (this lane's own element) ----
-#pragma unroll 8
-  for (int sg = 0; sg < S - 1; ++sg) {
-    double a = eseg[((size_t)sg * NX + i) * P_ + col];
-#pragma unroll
-    for (int l = 0; l < NX; ++l) a = fma(rowp[(((size_t)sg * 3 + 1) * NX * NX + l) * P_], tin[((size_t)sg * NX + l) * P_ + col], a);
-    eseg[((size_t)sg * NX + i) * P_ + col] = a;
-  }
+  __syncthreads();                 // c(s) of every segment is in memory (each element written by the lane that reads it below)
   // ---- x chain: step sg = 0 .. S-2 produces x_in(sg+1) ----
   {
     mine = x0[(size_t)i * P_ + col];
