@@ -620,8 +620,8 @@ int upload_factor(admm_handle* h) {
   HIP_TRY(hipMemcpy(h->recB, h->fac.recB.data(), sizeof(double) * h->fac.recB.size(), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(h->recF, h->fac.recF.data(), sizeof(double) * h->fac.recF.size(), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(h->recS, h->fac.recS.data(), sizeof(double) * h->fac.recS.size(), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(h->scanWp, h->fac.scanWp.data(), sizeof(double) * h->fac.scanWp.size(), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(h->scan_range, h->fac.scanRange.data(), sizeof(int32_t) * h->fac.scanRange.size(), hipMemcpyHostToDevice));
+  if (!h->scan_gemv) HIP_TRY(hipMemcpy(h->scanWp, h->fac.scanWp.data(), sizeof(double) * h->fac.scanWp.size(), hipMemcpyHostToDevice));
+  if (!h->scan_gemv) HIP_TRY(hipMemcpy(h->scan_range, h->fac.scanRange.data(), sizeof(int32_t) * h->fac.scanRange.size(), hipMemcpyHostToDevice));
   int rc;
   if (h->scan_gemv && (rc = upload_scan_dense(h->fac.scanW, h->fac.scanM, h->fac.scanK, h->scanWd, h->scan_rows))) return rc;
   h->alt_state = admm_handle::ALT_NONE;
@@ -637,8 +637,8 @@ int upload_factor(admm_handle* h) {
   if (h->alt_allowed) {
     HIP_TRY(hipMemcpy(h->recFE, h->fac.recFE.data(), sizeof(double) * h->fac.recFE.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->recBE, h->fac.recBE.data(), sizeof(double) * h->fac.recBE.size(), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(h->scanWpB, h->fac.scanWpB.data(), sizeof(double) * h->fac.scanWpB.size(), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(h->scan_rangeB, h->fac.scanRangeB.data(), sizeof(int32_t) * h->fac.scanRangeB.size(), hipMemcpyHostToDevice));
+    if (!h->scan_gemv) HIP_TRY(hipMemcpy(h->scanWpB, h->fac.scanWpB.data(), sizeof(double) * h->fac.scanWpB.size(), hipMemcpyHostToDevice));
+    if (!h->scan_gemv) HIP_TRY(hipMemcpy(h->scan_rangeB, h->fac.scanRangeB.data(), sizeof(int32_t) * h->fac.scanRangeB.size(), hipMemcpyHostToDevice));
     if (h->scan_gemv && (rc = upload_scan_dense(h->fac.scanWB, h->fac.scanM, h->fac.scanK, h->scanWBd, h->scan_rowsB))) return rc;
   }
   return ADMM_OK;
@@ -1068,8 +1068,11 @@ int admm_setup(admm_handle** out, const admm_problem* p, const admm_options* o_i
       h->mfma_mode = 2;          // FP64: the fp64 MFMA form where it is the faster one (ADMM_FLAG_NO_MFMA)
     }
   }
+  // batches of a few QPs run the scan as a matrix-vector product (xscan_gemv_kernel) and need no MFMA-packed scan matrices
+  h->scan_gemv = h->batch <= admm::SCAN_GEMV_MAXCOLS && !(o.flags & ADMM_FLAG_SCAN_CHAIN) &&
+                 std::getenv("ADMM_NO_GEMV_SCAN") == nullptr;
   std::string err;
-  rc = admm::factorise(*p, o.rho, h->S, h->fac, err, h->mfma_mode);
+  rc = admm::factorise(*p, o.rho, h->S, h->fac, err, h->mfma_mode, !h->scan_gemv);
   if (rc) { release(h); return fail(rc, err); }
   // Conditioning guard of the parallel-in-time form: the segment coupling is exact in exact
   // arithmetic, but its transfer matrices are products of closed-loop matrices, and for a barely
@@ -1081,7 +1084,7 @@ int admm_setup(admm_handle** out, const admm_problem* p, const admm_options* o_i
   if (o.segments == 0) {
     while (h->fac.S > 1 && scan_growth(h->fac) > SCAN_GROWTH_MAX) {
       const int S2 = std::max(1, h->fac.S / 2);
-      rc = admm::factorise(*p, o.rho, S2, h->fac, err, h->mfma_mode);
+      rc = admm::factorise(*p, o.rho, S2, h->fac, err, h->mfma_mode, !h->scan_gemv);
       if (rc) { release(h); return fail(rc, err); }
     }
   }
@@ -1110,8 +1113,6 @@ int admm_setup(admm_handle** out, const admm_problem* p, const admm_options* o_i
   {  // scan operands: in = tseg | x0 | eseg | pad,  out = t_in | pad | x_in | pad  (admm_factor.hpp)
     const size_t Sn = (size_t)h->S * h->n;
     TRY_RELEASE(dalloc(&h->scan_in, (size_t)h->fac.scanK * P));
-    h->scan_gemv = h->batch <= admm::SCAN_GEMV_MAXCOLS && !(o.flags & ADMM_FLAG_SCAN_CHAIN) &&
-                   std::getenv("ADMM_NO_GEMV_SCAN") == nullptr;
     {  // split-K of the scan when the grid would be small: aim at >= 256 workgroups, <= 8 slices
       const int wgs = (h->pitch / 64) * (h->fac.scanM / 16 / admm::SCAN_MT);
       int sp = 1;
@@ -1177,8 +1178,8 @@ int admm_setup(admm_handle** out, const admm_problem* p, const admm_options* o_i
     HIP_TRY_RELEASE(hipMemsetAsync(h->mvec, 0, sizeof(double) * (size_t)h->N * h->m * P, h->stream));
     HIP_TRY_RELEASE(hipMemcpy(h->recFE, h->fac.recFE.data(), sizeof(double) * h->fac.recFE.size(), hipMemcpyHostToDevice));
     HIP_TRY_RELEASE(hipMemcpy(h->recBE, h->fac.recBE.data(), sizeof(double) * h->fac.recBE.size(), hipMemcpyHostToDevice));
-    HIP_TRY_RELEASE(hipMemcpy(h->scanWpB, h->fac.scanWpB.data(), sizeof(double) * h->fac.scanWpB.size(), hipMemcpyHostToDevice));
-    HIP_TRY_RELEASE(hipMemcpy(h->scan_rangeB, h->fac.scanRangeB.data(), sizeof(int32_t) * h->fac.scanRangeB.size(), hipMemcpyHostToDevice));
+    if (!h->scan_gemv) HIP_TRY_RELEASE(hipMemcpy(h->scanWpB, h->fac.scanWpB.data(), sizeof(double) * h->fac.scanWpB.size(), hipMemcpyHostToDevice));
+    if (!h->scan_gemv) HIP_TRY_RELEASE(hipMemcpy(h->scan_rangeB, h->fac.scanRangeB.data(), sizeof(int32_t) * h->fac.scanRangeB.size(), hipMemcpyHostToDevice));
   }
   const size_t part_chunks = (size_t)(h->zchunks > h->S ? h->zchunks : h->S);
   TRY_RELEASE(dalloc(&h->part, part_chunks * 5 * P));
@@ -1211,8 +1212,8 @@ int admm_setup(admm_handle** out, const admm_problem* p, const admm_options* o_i
   HIP_TRY_RELEASE(hipMemcpy(h->recB, h->fac.recB.data(), sizeof(double) * h->fac.recB.size(), hipMemcpyHostToDevice));
   HIP_TRY_RELEASE(hipMemcpy(h->recF, h->fac.recF.data(), sizeof(double) * h->fac.recF.size(), hipMemcpyHostToDevice));
   HIP_TRY_RELEASE(hipMemcpy(h->recS, h->fac.recS.data(), sizeof(double) * h->fac.recS.size(), hipMemcpyHostToDevice));
-  HIP_TRY_RELEASE(hipMemcpy(h->scanWp, h->fac.scanWp.data(), sizeof(double) * h->fac.scanWp.size(), hipMemcpyHostToDevice));
-  HIP_TRY_RELEASE(hipMemcpy(h->scan_range, h->fac.scanRange.data(), sizeof(int32_t) * h->fac.scanRange.size(), hipMemcpyHostToDevice));
+  if (!h->scan_gemv) HIP_TRY_RELEASE(hipMemcpy(h->scanWp, h->fac.scanWp.data(), sizeof(double) * h->fac.scanWp.size(), hipMemcpyHostToDevice));
+  if (!h->scan_gemv) HIP_TRY_RELEASE(hipMemcpy(h->scan_range, h->fac.scanRange.data(), sizeof(int32_t) * h->fac.scanRange.size(), hipMemcpyHostToDevice));
   HIP_TRY_RELEASE(hipMemcpy(h->seg_start, h->fac.seg_start.data(), sizeof(int32_t) * h->fac.seg_start.size(), hipMemcpyHostToDevice));
   if (h->scan_gemv) {
     TRY_RELEASE(upload_scan_dense(h->fac.scanW, h->fac.scanM, h->fac.scanK, h->scanWd, h->scan_rows));
@@ -1319,7 +1320,7 @@ static void spec_start(admm_handle* h) {
       try {
         admm::Factor f;
         std::string err;
-        rc = admm::factorise(p, s->rho, hc->S, f, err, hc->mfma_mode);
+        rc = admm::factorise(p, s->rho, hc->S, f, err, hc->mfma_mode, !hc->scan_gemv);
         s->f = std::move(f);
         s->err = std::move(err);
       } catch (...) {
@@ -1392,7 +1393,7 @@ static int set_rho_internal(admm_handle* h, double rho_new) {
     f = std::move(sp->f);
     ++h->spec_hits;
   } else {
-    rc = admm::factorise(p, rho_new, h->S, f, err, h->mfma_mode);
+    rc = admm::factorise(p, rho_new, h->S, f, err, h->mfma_mode, !h->scan_gemv);
     ++h->spec_misses;
   }
   lap("factor (take / compute)");
@@ -1464,7 +1465,7 @@ int admm_update_problem(admm_handle* h, const admm_problem* p) {
   }
   admm::Factor f;
   std::string err;
-  if ((rc = admm::factorise(*p, h->opt.rho, h->S, f, err, h->mfma_mode))) return fail(rc, err);
+  if ((rc = admm::factorise(*p, h->opt.rho, h->S, f, err, h->mfma_mode, !h->scan_gemv))) return fail(rc, err);
   if (f.recB.size() != h->fac.recB.size() || f.scanWp.size() != h->fac.scanWp.size())
     return fail(ADMM_ERR_NUMERIC, "internal: record sizes changed on refactor");
   if (h->auto_segments && h->S > 1 && scan_growth(f) > SCAN_GROWTH_MAX)

@@ -335,7 +335,7 @@ Mat pinv_psd(const Mat& a_in, int n, double tol) {
 // is enabled.  Needs every A_k invertible (true for any discretised ODE).
 // Leaves f.alt_ok false if a pivot fails, a transfer matrix overflows or the verification misses.
 void build_alternating(Factor& f, const std::vector<Mat>& A, const std::vector<Mat>& B, const Mat& Q,
-                       const Mat& R, const Mat& QN, double rho) {
+                       const Mat& R, const Mat& QN, double rho, bool pack_scan_mfma) {
   const int N = f.N, n = f.n, m = f.m, S = f.S;
   f.alt_ok = false;
   f.RFE = rec_fe_size(n, m);
@@ -574,7 +574,9 @@ void build_alternating(Factor& f, const std::vector<Mat>& A, const std::vector<M
     if (!(f.alt_check <= 5e-12)) return;
   }
   timer.lap("  alt: verification");
-  pack_scan(f.scanWB, M, K, f.scanWpB, f.scanRangeB);
+  f.scanWpB.clear();
+  f.scanRangeB.clear();
+  if (pack_scan_mfma) pack_scan(f.scanWB, M, K, f.scanWpB, f.scanRangeB);
   f.alt_ok = true;
   timer.lap("  alt: pack scan");
 }
@@ -768,7 +770,7 @@ void build_mfma(Factor& f, int mode) {
 
 void set_factor_thread_cap(int cap) { g_thread_cap = cap; }
 
-int factorise(const admm_problem& p, double rho, int segments, Factor& f, std::string& err, int mfma_mode) {
+int factorise(const admm_problem& p, double rho, int segments, Factor& f, std::string& err, int mfma_mode, bool pack_scan_mfma) {
   if (mfma_mode < 0 || mfma_mode > 2) { err = "mfma_mode must be 0, 1 or 2"; return ADMM_ERR_INVALID; }
   if (mfma_mode != 0 && !mfma_dims(p.n, p.m)) { err = "the MFMA form needs n <= 12 and m <= 8"; return ADMM_ERR_UNSUPPORTED; }
   const int N = p.N, n = p.n, m = p.m;
@@ -931,11 +933,13 @@ int factorise(const admm_problem& p, double rho, int segments, Factor& f, std::s
       rowblock_step(f.scanW, K, n, r_x + (s + 1) * n, &Th[s], r_x + s * n, &Xi[s], r_t + s * n, c_e + s * n);
     for (double v : f.scanW)
       if (!std::isfinite(v)) { err = "scan matrix overflowed; use more segments"; return ADMM_ERR_NUMERIC; }
-    pack_scan(f.scanW, M, K, f.scanWp, f.scanRange);
+    f.scanWp.clear();
+    f.scanRange.clear();
+    if (pack_scan_mfma) pack_scan(f.scanW, M, K, f.scanWp, f.scanRange);
   }
 
   timer.lap("scan matrix");
-  build_alternating(f, A, B, Q, R, QN, rho);
+  build_alternating(f, A, B, Q, R, QN, rho, pack_scan_mfma);
   timer.lap("alternating form");
   f.mfma_mode = mfma_mode;
   f.recMF.clear();

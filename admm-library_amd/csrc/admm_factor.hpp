@@ -104,7 +104,10 @@ inline int rec_be_size(int n, int m) { return rec_be_layout(n, m).SIZE; }
 // Validates nothing about the batch; only dynamics/weights.  Returns an
 // admm_status; err receives a message on failure.
 // mfma_mode: 0 = no MFMA records; 1 / 2 = also pack the MFMA form, mixed / fp64 (needs mfma_dims(n, m)).
-int factorise(const admm_problem& p, double rho, int segments, Factor& out, std::string& err, int mfma_mode = 0);
+// pack_scan_mfma = false leaves scanWp / scanRange (and the B pair) empty: handles whose scan runs as a matrix-vector
+// product (batches of <= 4 QPs) only need the dense matrices.
+int factorise(const admm_problem& p, double rho, int segments, Factor& out, std::string& err, int mfma_mode = 0,
+              bool pack_scan_mfma = true);
 
 // The per-stage / per-segment loops of factorise run on host threads (ADMM_FACTOR_THREADS, default min(cores, 16)); this
 // caps the count for factorisations started from the calling thread (0 = no cap).  Used by the background refactors of
