@@ -28,8 +28,8 @@ void launch_dim(const PLaunch& l, PKernel k) {
                          l.Psd, l.Segd, l.grow, l.pitch, l.batch);
       break;
     case PKernel::SCAN:
-      hipLaunchKernelGGL((pscan_kernel<NX>), grid, dim3(PI_THREADS * NX), 0, l.stream, l.Segd, l.tseg, l.eseg, l.x0, l.tin, l.xin,
-                         l.S, l.pitch);
+      hipLaunchKernelGGL((pscan_kernel<NX>), dim3(l.pitch / PscanShape<NX>::QPW), block, 0, l.stream, l.Segd, l.tseg, l.eseg, l.x0,
+                         l.tin, l.xin, l.S, l.pitch);
       break;
     case PKernel::FACTOR:
       hipLaunchKernelGGL((pfactor_kernel<NX, NU>), grid, block, 0, l.stream, l.Ad, l.Bd, l.Q, l.R, l.QN, l.rhov, l.todo, l.Kd, l.Sd,

@@ -558,42 +558,38 @@ __global__ __launch_bounds__(PI_THREADS) void pseg_kernel(
 
 // Segment scan, per QP (both chains are S sequential n x n mat-vecs with the QP's own matrices):
 //     t_in(S-1) = 0;  t_in(s-1) = tseg(s) + Phi_s t_in(s)          x_in(0) = x0;  x_in(s+1) = c(s) + Th_s x_in(s),  c(s) = eseg(s) + Xi_s t_in(s)
-// Workgroup = 64 QPs x n rows: wave i forms ROW i of every mat-vec, so a lane loads n doubles per step (not n^2) and the
-// operands of the next PSCAN_D steps wait in registers; the vector passes between the waves through a double-buffered LDS
-// slab with ONE barrier per step -- a barrier that waits for LDS traffic only (lds_barrier): __syncthreads also drains the
-// vector-memory queue, i.e. every step would wait for the prefetches and for its own store of t_in / x_in (measured: 3 us
-// per step, the scan of 32 segments cost 188 us against 50 us for each sweep).  c(s) does not depend on the x chain: it is
-// formed in the t chain, at the step that has t_in(s) in the slab anyway, and overwrites eseg(s).
+// One WAVE serves QPW QPs x n rows: lane (i, c) forms row i of every mat-vec of QP c, so it loads n doubles per step (not
+// n^2; the operands of the next PSCAN_D steps wait in registers) and the vector never leaves the wave: element l of QP c's
+// vector is the running value of lane (l, c), fetched with a cross-lane read -- no LDS, no barrier.  (History: one lane per QP
+// doing whole mat-vecs, 2.5 us per step; one wave per row with the vector in LDS and a barrier per step, 0.7 us per step
+// whatever was taken out of it -- the scan of 32 segments cost as much as a whole sweep.)  c(s) does not depend on the x chain:
+// it is formed in the t chain, at the step whose input is t_in(s), and overwrites eseg(s).
 constexpr int PSCAN_D = 8;        // steps whose operands are prefetched as one group
-
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+template <int NX> struct PscanShape { static constexpr int QPW = NX <= 2 ? 32 : (NX <= 4 ? 16 : (NX <= 8 ? 8 : 4)); };
 
 template <int NX>
-__global__ __launch_bounds__(PI_THREADS * NX) void pscan_kernel(
+__global__ __launch_bounds__(PI_THREADS) void pscan_kernel(
     const double* __restrict__ Segd, const double* __restrict__ tseg, double* __restrict__ eseg,
     const double* __restrict__ x0, double* __restrict__ tin, double* __restrict__ xin, int S, int pitch) {
   // (eseg and tin are each read and written here, through these pointers only; no two of the arrays overlap)
-  constexpr int D = PSCAN_D;
-  static_assert(D % 2 == 0, "the LDS slab index returns to its start after a group");
-  __shared__ double vec[2][NX][PI_THREADS];
-  const int lane = threadIdx.x & (PI_THREADS - 1);
-  const int i = __builtin_amdgcn_readfirstlane(threadIdx.x / PI_THREADS);     // this wave's row
-  const int col = blockIdx.x * PI_THREADS + lane;                             // pitch is a multiple of 64
+  constexpr int D = PSCAN_D, QPW = PscanShape<NX>::QPW;
+  static_assert(QPW * NX <= PI_THREADS, "rows x QPs of a wave");
+  const int lane = threadIdx.x;
+  const int c = lane % QPW, ir = lane / QPW;
+  const bool live = ir < NX;                          // (lanes beyond n x QPW shadow row 0: loads and arithmetic only)
+  const int i = live ? ir : 0;
+  const int col = blockIdx.x * QPW + c;               // pitch is a multiple of 64, hence of QPW
   const size_t P_ = (size_t)pitch;
-  const double* rowp = Segd + (size_t)i * NX * P_ + col;                      // row i of block (sg, which): + ((sg * 3 + which) * NX * NX + l) * P_
-  const int nsteps = S - 1, ngroups = (nsteps + D - 1) / D;
-  // Both chains run as groups of D steps with straight-line code inside a group: a step beyond the chain's end repeats the
-  // lane's value and stores nothing (its operand loads are clamped to valid addresses), so every barrier is reached by every wave
-  // and the compiler's wait counts see one path.
-  struct Ops { double M[D][NX], c[D]; };
+  const double* rowp = Segd + (size_t)i * NX * P_ + col;     // row i of block (sg, which): + ((sg * 3 + which) * NX * NX + l) * P_
+  auto element = [&](double mine, int l) { return __shfl(mine, l * QPW + c, PI_THREADS); };   // element l of this QP's vector
+  // Both chains run as groups of steps with straight-line code inside a group: a step beyond the chain's end keeps the
+  // lane's value and stores nothing (its operand loads are clamped to valid addresses).
   double mine = 0.0;
-  // ---- t chain: step u = 0 .. S-1 handles segment sg = S-1-u: t_in(sg) is in the slab; it produces t_in(sg-1) (sg >= 1) and,
-  //      from the same LDS reads, c(sg) = eseg(sg) + Xi_sg t_in(sg), which overwrites eseg(sg) (this lane's own element) ----
-  vec[0][i][lane] = 0.0;
-  tin[((size_t)(S - 1) * NX + i) * P_ + col] = 0.0;
+  // ---- t chain: step u = 0 .. S-1 handles segment sg = S-1-u: the wave holds t_in(sg); it produces t_in(sg-1) (sg >= 1)
+  //      and c(sg) = eseg(sg) + Xi_sg t_in(sg) from the same cross-lane reads ----
+  if (live) tin[((size_t)(S - 1) * NX + i) * P_ + col] = 0.0;
   {
-    constexpr int DT = D / 2;                        // two rows of operands per step: half the steps per group
-    static_assert(DT % 2 == 0, "the LDS slab index returns to its start after a group");
+    constexpr int DT = D / 2;                         // two rows of operands per step: half the steps per group
     struct OpsT { double M[DT][NX], X[DT][NX], ts[DT], es[DT]; };
     const int nst = S, ngt = (nst + DT - 1) / DT;
     auto load = [&](OpsT& o, int u0) {
@@ -614,25 +610,21 @@ __global__ __launch_bounds__(PI_THREADS * NX) void pscan_kernel(
       for (int u = 0; u < DT; ++u) {
         const bool valid = u0 + u < nst;
         const int sg = S - 1 - (u0 + u);
-        double a = o.ts[u], c = o.es[u];
+        double a = o.ts[u], cc = o.es[u];
 #pragma unroll
         for (int l = 0; l < NX; ++l) {
-          const double v = vec[u & 1][l][lane];
+          const double v = element(mine, l);
           a = fma(o.M[u][l], v, a);
-          c = fma(o.X[u][l], v, c);
+          cc = fma(o.X[u][l], v, cc);
         }
         const bool chain = valid && sg >= 1;           // (sg = 0: only c(0) is left to form)
-        a = chain ? a : mine;
-        mine = a;
-        vec[(u & 1) ^ 1][i][lane] = a;
-        if (chain) tin[((size_t)(sg - 1) * NX + i) * P_ + col] = a;
-        if (valid) eseg[((size_t)sg * NX + i) * P_ + col] = c;
-        lds_barrier();
+        mine = chain ? a : mine;
+        if (chain && live) tin[((size_t)(sg - 1) * NX + i) * P_ + col] = a;
+        if (valid && live) eseg[((size_t)sg * NX + i) * P_ + col] = cc;
       }
     };
     OpsT A, B;
     load(A, 0);
-    lds_barrier();
     for (int g = 0; g < ngt; g += 2) {
       if (g + 1 < ngt) load(B, (g + 1) * DT);
       steps(A, g * DT);
@@ -641,12 +633,12 @@ __global__ __launch_bounds__(PI_THREADS * NX) void pscan_kernel(
       steps(B, (g + 1) * DT);
     }
   }
-  __syncthreads();                 // c(s) of every segment is in memory (each element written by the lane that reads it below)
-  // ---- x chain: step sg = 0 .. S-2 produces x_in(sg+1) ----
+  // ---- x chain: step sg = 0 .. S-2 produces x_in(sg+1) (c(sg): this lane's own store above) ----
   {
+    struct Ops { double M[D][NX], c[D]; };
+    const int nsteps = S - 1, ngroups = (nsteps + D - 1) / D;
     mine = x0[(size_t)i * P_ + col];
-    vec[0][i][lane] = mine;
-    xin[(size_t)i * P_ + col] = mine;
+    if (live) xin[(size_t)i * P_ + col] = mine;
     auto load = [&](Ops& o, int u0) {
 #pragma unroll
       for (int u = 0; u < D; ++u) {
@@ -663,17 +655,13 @@ __global__ __launch_bounds__(PI_THREADS * NX) void pscan_kernel(
         const int sg = u0 + u;
         double a = o.c[u];
 #pragma unroll
-        for (int l = 0; l < NX; ++l) a = fma(o.M[u][l], vec[u & 1][l][lane], a);
-        a = valid ? a : mine;
-        mine = a;
-        vec[(u & 1) ^ 1][i][lane] = a;
-        if (valid) xin[((size_t)(sg + 1) * NX + i) * P_ + col] = a;
-        lds_barrier();
+        for (int l = 0; l < NX; ++l) a = fma(o.M[u][l], element(mine, l), a);
+        mine = valid ? a : mine;
+        if (valid && live) xin[((size_t)(sg + 1) * NX + i) * P_ + col] = a;
       }
     };
     Ops A, B;
     load(A, 0);
-    lds_barrier();
     for (int g = 0; g < ngroups; g += 2) {
       if (g + 1 < ngroups) load(B, (g + 1) * D);
       steps(A, g * D);
