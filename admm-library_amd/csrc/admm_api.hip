@@ -767,7 +767,8 @@ int setup_pinst(admm_handle* h, const admm_problem* p) {
   h->pbounds = p->stage_bounds == 2;
   // Segments in time (csrc/admm_pinst.hpp): one lane sweeps one segment of one QP, so an iteration takes N / S dependent
   // stage round trips instead of N.  Automatic count: enough (64-QP wave, segment) pairs for one wave per SIMD, segments
-  // of at least 8 stages, at most 32 (the scan is S sequential steps per QP); large batches fill the chip alone (S = 1).
+  // of at least 8 stages, at most 64 (32 from 512 QPs: the scan is S sequential steps per QP); large batches fill the chip
+  // alone (S = 1).
   h->auto_segments = o.segments == 0;
   {
     int S = o.segments;
@@ -777,12 +778,12 @@ int setup_pinst(admm_handle* h, const admm_problem* p) {
       //  alone reaches the HBM roofline and the segments' extra operands -- Omega_k, Psi_k: +16 % bytes -- only cost)
       S = waves <= 64 ? (4 * h->num_cus) / std::max(1, waves) : 1;
       if (S > h->N / 8) S = h->N / 8;
-      if (S > 32) S = 32;
+      if (S > (waves <= 4 ? 64 : 32)) S = waves <= 4 ? 64 : 32;     // (from 512 QPs the sweeps stop gaining, the scan keeps growing)
       if (std::getenv("ADMM_PI_NO_SEGMENTS")) S = 1;
     }
     if (S > h->N) S = h->N;
     if (S < 1) S = 1;
-    if (S > 32) return fail(ADMM_ERR_INVALID, "options.segments: at most 32 with per-instance dynamics");
+    if (S > 64) return fail(ADMM_ERR_INVALID, "options.segments: at most 64 with per-instance dynamics");
     h->S = S;
   }
   h->alt = h->alt_allowed = false;

@@ -82,7 +82,7 @@ typedef struct admm_options {
   double eps_rel;
   int32_t max_iter;
   int32_t check_interval; /* residuals + stop test every this many iterations */
-  int32_t segments;       /* parallel-in-time segments of the x-update; 0 = auto (per-instance dynamics: at most 32) */
+  int32_t segments;       /* parallel-in-time segments of the x-update; 0 = auto (per-instance dynamics: at most 64) */
   int32_t device;         /* HIP device ordinal; -1 = current device */
   int32_t zrows;          /* rows per workgroup chunk in the z/dual kernel; 0 = auto */
   int32_t flags;          /* ADMM_FLAG_* */

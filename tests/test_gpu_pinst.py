@@ -35,7 +35,7 @@ def test_iterates_match_the_oracle(gpu, idx, alpha, segments):
     time with per-QP transfer matrices computed on the device (pseg_kernel, pscan_kernel; capped at N)."""
     p = pkg.random_instances(**CASES[idx])
     with pkg.Solver(p, pkg.Options(rho=0.3, alpha=alpha, segments=segments)) as s:
-        want = {0: max(1, min(32, p.N // 8)), 1: 1, 5: min(5, p.N)}[segments]
+        want = {0: max(1, min(64, p.N // 8)), 1: 1, 5: min(5, p.N)}[segments]
         assert s.geometry()["segments"] == want
         done = 0
         for upto in (1, 2, 3, 10, 40):
