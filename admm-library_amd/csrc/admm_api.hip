@@ -107,6 +107,7 @@ struct admm_handle {
   // segments in time of the per-instance path (S > 1; csrc/admm_pinst.hpp, pseg_kernel): per-QP transfer matrices
   double *Omd = nullptr, *Psd = nullptr, *Segd = nullptr;
   int* pgrow = nullptr;
+  bool pi_rows = false;          // small batches: sweeps with a QP's rows spread over lanes (csrc/admm_pinst_rows.hpp)
   // per-QP rho (every QP of a per-instance problem has its own factor, so the adaptive rule runs QP by QP on the device)
   double *rho_d = nullptr, *cscale_d = nullptr;     // [pitch]
   int *nupd_d = nullptr, *todo_d = nullptr, *nchanged_d = nullptr;
@@ -175,6 +176,7 @@ admm::PLaunch plaunch_of(const admm_handle* h) {
   l.rhov = h->rho_d; l.todo = nullptr;
   l.S = h->S; l.seg_start = h->seg_start; l.Omd = h->Omd; l.Psd = h->Psd; l.Segd = h->Segd;
   l.tseg = h->tseg; l.eseg = h->eseg; l.tin = h->tin; l.xin = h->xin; l.grow = h->pgrow;
+  l.rows = h->pi_rows;
   l.Ad = h->Ad; l.Bd = h->Bd; l.Q = h->Qd; l.R = h->Rd; l.QN = h->QNd; l.Kd = h->Kd; l.Sd = h->Sd; l.fail = h->pfail;
   l.lo = h->pbounds ? h->lod : h->lo; l.hi = h->pbounds ? h->hid : h->hi;
   l.z = h->z; l.y = h->y; l.q = h->q; l.x0 = h->x0; l.v = h->v; l.w = h->w; l.dbuf = h->dbuf; l.part = h->part;
@@ -785,6 +787,12 @@ int setup_pinst(admm_handle* h, const admm_problem* p) {
     if (S < 1) S = 1;
     if (S > 64) return fail(ADMM_ERR_INVALID, "options.segments: at most 64 with per-instance dynamics");
     h->S = S;
+    // few QPs: a lane per (QP, row) instead of a lane per QP (ADMM_PI_LANE_PER_QP=1 / ADMM_PI_ROWS=1 force either form)
+    // (measured, N = 1000: 64 QPs 29 -> 23 us per sweep, N = 200: 15 -> 9 us; from 128 QPs the 8-QP waves' 64-byte accesses lose:
+    //  256 QPs 44 -> 86 us)
+    h->pi_rows = h->pitch <= 64;
+    if (std::getenv("ADMM_PI_LANE_PER_QP")) h->pi_rows = false;
+    if (std::getenv("ADMM_PI_ROWS")) h->pi_rows = true;
   }
   h->alt = h->alt_allowed = false;
   h->time_varying = 2;

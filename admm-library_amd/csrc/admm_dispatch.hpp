@@ -63,6 +63,7 @@ struct PLaunch {
   double *Omd, *Psd, *Segd;            // Omega_k [N][n*m], Psi_k [N][m*n], (Phi, Xi, Th) [S][3][n*n], all x pitch
   double *tseg, *eseg, *tin, *xin;     // [S][n][pitch]
   int* grow;                           // SEGMENTS: set if a transfer matrix exceeds the conditioning bound
+  bool rows;                           // small batches: the sweeps with a QP's rows spread over lanes (admm_pinst_rows.hpp)
 };
 enum class PKernel { FACTOR, XB, XF, XFZ, SEGMENTS, SCAN };
 bool launch_pinst(const PLaunch& l, PKernel k, bool query_only);

@@ -1,6 +1,7 @@
 // Per-instance dynamics (admm_pinst.hpp): instantiations and launcher.  Adding a shape = adding X(n, m) below.
 #include "admm_dispatch.hpp"
 #include "admm_pinst.hpp"
+#include "admm_pinst_rows.hpp"
 
 #define ADMM_PINST_DIMS(X) X(6, 3) X(2, 1) X(4, 2) X(3, 2)
 
@@ -21,6 +22,7 @@ void launch_dim(const PLaunch& l, PKernel k) {
   const bool seg = l.S > 1;
   const dim3 grid((l.pitch + PI_THREADS - 1) / PI_THREADS), block(PI_THREADS);
   const dim3 sgrid((l.pitch + PI_THREADS - 1) / PI_THREADS, l.S > 0 ? l.S : 1);     // one wave per (64 QPs, segment)
+  const dim3 rgrid(l.pitch / PscanShape<NX>::QPW, l.S > 0 ? l.S : 1);               // rows over lanes: QPW QPs per wave
   const bool relax = l.alpha != 1.0;
   switch (k) {
     case PKernel::SEGMENTS:
@@ -38,7 +40,13 @@ void launch_dim(const PLaunch& l, PKernel k) {
     case PKernel::XB: {
 #define XB(HQ, VF, PB_)                                                                                                          \
   do {                                                                                                                           \
-    if (seg)                                                                                                                     \
+    if (l.rows && seg)                                                                                                           \
+      hipLaunchKernelGGL((pxb_rows_kernel<NX, NU, HQ, VF, PB_, true>), rgrid, block, 0, l.stream, l.vform ? l.v : l.z, l.y, l.q,  \
+                         l.Ad, l.Bd, l.Kd, l.Sd, l.lo, l.hi, l.dbuf, l.rhov, l.N, l.pitch, l.Omd, l.seg_start, l.tseg, l.eseg);   \
+    else if (l.rows)                                                                                                             \
+      hipLaunchKernelGGL((pxb_rows_kernel<NX, NU, HQ, VF, PB_, false>), rgrid, block, 0, l.stream, l.vform ? l.v : l.z, l.y, l.q, \
+                         l.Ad, l.Bd, l.Kd, l.Sd, l.lo, l.hi, l.dbuf, l.rhov, l.N, l.pitch, nullptr, nullptr, nullptr, nullptr);   \
+    else if (seg)                                                                                                                \
       hipLaunchKernelGGL((pxb_kernel<NX, NU, HQ, VF, PB_, true>), sgrid, block, 0, l.stream, l.vform ? l.v : l.z, l.y, l.q, l.Ad, \
                          l.Bd, l.Kd, l.Sd, l.lo, l.hi, l.dbuf, l.rhov, l.N, l.pitch, l.Omd, l.seg_start, l.tseg, l.eseg);         \
     else                                                                                                                         \
@@ -53,7 +61,15 @@ void launch_dim(const PLaunch& l, PKernel k) {
       break;
     }
     case PKernel::XF:      // read-out: w of the last x-update
-      if (seg)
+      if (l.rows && seg)
+        hipLaunchKernelGGL((pxfz_rows_kernel<NX, NU, false, false, false, false, false, true, true>), rgrid, block, 0, l.stream,
+                           l.dbuf, l.x0, l.Ad, l.Bd, l.Kd, l.lo, l.hi, l.z, l.y, l.v, l.w, l.part, l.alpha, l.N, l.pitch, l.Psd,
+                           l.seg_start, l.tin, l.xin);
+      else if (l.rows)
+        hipLaunchKernelGGL((pxfz_rows_kernel<NX, NU, false, false, false, false, false, true, false>), rgrid, block, 0, l.stream,
+                           l.dbuf, l.x0, l.Ad, l.Bd, l.Kd, l.lo, l.hi, l.z, l.y, l.v, l.w, l.part, l.alpha, l.N, l.pitch, nullptr,
+                           nullptr, nullptr, nullptr);
+      else if (seg)
         hipLaunchKernelGGL((pxfz_kernel<NX, NU, false, false, false, false, false, true, true>), sgrid, block, 0, l.stream, l.dbuf,
                            l.x0, l.Ad, l.Bd, l.Kd, l.lo, l.hi, l.z, l.y, l.v, l.w, l.part, l.alpha, l.N, l.pitch, l.Psd,
                            l.seg_start, l.tin, l.xin);
@@ -65,7 +81,15 @@ void launch_dim(const PLaunch& l, PKernel k) {
     case PKernel::XFZ: {
 #define XFZ(RS, RX, VI, PB_)                                                                                                       \
   do {                                                                                                                             \
-    if (seg)                                                                                                                       \
+    if (l.rows && seg)                                                                                                             \
+      hipLaunchKernelGGL((pxfz_rows_kernel<NX, NU, true, RS, RX, VI, PB_, false, true>), rgrid, block, 0, l.stream, l.dbuf, l.x0,  \
+                         l.Ad, l.Bd, l.Kd, l.lo, l.hi, l.z, l.y, l.v, l.w, l.part, l.alpha, l.N, l.pitch, l.Psd, l.seg_start,      \
+                         l.tin, l.xin);                                                                                            \
+    else if (l.rows)                                                                                                               \
+      hipLaunchKernelGGL((pxfz_rows_kernel<NX, NU, true, RS, RX, VI, PB_, false, false>), rgrid, block, 0, l.stream, l.dbuf, l.x0, \
+                         l.Ad, l.Bd, l.Kd, l.lo, l.hi, l.z, l.y, l.v, l.w, l.part, l.alpha, l.N, l.pitch, nullptr, nullptr,        \
+                         nullptr, nullptr);                                                                                        \
+    else if (seg)                                                                                                                  \
       hipLaunchKernelGGL((pxfz_kernel<NX, NU, true, RS, RX, VI, PB_, false, true>), sgrid, block, 0, l.stream, l.dbuf, l.x0, l.Ad, \
                          l.Bd, l.Kd, l.lo, l.hi, l.z, l.y, l.v, l.w, l.part, l.alpha, l.N, l.pitch, l.Psd, l.seg_start, l.tin,    \
                          l.xin);                                                                                                   \

@@ -27,12 +27,21 @@ def _close(got, ref):
     return all(np.abs(a - ref[k]).max() <= TOL * max(1.0, np.abs(ref[k]).max()) for a, k in zip(got, ("w", "z", "y")))
 
 
+@pytest.mark.parametrize("form", ["auto", "lane_per_qp", "rows_over_lanes"])
 @pytest.mark.parametrize("segments", [0, 1, 5], ids=["auto_segments", "one_segment", "five_segments"])
 @pytest.mark.parametrize("alpha", [1.0, 1.5])
 @pytest.mark.parametrize("idx", range(len(CASES)))
-def test_iterates_match_the_oracle(gpu, idx, alpha, segments):
+def test_iterates_match_the_oracle(gpu, idx, alpha, segments, form, monkeypatch):
     """segments: 0 = the library's choice (N / 8 at these sizes), 1 = one lane sweeps the whole horizon, 5 = segments in
-    time with per-QP transfer matrices computed on the device (pseg_kernel, pscan_kernel; capped at N)."""
+    time with per-QP transfer matrices computed on the device (pseg_kernel, pscan_kernel; capped at N).
+    form: the sweeps with one lane per QP (csrc/admm_pinst.hpp) or with a QP's rows spread over lanes
+    (csrc/admm_pinst_rows.hpp; the library's choice for batches of up to 64 QPs), forced either way."""
+    monkeypatch.delenv("ADMM_PI_LANE_PER_QP", raising=False)
+    monkeypatch.delenv("ADMM_PI_ROWS", raising=False)
+    if form == "lane_per_qp":
+        monkeypatch.setenv("ADMM_PI_LANE_PER_QP", "1")
+    elif form == "rows_over_lanes":
+        monkeypatch.setenv("ADMM_PI_ROWS", "1")
     p = pkg.random_instances(**CASES[idx])
     with pkg.Solver(p, pkg.Options(rho=0.3, alpha=alpha, segments=segments)) as s:
         want = {0: max(1, min(64, p.N // 8)), 1: 1, 5: min(5, p.N)}[segments]

@@ -22,7 +22,14 @@ for trial in range(trials):
     rho = float(rng.choice([0.05, 0.3, 1.0]))
     p = pkg.random_instances(N=N, n=n, m=m, batch=batch, seed=1000 + trial, with_q=bool(rng.integers(2)),
                              instance_bounds=bool(rng.integers(2)))
-    desc = dict(trial=trial, n=n, m=m, N=N, batch=batch, segs=segs, alpha=alpha, rho=rho)
+    form = str(rng.choice(["auto", "lane_per_qp", "rows"]))          # csrc/admm_pinst.hpp / admm_pinst_rows.hpp, forced either way
+    os.environ.pop("ADMM_PI_LANE_PER_QP", None)
+    os.environ.pop("ADMM_PI_ROWS", None)
+    if form == "lane_per_qp":
+        os.environ["ADMM_PI_LANE_PER_QP"] = "1"
+    elif form == "rows":
+        os.environ["ADMM_PI_ROWS"] = "1"
+    desc = dict(trial=trial, n=n, m=m, N=N, batch=batch, segs=segs, alpha=alpha, rho=rho, form=form)
     try:
         if rng.integers(3) == 0:                      # a solve with the per-QP adaptive rule
             ci = int(rng.choice([1, 5, 10]))
