@@ -1,126 +1,24 @@
-// Per-instance dynamics (admm_pinst.hpp): instantiations and launcher.  Adding a shape = adding X(n, m) below.
-#include "admm_dispatch.hpp"
-#include "admm_pinst.hpp"
-#include "admm_pinst_rows.hpp"
+// Per-instance dynamics (admm_pinst.hpp): instantiations and launcher.  Adding a shape = adding X(n, m) to one of the two
+// groups (this file, admm_pinst_g1.hip); both are compiled in parallel by build().
+#include <string>
 
-#define ADMM_PINST_DIMS(X) X(6, 3) X(2, 1) X(4, 2) X(3, 2)
+#include "admm_pinst_launch.hpp"
+
+#define ADMM_PINST_DIMS_G0(X) X(6, 3) X(2, 1) X(4, 2) X(3, 2)
+ADMM_PINST_GROUP(g0, ADMM_PINST_DIMS_G0)
 
 namespace admm {
 
-const char* dims_pinst() {
-#define ADMM_STR2(x) #x
-#define ADMM_STR(x) ADMM_STR2(x)
-#define X(NX, NU) "(" ADMM_STR(NX) "," ADMM_STR(NU) ") "
-  return ADMM_PINST_DIMS(X);
-#undef X
-}
-
-namespace {
-
-template <int NX, int NU>
-void launch_dim(const PLaunch& l, PKernel k) {
-  const bool seg = l.S > 1;
-  const dim3 grid((l.pitch + PI_THREADS - 1) / PI_THREADS), block(PI_THREADS);
-  const dim3 sgrid((l.pitch + PI_THREADS - 1) / PI_THREADS, l.S > 0 ? l.S : 1);     // one wave per (64 QPs, segment)
-  const dim3 rgrid(l.pitch / PscanShape<NX>::QPW, l.S > 0 ? l.S : 1);               // rows over lanes: QPW QPs per wave
-  const bool relax = l.alpha != 1.0;
-  switch (k) {
-    case PKernel::SEGMENTS:
-      hipLaunchKernelGGL((pseg_kernel<NX, NU>), sgrid, block, 0, l.stream, l.Ad, l.Bd, l.Kd, l.Sd, l.seg_start, l.todo, l.Omd,
-                         l.Psd, l.Segd, l.grow, l.pitch, l.batch);
-      break;
-    case PKernel::SCAN:
-      hipLaunchKernelGGL((pscan_kernel<NX>), dim3(l.pitch / PscanShape<NX>::QPW), block, 0, l.stream, l.Segd, l.tseg, l.eseg, l.x0,
-                         l.tin, l.xin, l.S, l.pitch);
-      break;
-    case PKernel::FACTOR:
-      hipLaunchKernelGGL((pfactor_kernel<NX, NU>), grid, block, 0, l.stream, l.Ad, l.Bd, l.Q, l.R, l.QN, l.rhov, l.todo, l.Kd, l.Sd,
-                         l.fail, l.N, l.pitch, l.batch);
-      break;
-    case PKernel::XB: {
-#define XB(HQ, VF, PB_)                                                                                                          \
-  do {                                                                                                                           \
-    if (l.rows && seg)                                                                                                           \
-      hipLaunchKernelGGL((pxb_rows_kernel<NX, NU, HQ, VF, PB_, true>), rgrid, block, 0, l.stream, l.vform ? l.v : l.z, l.y, l.q,  \
-                         l.Ad, l.Bd, l.Kd, l.Sd, l.lo, l.hi, l.dbuf, l.rhov, l.N, l.pitch, l.Omd, l.seg_start, l.tseg, l.eseg);   \
-    else if (l.rows)                                                                                                             \
-      hipLaunchKernelGGL((pxb_rows_kernel<NX, NU, HQ, VF, PB_, false>), rgrid, block, 0, l.stream, l.vform ? l.v : l.z, l.y, l.q, \
-                         l.Ad, l.Bd, l.Kd, l.Sd, l.lo, l.hi, l.dbuf, l.rhov, l.N, l.pitch, nullptr, nullptr, nullptr, nullptr);   \
-    else if (seg)                                                                                                                \
-      hipLaunchKernelGGL((pxb_kernel<NX, NU, HQ, VF, PB_, true>), sgrid, block, 0, l.stream, l.vform ? l.v : l.z, l.y, l.q, l.Ad, \
-                         l.Bd, l.Kd, l.Sd, l.lo, l.hi, l.dbuf, l.rhov, l.N, l.pitch, l.Omd, l.seg_start, l.tseg, l.eseg);         \
-    else                                                                                                                         \
-      hipLaunchKernelGGL((pxb_kernel<NX, NU, HQ, VF, PB_, false>), grid, block, 0, l.stream, l.vform ? l.v : l.z, l.y, l.q, l.Ad, \
-                         l.Bd, l.Kd, l.Sd, l.lo, l.hi, l.dbuf, l.rhov, l.N, l.pitch, nullptr, nullptr, nullptr, nullptr);          \
-  } while (0)
-#define XB2(HQ, VF) do { if (l.pbounds) XB(HQ, VF, true); else XB(HQ, VF, false); } while (0)
-      if (l.has_q) { if (l.vform) XB2(true, true); else XB2(true, false); }
-      else         { if (l.vform) XB2(false, true); else XB2(false, false); }
-#undef XB2
-#undef XB
-      break;
-    }
-    case PKernel::XF:      // read-out: w of the last x-update
-      if (l.rows && seg)
-        hipLaunchKernelGGL((pxfz_rows_kernel<NX, NU, false, false, false, false, false, true, true>), rgrid, block, 0, l.stream,
-                           l.dbuf, l.x0, l.Ad, l.Bd, l.Kd, l.lo, l.hi, l.z, l.y, l.v, l.w, l.part, l.alpha, l.N, l.pitch, l.Psd,
-                           l.seg_start, l.tin, l.xin);
-      else if (l.rows)
-        hipLaunchKernelGGL((pxfz_rows_kernel<NX, NU, false, false, false, false, false, true, false>), rgrid, block, 0, l.stream,
-                           l.dbuf, l.x0, l.Ad, l.Bd, l.Kd, l.lo, l.hi, l.z, l.y, l.v, l.w, l.part, l.alpha, l.N, l.pitch, nullptr,
-                           nullptr, nullptr, nullptr);
-      else if (seg)
-        hipLaunchKernelGGL((pxfz_kernel<NX, NU, false, false, false, false, false, true, true>), sgrid, block, 0, l.stream, l.dbuf,
-                           l.x0, l.Ad, l.Bd, l.Kd, l.lo, l.hi, l.z, l.y, l.v, l.w, l.part, l.alpha, l.N, l.pitch, l.Psd,
-                           l.seg_start, l.tin, l.xin);
-      else
-        hipLaunchKernelGGL((pxfz_kernel<NX, NU, false, false, false, false, false, true>), grid, block, 0, l.stream, l.dbuf,
-                           l.x0, l.Ad, l.Bd, l.Kd, l.lo, l.hi, l.z, l.y, l.v, l.w, l.part, l.alpha, l.N, l.pitch, nullptr,
-                           nullptr, nullptr, nullptr);
-      break;
-    case PKernel::XFZ: {
-#define XFZ(RS, RX, VI, PB_)                                                                                                       \
-  do {                                                                                                                             \
-    if (l.rows && seg)                                                                                                             \
-      hipLaunchKernelGGL((pxfz_rows_kernel<NX, NU, true, RS, RX, VI, PB_, false, true>), rgrid, block, 0, l.stream, l.dbuf, l.x0,  \
-                         l.Ad, l.Bd, l.Kd, l.lo, l.hi, l.z, l.y, l.v, l.w, l.part, l.alpha, l.N, l.pitch, l.Psd, l.seg_start,      \
-                         l.tin, l.xin);                                                                                            \
-    else if (l.rows)                                                                                                               \
-      hipLaunchKernelGGL((pxfz_rows_kernel<NX, NU, true, RS, RX, VI, PB_, false, false>), rgrid, block, 0, l.stream, l.dbuf, l.x0, \
-                         l.Ad, l.Bd, l.Kd, l.lo, l.hi, l.z, l.y, l.v, l.w, l.part, l.alpha, l.N, l.pitch, nullptr, nullptr,        \
-                         nullptr, nullptr);                                                                                        \
-    else if (seg)                                                                                                                  \
-      hipLaunchKernelGGL((pxfz_kernel<NX, NU, true, RS, RX, VI, PB_, false, true>), sgrid, block, 0, l.stream, l.dbuf, l.x0, l.Ad, \
-                         l.Bd, l.Kd, l.lo, l.hi, l.z, l.y, l.v, l.w, l.part, l.alpha, l.N, l.pitch, l.Psd, l.seg_start, l.tin,    \
-                         l.xin);                                                                                                   \
-    else                                                                                                                           \
-      hipLaunchKernelGGL((pxfz_kernel<NX, NU, true, RS, RX, VI, PB_, false>), grid, block, 0, l.stream, l.dbuf, l.x0, l.Ad,        \
-                         l.Bd, l.Kd, l.lo, l.hi, l.z, l.y, l.v, l.w, l.part, l.alpha, l.N, l.pitch, nullptr, nullptr, nullptr,     \
-                         nullptr);                                                                                                 \
-  } while (0)
-#define XFZ3(RS, RX, VI) do { if (l.pbounds) XFZ(RS, RX, VI, true); else XFZ(RS, RX, VI, false); } while (0)
-#define XFZ2(RS, RX) do { if (l.vform) XFZ3(RS, RX, true); else XFZ3(RS, RX, false); } while (0)
-      if (l.resid) { if (relax) XFZ2(true, true); else XFZ2(true, false); }
-      else         { if (relax) XFZ2(false, true); else XFZ2(false, false); }
-#undef XFZ2
-#undef XFZ3
-#undef XFZ
-      break;
-    }
-  }
-}
-
-}  // namespace
+bool launch_pinst_g1(const PLaunch& l, PKernel k, bool query_only);
+const char* dims_pinst_g1();
 
 bool launch_pinst(const PLaunch& l, PKernel k, bool query_only) {
-#define X(NX, NU)                              \
-  if (l.n == NX && l.m == NU) {                \
-    if (!query_only) launch_dim<NX, NU>(l, k); \
-    return true;                               \
-  }
-  ADMM_PINST_DIMS(X)
-#undef X
-  return false;
+  return launch_pinst_g0(l, k, query_only) || launch_pinst_g1(l, k, query_only);
+}
+
+const char* dims_pinst() {
+  static const std::string all = std::string(dims_pinst_g0()) + dims_pinst_g1();
+  return all.c_str();
 }
 
 void launch_padapt(hipStream_t stream, const double* resid, const int* status, double* rhov, int* nupd, int* todo,

@@ -20,6 +20,12 @@ CASES = [
     dict(N=12, n=4, m=2, batch=130, seed=6),
     dict(N=7, n=3, m=2, batch=3, seed=7),
     dict(N=1, n=6, m=3, batch=2, seed=8),
+    dict(N=30, n=6, m=4, batch=67, seed=9),                                   # the shapes of csrc/admm_pinst_g1.hip
+    dict(N=33, n=6, m=2, batch=5, seed=10),
+    dict(N=20, n=6, m=1, batch=65, seed=11, with_q=False),
+    dict(N=50, n=4, m=1, batch=3, seed=12),
+    dict(N=17, n=2, m=2, batch=130, seed=13, instance_bounds=False),
+    dict(N=60, n=1, m=1, batch=64, seed=14),
 ]
 
 

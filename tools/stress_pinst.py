@@ -11,7 +11,7 @@ import oracle_c as oc
 
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 3)
 trials = int(sys.argv[2]) if len(sys.argv) > 2 else 120
-dims = [(6, 3), (2, 1), (4, 2), (3, 2)]
+dims = [(6, 3), (2, 1), (4, 2), (3, 2), (1, 1), (2, 2), (4, 1), (6, 1), (6, 2), (6, 4)]
 worst, bad = 0.0, 0
 for trial in range(trials):
     n, m = dims[rng.integers(len(dims))]
