@@ -57,6 +57,7 @@ struct admm_handle {
   int device = 0;
   int num_cus = 256;             // hipDeviceProp_t::multiProcessorCount of the handle's device
   bool xfree = false;            // every state row is unbounded at every stage (XFREE kernel forms, see xfze_kernel)
+  int xfree_mode = 1;            // 2 while enqueue_one launches an iteration whose successor will not read those rows' v
   bool auto_segments = false;    // the segment count was chosen by admm_setup (and is guarded by scan_growth)
   bool has_q = false;
   bool has_soc = false;          // some stage has a finite thrust-magnitude bound
@@ -149,7 +150,7 @@ using admm::Z_THREADS;
 admm::XLaunch xlaunch_of(const admm_handle* h) {
   admm::XLaunch l{};
   l.stream = h->stream;
-  l.n = h->n; l.m = h->m; l.S = h->S; l.pitch = h->pitch; l.batch = h->batch; l.xfree = h->xfree;
+  l.n = h->n; l.m = h->m; l.S = h->S; l.pitch = h->pitch; l.batch = h->batch; l.xfree = h->xfree ? h->xfree_mode : 0;
   l.has_q = h->has_q;
   l.has_soc = h->has_soc;
   l.rho = h->opt.rho; l.alpha = h->opt.alpha;
@@ -1557,7 +1558,8 @@ int admm_step_z(admm_handle* h, int32_t residuals) {
 // `remaining` = iterations (this one included) the caller still enqueues before it returns:
 // it selects the iteration form (next_form).  it_number > 0: a checked iteration of admm_solve
 // (residuals + finalise with that iteration number, launched directly).
-static int enqueue_one(admm_handle* h, bool resid, bool use_graph, int remaining, int it_number = 0) {
+// next_plain: another iteration follows in this call and evaluates no residuals (admm_run / admm_solve_step know).
+static int enqueue_one(admm_handle* h, bool resid, bool use_graph, int remaining, int it_number = 0, bool next_plain = false) {
   int rc;
   const bool steady = fused(h) ? h->v_valid : h->zy_valid;
   if (!fused(h) && !h->zy_valid && (rc = ensure_zy(h))) return rc;
@@ -1566,8 +1568,16 @@ static int enqueue_one(admm_handle* h, bool resid, bool use_graph, int remaining
     const bool fin_prev = h->fin_pending;
     if (use_graph) {
       HIP_TRY(hipGraphLaunch(h->graph_exec[4 * (int)form + (resid ? 2 : 0) + (fin_prev ? 1 : 0)], h->stream));
-    } else if ((rc = enqueue_form(h, form, resid, fin_prev))) {
-      return rc;
+    } else {
+      // XFREE = 2: where the state rows are unbounded everywhere, an iteration without residuals or
+      // relaxation neither reads their v nor -- if its successor in this call is of the same kind AND a fused alternating
+      // kernel (not a start form: xb_kernel reads all of v) -- writes it.  The last iteration of a call always writes.
+      const bool next_alternates = form == IT_BWD || (remaining - 1 >= 1 && (remaining - 1) % 2 == 0);
+      static const bool no_skip_store = std::getenv("ADMM_NO_SKIPV_STORE") != nullptr;
+      h->xfree_mode = (next_plain && !resid && next_alternates && h->opt.alpha == 1.0 && !no_skip_store) ? 2 : 1;
+      rc = enqueue_form(h, form, resid, fin_prev);
+      h->xfree_mode = 1;
+      if (rc) return rc;
     }
     after_form(h, form);
     h->fin_pending = resid;                 // carried by the next scan launch, or flushed by the caller
@@ -1602,7 +1612,8 @@ int admm_run(admm_handle* h, int32_t iters, int32_t residual_every) {
   }
   for (int it = 1; it <= iters; ++it) {
     const bool resid = residual_every > 0 && (it % residual_every == 0);
-    int rc = enqueue_one(h, resid, use_graph, iters - it + 1);
+    const bool next_plain = it < iters && !(residual_every > 0 && ((it + 1) % residual_every == 0));
+    int rc = enqueue_one(h, resid, use_graph, iters - it + 1, 0, next_plain);
     if (rc) return rc;
   }
   int rcf = flush_finalize(h);
@@ -1665,7 +1676,7 @@ int admm_solve_step(admm_handle* h, int32_t* iters_done, int32_t* n_converged, d
     const bool check = (it % ci == 0) || it == h->opt.max_iter;
     if (!check) {
       const int next_check = std::min(((it / ci) + 1) * ci, h->opt.max_iter);
-      if ((rc = enqueue_one(h, false, use_graph, next_check - it + 1))) return rc;
+      if ((rc = enqueue_one(h, false, use_graph, next_check - it + 1, 0, /*next_plain=*/it + 1 < next_check))) return rc;
       continue;
     }
     // checked iteration: launched directly so that the finalise kernel gets the iteration number

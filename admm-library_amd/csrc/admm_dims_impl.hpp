@@ -76,11 +76,13 @@ void launch_dim(const XLaunch& l, XKernel k, bool a, bool b) {
                          l.recBE, l.seg_start, l.q, l.v, l.dbuf, l.tseg, l.eseg, l.part, l.alpha, l.rho,     \
                          l.pitch, l.nsplit, l.split_stride);                                                 \
   } while (0)
-// XFREE forms (state rows unbounded everywhere: their v is not read) exist for the non-residual, non-relaxed kernels only
+// XFREE forms (state rows unbounded everywhere: their v is not read -- 1 -- and, when the next iteration is of the same kind,
+// not written either -- 2) exist for the non-residual, non-relaxed kernels only
 #define ALT3(RS, RX, HQ, SC)                                                                                  \
   do {                                                                                                       \
-    if constexpr (!(RS) && !(RX)) { if (l.xfree) ALT4(RS, RX, HQ, SC, true); else ALT4(RS, RX, HQ, SC, false); } \
-    else ALT4(RS, RX, HQ, SC, false);                                                                        \
+    if constexpr (!(RS) && !(RX)) {                                                                          \
+      if (l.xfree == 2) ALT4(RS, RX, HQ, SC, 2); else if (l.xfree == 1) ALT4(RS, RX, HQ, SC, 1); else ALT4(RS, RX, HQ, SC, 0); \
+    } else ALT4(RS, RX, HQ, SC, 0);                                                                          \
   } while (0)
 #define ALT2(RS, RX, HQ) do { if (l.has_soc) ALT3(RS, RX, HQ, true); else ALT3(RS, RX, HQ, false); } while (0)
 #define ALT1(RS, RX) do { if (l.has_q) ALT2(RS, RX, true); else ALT2(RS, RX, false); } while (0)

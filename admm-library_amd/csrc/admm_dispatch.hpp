@@ -11,7 +11,8 @@ struct XLaunch {
   hipStream_t stream;
   int n, m, S, pitch;
   int batch;                    // QPs really present (columns batch .. pitch-1 are padding)
-  bool xfree;                   // every state row is unbounded at every stage: z = v, y = 0 there (XFREE kernel forms)
+  int xfree;                    // every state row is unbounded at every stage: z = v, y = 0 there (XFREE kernel forms):
+                                // 1 = their v is not read, 2 = nor written (the next iteration does not read it either)
   bool has_q;
   bool has_soc;                 // thrust-magnitude bound on some stage: SOC kernel forms
   double rho, alpha;

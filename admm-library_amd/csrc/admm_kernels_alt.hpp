@@ -105,7 +105,7 @@ __device__ __forceinline__ double scan_row(const double* base, size_t o, int nsp
 //     mu  = FM_k mu + GA_k g^u + PI_k g^x
 // and on exit mu -> mseg[s], eb -> ebseg[s].
 // ---------------------------------------------------------------------------
-template <int NX, int NU, bool RESID, bool RELAX, bool HASQ, bool SOC, bool XFREE = false>
+template <int NX, int NU, bool RESID, bool RELAX, bool HASQ, bool SOC, int XFREE = 0>
 __global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY(NX + NU, HASQ, SOC) void xfze_kernel(
     const double* __restrict__ dbuf, const double* __restrict__ tin, const double* __restrict__ xin,
     const double* __restrict__ recFE, const int* __restrict__ seg_start_, const double* __restrict__ q,
@@ -260,10 +260,8 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY(NX + NU, HASQ, SOC) 
           double wh = wv[r];
           if (RELAX) wh = fma(alpha, wv[r], (1.0 - alpha) * zo);
           const double vn = wh + yo;
-#ifdef ADMM_ABLATE_NOSTORE          // timing only: a form that also skipped WRITING v+ of the unbounded state rows
-          if (!(XFREE && r >= NU))
-#endif
-          vv.store<ADMM_ALT_STORE_AUX>(vn, lb_st, r0 + r * PB);
+          if (!(XFREE == 2 && r >= NU))      // XFREE = 2: the next iteration does not read these rows either
+            vv.store<ADMM_ALT_STORE_AUX>(vn, lb_st, r0 + r * PB);
           const double zn = fmin(fmax(ball ? vn * cs_new : vn, lo_r), hi_r);
           const double yn = vn - zn;
           g[r] = -rho * (zn - yn);
@@ -332,7 +330,7 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY(NX + NU, HASQ, SOC) 
 //     p = g^x + t;  h = BT_k p + g^u;  d0_k = SI_k h -> dbuf;  t = AT_k p - KT_k h;  e += OM_k d0_k
 // and on exit t -> tseg[s], e -> eseg[s]: exactly what xb_kernel leaves for the plain scan.
 // ---------------------------------------------------------------------------
-template <int NX, int NU, bool RESID, bool RELAX, bool HASQ, bool SOC, bool XFREE = false>
+template <int NX, int NU, bool RESID, bool RELAX, bool HASQ, bool SOC, int XFREE = 0>
 __global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY(NX + NU, HASQ, SOC) void xbze_kernel(
     const double* __restrict__ dbb, const double* __restrict__ min_, const double* __restrict__ xend,
     const double* __restrict__ recBE, const int* __restrict__ seg_start_, const double* __restrict__ q,
@@ -481,10 +479,8 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY(NX + NU, HASQ, SOC) 
             double wh = wv[r];
             if (RELAX) wh = fma(alpha, wv[r], (1.0 - alpha) * zo);
             const double vn = wh + yo;
-#ifdef ADMM_ABLATE_NOSTORE          // timing only: a form that also skipped WRITING v+ of the unbounded state rows
-            if (!(XFREE && r >= NU))
-#endif
-            vv.store<ADMM_ALT_STORE_AUX>(vn, lb_st, r0 + r * PB);
+            if (!(XFREE == 2 && r >= NU))
+              vv.store<ADMM_ALT_STORE_AUX>(vn, lb_st, r0 + r * PB);
             const double zn = fmin(fmax(ball ? vn * cs_new : vn, lo), hi);
             const double yn = vn - zn;
             g[r] = -rho * (zn - yn);

@@ -35,8 +35,8 @@ bool launch_dim(const XLaunch& l, XKernel k, bool resid, bool query_only) {
   hipLaunchKernelGGL((xbzem_kernel<NX, NU, NT_, TS, TE, RS, RX, SB, XF>), grid, block, 0, l.stream, l.mvec, l.tin, l.xin, l.recMB, \
                      l.seg_start, l.v, l.dbuf, l.tseg, l.eseg, l.part, l.alpha, l.rho, l.pitch, l.nsplit, l.split_stride, l.batch)
 // XFREE forms for the non-residual, non-relaxed kernels that update v (not the plain path's backward sweep)
-#define FWD1(NT_, TS, TE, RS, RX, EL) do { if constexpr (!(RS) && !(RX)) { if (l.xfree) FWD0(NT_, TS, TE, RS, RX, EL, true); else FWD0(NT_, TS, TE, RS, RX, EL, false); } else FWD0(NT_, TS, TE, RS, RX, EL, false); } while (0)
-#define BWD1(NT_, TS, TE, RS, RX, SB) do { if constexpr (!(RS) && !(RX) && (SB)) { if (l.xfree) BWD0(NT_, TS, TE, RS, RX, SB, true); else BWD0(NT_, TS, TE, RS, RX, SB, false); } else BWD0(NT_, TS, TE, RS, RX, SB, false); } while (0)
+#define FWD1(NT_, TS, TE, RS, RX, EL) do { if constexpr (!(RS) && !(RX)) { if (l.xfree == 2) FWD0(NT_, TS, TE, RS, RX, EL, 2); else if (l.xfree == 1) FWD0(NT_, TS, TE, RS, RX, EL, 1); else FWD0(NT_, TS, TE, RS, RX, EL, 0); } else FWD0(NT_, TS, TE, RS, RX, EL, 0); } while (0)
+#define BWD1(NT_, TS, TE, RS, RX, SB) do { if constexpr (!(RS) && !(RX) && (SB)) { if (l.xfree == 2) BWD0(NT_, TS, TE, RS, RX, SB, 2); else if (l.xfree == 1) BWD0(NT_, TS, TE, RS, RX, SB, 1); else BWD0(NT_, TS, TE, RS, RX, SB, 0); } else BWD0(NT_, TS, TE, RS, RX, SB, 0); } while (0)
 #define FWD(TS, TE, RS, RX, EL) do { if (nt1) FWD1(1, TS, TE, RS, RX, EL); else FWD1(2, TS, TE, RS, RX, EL); } while (0)
 #define BWD(TS, TE, RS, RX, SB) do { if (nt1) BWD1(1, TS, TE, RS, RX, SB); else BWD1(2, TS, TE, RS, RX, SB); } while (0)
 #define BY_FLAGS(CALL, TS, TE, LAST)                                                      \

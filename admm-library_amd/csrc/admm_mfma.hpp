@@ -157,7 +157,7 @@ __device__ __forceinline__ double mf_colsum(double x) {
 //     ELIM_F:  [mu+ ; deps ; db_k] = M [mu ; g^x ; g^u],  eps += deps,  db_k -> dbb          (ELIM only)
 // and on exit mu -> mseg[s], eps -> epsseg[s] (ELIM), residual partials -> part (RESID).
 // ---------------------------------------------------------------------------
-template <int NX, int NU, int NT, class TS, class TE, bool RESID, bool RELAX, bool ELIM, bool XFREE = false>
+template <int NX, int NU, int NT, class TS, class TE, bool RESID, bool RELAX, bool ELIM, int XFREE = 0>
 __global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void xfzem_kernel(
     const double* __restrict__ dbuf, const double* __restrict__ tin, const double* __restrict__ xin,
     const unsigned char* __restrict__ recMF, const int* __restrict__ seg_start_, double* __restrict__ v,
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
           mf_zupdate<RESID, RELAX>(c0[nt][r], (double)a0[nt][r], lohi[r * 4 + g], lohi[20 + r * 4 + g], alpha, rho, vn, gg[nt][r], racc[nt]);
-          vv.store(vn, okx[r] ? lbs[nt] : ROWVIEW_OOB, r0 + (unsigned)(NU + 4 * r) * PB);
+          if (XFREE != 2) vv.store(vn, okx[r] ? lbs[nt] : ROWVIEW_OOB, r0 + (unsigned)(NU + 4 * r) * PB);
           X[nt][r] = a0[nt][r];
         }
         mf_zupdate<RESID, RELAX>(c0[nt][3], (double)a0[nt][3], lohi[12 + g], lohi[32 + g], alpha, rho, vn, gg[nt][3], racc[nt]);
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 //     ELIM_B:  [t+ ; de ; d0_k] = M [g^x + t ; g^u],  e += de,  d0_k -> dbuf
 // and on exit t -> tseg[s], e -> eseg[s]: what xb_kernel / xbze_kernel leave for the plain scan.
 // ---------------------------------------------------------------------------
-template <int NX, int NU, int NT, class TS, class TE, bool RESID, bool RELAX, bool SUBST, bool XFREE = false>
+template <int NX, int NU, int NT, class TS, class TE, bool RESID, bool RELAX, bool SUBST, int XFREE = 0>
 __global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void xbzem_kernel(
     const double* __restrict__ dbb, const double* __restrict__ min_, const double* __restrict__ xend,
     const unsigned char* __restrict__ recMB, const int* __restrict__ seg_start_, double* __restrict__ v,
@@ -566,7 +566,7 @@ __global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
           for (int r = 0; r < NR; ++r) {
             mf_zupdate<RESID, RELAX>(c0[nt][r], (double)X[nt][r], lohi[r * 4 + g], lohi[20 + r * 4 + g], alpha, rho, vn, gg[nt][r], racc[nt]);
-            vv.store(vn, okx[r] ? lbs[nt] : ROWVIEW_OOB, r0 + (unsigned)(NU + 4 * r) * PB);
+            if (XFREE != 2) vv.store(vn, okx[r] ? lbs[nt] : ROWVIEW_OOB, r0 + (unsigned)(NU + 4 * r) * PB);
             X[nt][r] = a0[nt][r];                                 // x_k
           }
           mf_zupdate<RESID, RELAX>(c0[nt][3], (double)a0[nt][3], lohi[12 + g], lohi[32 + g], alpha, rho, vn, gg[nt][3], racc[nt]);

@@ -421,6 +421,8 @@ def main():
     xfree = (prof_alt is not None and not full.per_instance
              and bool(np.all(np.asarray(full.lo)[..., m_:] == -np.inf) and np.all(np.asarray(full.hi)[..., m_:] == np.inf)))
     b_iter_plain = (8.0 + 24.0 * m_ / (n_ + m_) + (8.0 if full.q is not None else 0.0)) if xfree else b_iter
+    # ... and do not write it either while the next iteration is of the same kind (XFREE = 2 forms: 8 of 10 at check_interval 10)
+    b_iter_nostore = (32.0 * m_ / (n_ + m_) + (8.0 if full.q is not None else 0.0)) if xfree else b_iter
     # mixed mode a solver would normally run: residuals every 10th iteration
     warm(solver, 0.25 * a.warm_seconds, every=10)
     dt10 = float(np.median(timed_blocks(solver, 10)))
@@ -541,7 +543,8 @@ def main():
                                   "QP_iterations_per_s": gbatch * a.steps / dt10,
                                   "state_rows_unbounded_v_not_read": xfree,
                                   "bytes_per_element_without_residuals": b_iter_plain,
-                                  "iteration_GBs": (0.9 * b_iter_plain + 0.1 * b_iter) * elems / (dt10 / a.steps) / 1e9},
+                                  "bytes_per_element_neither_read_nor_written": b_iter_nostore,
+                                  "iteration_GBs": (0.8 * b_iter_nostore + 0.1 * b_iter_plain + 0.1 * b_iter) * elems / (dt10 / a.steps) / 1e9},
         }
         if cpu_base is not None:
             out["cpu_baseline"] = cpu_base

@@ -233,7 +233,7 @@ def test_alternating_properties_at_full_size(gpu):
                          ids=["one_lane_6_3", "mfma_12_6", "thrust_magnitude", "ltv_q_stage_bounds", "ltv_q_stage_thrust_bounds", "ltv_8_4"])
 def test_skipping_v_of_unbounded_state_rows_is_exact(gpu, make, monkeypatch):
     """XFREE kernel forms: where every state row is unbounded at every stage, the iterations that evaluate
-    no residuals do not read v of those rows (y = 0 identically there).  Same iterates, BIT for bit, as with the skip
+    no residuals do not read v of those rows (y = 0 identically there) -- nor write it while the next iteration is of the same kind.  Same iterates, BIT for bit, as with the skip
     disabled (ADMM_NO_SKIPV), through a mix of residual and non-residual iterations and both kernel families."""
     p = make()
     out = []
@@ -245,8 +245,11 @@ def test_skipping_v_of_unbounded_state_rows_is_exact(gpu, make, monkeypatch):
         with pkg.Solver(p, pkg.Options(rho=0.05)) as s:
             s.run(23, residual_every=5)
             s.iterate(4)
+            for k in (1, 2, 3, 7, 10):          # call lengths of both parities: the no-store form (XFREE = 2) needs its successor
+                s.iterate(k)                    # to be a fused alternating kernel of the same call, else the rows are written
+            s.run(11, residual_every=4)
             out.append(s.get() + s.residuals())
     for a, b in zip(*out):
         np.testing.assert_array_equal(a, b)
-    ref = oc.solve(p, rho=0.05, max_iter=27, stop=False)
+    ref = oc.solve(p, rho=0.05, max_iter=27 + 23 + 11, stop=False)
     assert _close(out[0][0], ref["w"]) and _close(out[0][1], ref["z"]) and _close(out[0][2], ref["y"])
