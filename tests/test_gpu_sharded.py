@@ -61,6 +61,49 @@ def test_two_rank_sharded_solve_equals_unsharded(gpu, tmp_path, adapt):
     assert np.abs(got["z"] - ref["z"]).max() <= 1e-10
 
 
+def _pinst_worker(rank, world, port, batch, out_dir):
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    import admm_library_amd as pkg
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    full = pkg.random_instances(N=30, n=6, m=3, batch=batch, seed=51)
+    shard = pkg.shard_problem(full, world, rank)
+    assert shard.per_instance and shard.batch in (batch // 2, batch - batch // 2)
+    opt = pkg.Options(rho=0.3, eps_abs=1e-7, eps_rel=1e-7, max_iter=2000, check_interval=10, device=0, adapt_interval=20,
+                      adapt_mu=1.5, adapt_max=8)
+    with pkg.Solver(shard, opt) as s:
+        info = pkg.solve_sharded(s, batch)
+        _, z, _ = s.get(False, True, False)
+        rho = s.rho_per_qp()
+    zf = pkg.gather_batch(torch.from_numpy(z), batch)
+    rf = pkg.gather_batch(torch.from_numpy(rho), batch)
+    itf = pkg.gather_batch(torch.from_numpy(info.iters), batch)
+    dist.barrier()
+    if rank == 0:
+        np.savez(os.path.join(out_dir, "pinst.npz"), z=zf.numpy(), rho=rf.numpy(), iters=itf.numpy(), iters_run=info.iters_run)
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_per_instance_solve(gpu, tmp_path):
+    """Per-instance dynamics sharded over two ranks: the shards keep their own dynamics / box (shard_problem slices them), the
+    stop decision is global, and the per-QP adaptive rule needs no exchange -- every QP's rho, first-converged iteration and
+    solution as in the unsharded oracle solve."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import admm_library_amd as pkg
+    import oracle_c as oc
+    batch = 21
+    mp.spawn(_pinst_worker, args=(2, _free_port(), batch, str(tmp_path)), nprocs=2, join=True)
+    got = np.load(tmp_path / "pinst.npz")
+    ref = oc.solve(pkg.random_instances(N=30, n=6, m=3, batch=batch, seed=51), rho=0.3, eps_abs=1e-7, eps_rel=1e-7, max_iter=2000,
+                   check_interval=10, adapt_interval=20, adapt_mu=1.5, adapt_max=8)
+    assert int(got["iters_run"]) == ref["iters_run"]
+    np.testing.assert_array_equal(got["rho"], ref["rho"])
+    np.testing.assert_array_equal(got["iters"], ref["iters"])
+    assert np.abs(got["z"] - ref["z"]).max() <= 1e-10 * max(1.0, np.abs(ref["z"]).max())
+
+
 def _nccl_worker(rank, world, port, out_dir):
     if ROOT not in sys.path:
         sys.path.insert(0, ROOT)
