@@ -1561,6 +1561,7 @@ int admm_step_z(admm_handle* h, int32_t residuals) {
 // next_plain: another iteration follows in this call and evaluates no residuals (admm_run / admm_solve_step know).
 static int enqueue_one(admm_handle* h, bool resid, bool use_graph, int remaining, int it_number = 0, bool next_plain = false) {
   int rc;
+  h->xfree_mode = 1;                       // (never inherited: an error path of admm_profile could have left it set)
   const bool steady = fused(h) ? h->v_valid : h->zy_valid;
   if (!fused(h) && !h->zy_valid && (rc = ensure_zy(h))) return rc;
   const IterForm form = next_form(h, remaining);
@@ -1856,6 +1857,7 @@ int admm_profile(admm_handle* h, int32_t iters, int32_t residuals, int32_t fused
   if (!h || !ms) return fail(ADMM_ERR_INVALID, "NULL argument");
   if (iters < 1 || iters > 4096) return fail(ADMM_ERR_INVALID, "iters must lie in [1, 4096]");
   if (h->pinst && fused_path != 1) return fail(ADMM_ERR_UNSUPPORTED, "admm_profile: per-instance dynamics run the plain fused path only (fused_path = 1)");
+  h->xfree_mode = 1;
   HIP_TRY(hipSetDevice(h->device));
   constexpr int NE = 6;     // events per iteration
   if ((fused_path == 2 || fused_path == 3) && !h->alt) return fail(ADMM_ERR_UNSUPPORTED, "the alternating-direction kernels are not enabled for this handle");
@@ -1934,6 +1936,9 @@ int admm_profile(admm_handle* h, int32_t iters, int32_t residuals, int32_t fused
       if (!rc) after_iterations(h, 1);
     }
     if (!rc) rc = launch_xb(h, true);
+    // without residuals these are the kernels a run spends its time in: each is followed by another fused alternating kernel
+    // of the same kind (the closing IT_FWD below writes everything), so the XFREE = 2 forms apply (enqueue_one)
+    if (!res && h->opt.alpha == 1.0 && std::getenv("ADMM_NO_SKIPV_STORE") == nullptr) h->xfree_mode = 2;
     for (int it = 0; it < iters && !rc; ++it) {
       hipEvent_t* e = &ev[(size_t)it * NE];
       HIP_TRY(hipEventRecord(e[0], h->stream));
@@ -1947,6 +1952,7 @@ int admm_profile(admm_handle* h, int32_t iters, int32_t residuals, int32_t fused
       HIP_TRY(hipEventRecord(e[4], h->stream));
       HIP_TRY(hipEventRecord(e[5], h->stream));
     }
+    h->xfree_mode = 1;
     if (!rc) rc = enqueue_form(h, IT_FWD, res, res);      // never stop after the backward form
     if (!rc && res) rc = launch_finalize(h, 0, h->S);
     if (!rc) after_form(h, IT_FWD);
