@@ -26,6 +26,7 @@ FLAG_SCAN_CHAIN = 4
 FLAG_NO_ALTERNATE = 8
 FLAG_GRAPH = 16
 FLAG_NO_MFMA = 32
+FLAG_HISTORY = 64
 
 PRECISION_FP64 = 0
 PRECISION_MIXED = 1

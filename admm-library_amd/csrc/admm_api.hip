@@ -70,6 +70,9 @@ struct admm_handle {
   std::vector<std::unique_ptr<SpecFactor>> spec;        // candidates of the adaptive rule (rho tau, rho / tau)
   std::vector<std::unique_ptr<SpecFactor>> spec_stale;  // no longer candidates; their threads are joined lazily
   int spec_hits = 0, spec_misses = 0;
+  // ADMM_FLAG_HISTORY: one record per stopping test of the last admm_solve
+  struct HistoryEntry { int32_t it, nconv; double max_r, max_s, rho; };
+  std::vector<HistoryEntry> history;
   int solve_it = 0, solve_nconv = 0;     // admm_solve_begin / _step / _end state
   std::chrono::steady_clock::time_point solve_t0;
   hipStream_t stream = nullptr;
@@ -1648,6 +1651,7 @@ int admm_solve_begin(admm_handle* h, const double* z0, const double* y0) {
   const bool use_graph = (h->opt.flags & ADMM_FLAG_GRAPH) != 0;
   if (use_graph && !h->graph_exec[0] && (rc = capture_iterations(h))) return rc;
   h->rho_updates = 0;
+  h->history.clear();
   if (h->pinst) HIP_TRY(hipMemsetAsync(h->nupd_d, 0, sizeof(int) * P, h->stream));
   h->spec_hits = h->spec_misses = 0;
   spec_start(h);                               // adaptive rule: factorise rho tau and rho / tau while the GPU iterates
@@ -1687,6 +1691,19 @@ int admm_solve_step(admm_handle* h, int32_t* iters_done, int32_t* n_converged, d
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->solve_nconv = *h->h_nconv;
     h->resid_valid = true;
+    if (h->opt.flags & ADMM_FLAG_HISTORY) {
+      std::vector<double> rs(2 * P);
+      HIP_TRY(hipMemcpy(rs.data(), h->resid, sizeof(double) * 2 * P, hipMemcpyDeviceToHost));
+      admm_handle::HistoryEntry e{it, h->solve_nconv, 0.0, 0.0, h->opt.rho};
+      for (int b = 0; b < h->batch; ++b) { e.max_r = std::max(e.max_r, rs[b]); e.max_s = std::max(e.max_s, rs[P + b]); }
+      if (h->pinst) {
+        std::vector<double> rq(P);
+        HIP_TRY(hipMemcpy(rq.data(), h->rho_d, sizeof(double) * P, hipMemcpyDeviceToHost));
+        e.rho = *std::max_element(rq.begin(), rq.begin() + h->batch);
+      }
+      if (h->mixed_phase1) e.nconv = 0;            // (the fp32 phase counts against raised tolerances: nothing has converged)
+      h->history.push_back(e);
+    }
     if (h->mixed_phase1) {
       // fp32 phase: the count is of the RAISED tolerances.  Once every QP meets them (or the budget is spent) the
       // solve continues with the fp64 kernels, which check the rule as given; nothing has converged so far.
@@ -1996,6 +2013,23 @@ int admm_profile(admm_handle* h, int32_t iters, int32_t residuals, int32_t fused
   }
   for (auto& e : ev) (void)hipEventDestroy(e);
   return rc;
+}
+
+int admm_get_history(admm_handle* h, int32_t capacity, int32_t* count, int32_t* iteration, int32_t* n_converged,
+                     double* max_r, double* max_s, double* rho) {
+  if (!h || !count) return fail(ADMM_ERR_INVALID, "NULL argument");
+  if (capacity < 0) return fail(ADMM_ERR_INVALID, "capacity must be >= 0");
+  *count = (int32_t)h->history.size();
+  const size_t n = std::min((size_t)capacity, h->history.size());
+  for (size_t i = 0; i < n; ++i) {
+    const admm_handle::HistoryEntry& e = h->history[i];
+    if (iteration) iteration[i] = e.it;
+    if (n_converged) n_converged[i] = e.nconv;
+    if (max_r) max_r[i] = e.max_r;
+    if (max_s) max_s[i] = e.max_s;
+    if (rho) rho[i] = e.rho;
+  }
+  return ADMM_OK;
 }
 
 int admm_get_rho(admm_handle* h, double* rho) {

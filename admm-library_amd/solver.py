@@ -61,6 +61,7 @@ _SIGNATURES = {
     "admm_profile": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, c_double_p]),
     "admm_get_geometry": (C.c_int, [C.c_void_p] + [c_int32_p] * 4),
     "admm_get_rho": (C.c_int, [C.c_void_p, c_double_p]),
+    "admm_get_history": (C.c_int, [C.c_void_p, C.c_int32, c_int32_p, c_int32_p, c_int32_p, c_double_p, c_double_p, c_double_p]),
     "admm_free": (None, [C.c_void_p]),
     "admm_last_error": (C.c_char_p, []),
     "admm_abi_version": (C.c_int, []),
@@ -295,6 +296,16 @@ class Solver:
             return {"xb_ms": ms[0], "xscan_ms": ms[1], "xfz_ms": ms[2], "finalize_ms": ms[4], "iter_ms": ms[5]}
         return {"xb_ms": ms[0], "xscan_ms": ms[1], "xf_ms": ms[2], "zdual_ms": ms[3], "finalize_ms": ms[4],
                 "iter_ms": ms[5]}
+
+    def history(self) -> dict:
+        """Residual history of the last solve (Options(flags=FLAG_HISTORY)): one entry per stopping test --
+        iteration, n_converged, max_r, max_s (maxima over the batch), rho."""
+        n = C.c_int32()
+        _check(self._lib, self._lib.admm_get_history(self._h, 0, C.byref(n), None, None, None, None, None))
+        it, nc = np.empty(n.value, np.int32), np.empty(n.value, np.int32)
+        r, s, rho = np.empty(n.value), np.empty(n.value), np.empty(n.value)
+        _check(self._lib, self._lib.admm_get_history(self._h, n.value, C.byref(n), iptr(it), iptr(nc), dptr(r), dptr(s), dptr(rho)))
+        return {"iteration": it, "n_converged": nc, "max_r": r, "max_s": s, "rho": rho}
 
     def rho_per_qp(self) -> np.ndarray:
         """rho of every QP: the handle's rho for batch-shared dynamics; with per-instance dynamics each QP's own

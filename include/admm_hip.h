@@ -142,6 +142,8 @@ typedef struct admm_options {
                                   the one-lane kernels there), or a batch of at most 128 QPs (one wave per segment runs a
                                   chain of ~15 MFMAs per stage instead of ~450 dependent vector instructions) */
 
+#define ADMM_FLAG_HISTORY 64     /* admm_solve records, at every stopping test, (iteration, converged QPs, max primal residual, max dual
+                                   residual, rho in force) for admm_get_history; costs one read-back of the per-QP residuals per test */
 #define ADMM_FLAG_NO_ALTERNATE 8 /* always eliminate backward / substitute forward (xb + xfz kernels); by
                                   default (unless the forward form fails its host check for the problem),
                                   consecutive iterations alternate the elimination direction so that each
@@ -259,6 +261,13 @@ int admm_get_info(admm_handle* h, int32_t* iters, int32_t* status, double* r, do
  * with z/dual/residual.  `residuals` selects the residual-evaluating kernel
  * forms (+ the finalise kernel). */
 int admm_profile(admm_handle* h, int32_t iters, int32_t residuals, int32_t fused_path, double ms[6]);
+
+/* Residual history of the last admm_solve (ADMM_FLAG_HISTORY; ABI v5): one entry per stopping test, oldest first.  *count =
+ * number of entries recorded; at most `capacity` of them are copied into each non-NULL array.  max_r / max_s are maxima over
+ * the real QPs of the batch (converged or not) of the residuals of that iteration; rho is the one in force during it (the
+ * largest one with per-instance dynamics). */
+int admm_get_history(admm_handle* h, int32_t capacity, int32_t* count, int32_t* iteration, int32_t* n_converged,
+                     double* max_r, double* max_s, double* rho);
 
 /* rho of every QP (batch entries): the handle's rho for batch-shared dynamics, each QP's own with per-instance
  * dynamics (where the adaptive rule moves them apart; admm_set_rho sets them all).  ABI v5. */

@@ -460,3 +460,30 @@ def test_background_refactor_survives_problem_updates_and_early_release(gpu):
     s = pkg.Solver(p1, pkg.Options(**kw))
     s.solve_begin()
     s.close()
+
+
+def test_residual_history(gpu):
+    """ADMM_FLAG_HISTORY (SURVEY.md §5 "optional residual history buffer"): one record per stopping test of admm_solve --
+    iteration, converged count, the batch maxima of r and s, rho in force -- checked against the oracle run to that iteration."""
+    p = pkg.cw_rendezvous(N=150, batch=9)
+    kw = dict(rho=0.05, eps_abs=1e-6, eps_rel=1e-6, max_iter=1200, check_interval=10, adapt_interval=50)
+    with pkg.Solver(p, pkg.Options(flags=64, **kw)) as s:           # ADMM_FLAG_HISTORY
+        info = s.solve()
+        h = s.history()
+        n = len(h["iteration"])
+        assert n == -(-int(info.iters_run) // 10) and n >= 5
+        np.testing.assert_array_equal(h["iteration"][:-1], 10 * np.arange(1, n))
+        assert int(h["iteration"][-1]) == int(info.iters_run) and int(h["n_converged"][-1]) == int(info.n_converged)
+        assert (np.diff(h["n_converged"]) >= 0).all()
+        assert abs(h["max_r"][-1] - info.max_r) <= 1e-15 and abs(h["max_s"][-1] - info.max_s) <= 1e-15
+        assert float(h["rho"][0]) == 0.05 and float(info.rho) in set(h["rho"].tolist()) | {float(info.rho)}
+        for k in (0, 3, n - 2):
+            it = int(h["iteration"][k])
+            ref = oc.solve(p, **{**kw, "max_iter": it}, stop=False)
+            assert abs(h["max_r"][k] - ref["r"].max()) <= 1e-10 and abs(h["max_s"][k] - ref["s"].max()) <= 1e-10
+            assert int(h["n_converged"][k]) == int(ref["status"].sum())
+        s.solve()                                   # a second solve starts its own history
+        assert int(s.history()["iteration"][0]) == 10
+    with pkg.Solver(p, pkg.Options(**kw)) as s:       # off by default: nothing recorded
+        s.solve()
+        assert len(s.history()["iteration"]) == 0
