@@ -207,6 +207,23 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
       out[i] = mxGetPr(plhs[i]);
     }
     check(admm_get(h, out[0], out[1], out[2]));
+  } else if (!std::strcmp(cmd, "history")) {      // admm_mex('history', h): the records of ADMM_FLAG_HISTORY (o.flags = 64)
+    int32_t n = 0;
+    check(admm_get_history(h, 0, &n, nullptr, nullptr, nullptr, nullptr, nullptr));
+    const char* names[] = {"iteration", "n_converged", "max_r", "max_s", "rho"};
+    plhs[0] = mxCreateStructMatrix(1, 1, 5, names);
+    mxArray* it = mxCreateNumericMatrix(n, 1, mxINT32_CLASS, mxREAL);
+    mxArray* nc = mxCreateNumericMatrix(n, 1, mxINT32_CLASS, mxREAL);
+    mxArray* r = mxCreateDoubleMatrix(n, 1, mxREAL);
+    mxArray* s = mxCreateDoubleMatrix(n, 1, mxREAL);
+    mxArray* rho = mxCreateDoubleMatrix(n, 1, mxREAL);
+    check(admm_get_history(h, n, &n, static_cast<int32_t*>(mxGetData(it)), static_cast<int32_t*>(mxGetData(nc)), mxGetPr(r),
+                           mxGetPr(s), mxGetPr(rho)));
+    mxSetField(plhs[0], 0, "iteration", it);
+    mxSetField(plhs[0], 0, "n_converged", nc);
+    mxSetField(plhs[0], 0, "max_r", r);
+    mxSetField(plhs[0], 0, "max_s", s);
+    mxSetField(plhs[0], 0, "rho", rho);
   } else if (!std::strcmp(cmd, "iterate")) {
     if (nrhs < 3) fail("admm:input", "iterate needs an iteration count");
     check(admm_iterate(h, static_cast<int32_t>(mxGetScalar(prhs[2]))));
