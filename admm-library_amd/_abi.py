@@ -90,7 +90,7 @@ def marshal_problem(p: Problem):
         "hi": np.ascontiguousarray(p.hi, np.float64),
         "q": None if p.q is None else np.ascontiguousarray(p.q, np.float64),
         "unorm": None if p.unorm is None else np.array(
-            np.broadcast_to(np.asarray(p.unorm, np.float64), (p.N,) if p.lo.ndim == 2 else (1,)), np.float64),
+            np.broadcast_to(np.asarray(p.unorm, np.float64), (p.N,) if p.lo.ndim >= 2 else (1,)), np.float64),
     }
     cp = CProblem(N=p.N, n=p.n, m=p.m, batch=p.batch,
                   time_varying=2 if p.per_instance else int(p.time_varying), stage_bounds=p.lo.ndim - 1,

@@ -181,6 +181,7 @@ admm::PLaunch plaunch_of(const admm_handle* h) {
   l.S = h->S; l.seg_start = h->seg_start; l.Omd = h->Omd; l.Psd = h->Psd; l.Segd = h->Segd;
   l.tseg = h->tseg; l.eseg = h->eseg; l.tin = h->tin; l.xin = h->xin; l.grow = h->pgrow;
   l.rows = h->pi_rows;
+  l.has_soc = h->has_soc; l.ub = h->ub;
   l.Ad = h->Ad; l.Bd = h->Bd; l.Q = h->Qd; l.R = h->Rd; l.QN = h->QNd; l.Kd = h->Kd; l.Sd = h->Sd; l.fail = h->pfail;
   l.lo = h->pbounds ? h->lod : h->lo; l.hi = h->pbounds ? h->hid : h->hi;
   l.z = h->z; l.y = h->y; l.q = h->q; l.x0 = h->x0; l.v = h->v; l.w = h->w; l.dbuf = h->dbuf; l.part = h->part;
@@ -296,7 +297,8 @@ int launch_xfz(admm_handle* h, bool resid, bool vin) { return launch_x(h, admm::
 int ensure_zy(admm_handle* h) {
   if (h->zy_valid) return ADMM_OK;
   if (h->pbounds) {
-    admm::launch_pv_to_zy(h->stream, h->v, h->z, h->y, h->lod, h->hid, (size_t)h->L * h->pitch);
+    if (h->has_soc) admm::launch_pv_to_zy_soc(h->stream, h->v, h->z, h->y, h->lod, h->hid, h->ub, h->N, h->nb, h->m, h->pitch);
+    else admm::launch_pv_to_zy(h->stream, h->v, h->z, h->y, h->lod, h->hid, (size_t)h->L * h->pitch);
     h->zy_valid = true;
     return ADMM_OK;
   }
@@ -483,7 +485,6 @@ int validate_problem(const admm_problem* p) {
   if (p->stage_bounds == 2 && p->time_varying != 2)
     return fail(ADMM_ERR_INVALID, "per-instance bounds (stage_bounds = 2) need per-instance dynamics (time_varying = 2)");
   if (p->time_varying == 2) {
-    if (p->unorm) return fail(ADMM_ERR_UNSUPPORTED, "the thrust-magnitude bound is not available with per-instance dynamics");
     if (!p->Q || !p->R || !p->QN) return fail(ADMM_ERR_INVALID, "Q, R, QN must be non-NULL");
     if (!finite_all(p->A, (size_t)p->n * p->n * p->N * p->batch) || !finite_all(p->B, (size_t)p->n * p->m * p->N * p->batch) ||
         !finite_all(p->Q, (size_t)p->n * p->n) || !finite_all(p->R, (size_t)p->m * p->m) || !finite_all(p->QN, (size_t)p->n * p->n))
@@ -501,9 +502,12 @@ int validate_problem(const admm_problem* p) {
       const double ub = p->unorm[k];
       if (std::isnan(ub) || !(ub > 0.0)) return fail(ADMM_ERR_INVALID, "unorm entries must be positive (inf = off)");
       if (std::isfinite(ub))
-        for (int j = 0; j < p->m; ++j)
-          if (std::isfinite(p->lo[(size_t)k * nb + j]) || std::isfinite(p->hi[(size_t)k * nb + j]))
-            return fail(ADMM_ERR_INVALID, "control rows must be unbounded (-inf, inf) where unorm is finite");
+        for (int b = 0; b < (p->stage_bounds == 2 ? p->batch : 1); ++b)       // (per-instance box: every QP's)
+          for (int j = 0; j < p->m; ++j) {
+            const size_t o = ((size_t)b * cnt + k) * nb + j;
+            if (std::isfinite(p->lo[o]) || std::isfinite(p->hi[o]))
+              return fail(ADMM_ERR_INVALID, "control rows must be unbounded (-inf, inf) where unorm is finite");
+          }
     }
   }
   if (!finite_all(p->x0, (size_t)p->n * p->batch)) return fail(ADMM_ERR_INVALID, "non-finite entry in x0");
@@ -751,6 +755,10 @@ int pinst_upload(admm_handle* h, const admm_problem* p) {
   if (h->pbounds) {
     if ((rc = upload_transposed(h, p->lo, h->lod, h->L))) return rc;
     if ((rc = upload_transposed(h, p->hi, h->hid, h->L))) return rc;
+    std::vector<double> ub(h->N, INFINITY);         // thrust-magnitude bound per stage (shared by the batch)
+    if (p->unorm)
+      for (int k = 0; k < h->N; ++k) ub[k] = p->unorm[k];
+    HIP_TRY(hipMemcpy(h->ub, ub.data(), sizeof(double) * h->N, hipMemcpyHostToDevice));
   } else if ((rc = upload_bounds(h, p))) {
     return rc;
   }
@@ -795,8 +803,9 @@ int setup_pinst(admm_handle* h, const admm_problem* p) {
     // (measured, N = 1000: 64 QPs 29 -> 23 us per sweep, N = 200: 15 -> 9 us; from 128 QPs the 8-QP waves' 64-byte accesses lose:
     //  256 QPs 44 -> 86 us)
     h->pi_rows = h->pitch <= 64;
+    if (h->has_soc) h->pi_rows = false;          // the thrust-magnitude forms exist for the one-lane kernels only
     if (std::getenv("ADMM_PI_LANE_PER_QP")) h->pi_rows = false;
-    if (std::getenv("ADMM_PI_ROWS")) h->pi_rows = true;
+    if (std::getenv("ADMM_PI_ROWS") && !h->has_soc) h->pi_rows = true;
   }
   h->alt = h->alt_allowed = false;
   h->time_varying = 2;
@@ -806,6 +815,7 @@ int setup_pinst(admm_handle* h, const admm_problem* p) {
     int chunks = std::max(1, (h->num_cus + col_groups - 1) / col_groups);
     int zr = ((h->L + chunks - 1) / chunks + 3) / 4 * 4;
     if (zr < 4) zr = 4;
+    if (h->has_soc) zr = ((zr + h->nb - 1) / h->nb) * h->nb;   // block-structured kernels: whole blocks per chunk
     h->zrows = zr;
     h->zchunks = (h->L + zr - 1) / zr;
   }

@@ -65,6 +65,8 @@ struct PLaunch {
   double *tseg, *eseg, *tin, *xin;     // [S][n][pitch]
   int* grow;                           // SEGMENTS: set if a transfer matrix exceeds the conditioning bound
   bool rows;                           // small batches: the sweeps with a QP's rows spread over lanes (admm_pinst_rows.hpp)
+  bool has_soc;                        // thrust-magnitude bound ub [N] on the control rows (one-lane kernels only)
+  const double* ub;
 };
 enum class PKernel { FACTOR, XB, XF, XFZ, SEGMENTS, SCAN };
 bool launch_pinst(const PLaunch& l, PKernel k, bool query_only);
@@ -72,6 +74,8 @@ void launch_padapt(hipStream_t stream, const double* resid, const int* status, d
                    double* cscale, int* nchanged, double mu2, double tau, int adapt_max, int pitch, int batch);
 void launch_padapt_scale(hipStream_t stream, double* y, const double* cscale, const int* todo, int rows, int pitch);
 void launch_pv_to_zy(hipStream_t stream, const double* v, double* z, double* y, const double* lo, const double* hi, size_t count);
+void launch_pv_to_zy_soc(hipStream_t stream, const double* v, double* z, double* y, const double* lo, const double* hi,
+                         const double* ub, int N, int nb, int m, int pitch);
 const char* dims_pinst();
 // " (n,m) (n,m) ..." of a group, for error messages
 const char* dims_group0();

@@ -31,6 +31,11 @@ void launch_padapt_scale(hipStream_t stream, double* y, const double* cscale, co
   hipLaunchKernelGGL(padapt_scale_kernel, dim3((pitch + 255) / 256, 64), dim3(256), 0, stream, y, cscale, todo, rows, pitch);
 }
 
+void launch_pv_to_zy_soc(hipStream_t stream, const double* v, double* z, double* y, const double* lo, const double* hi,
+                         const double* ub, int N, int nb, int m, int pitch) {
+  hipLaunchKernelGGL(pv_to_zy_soc_kernel, dim3((pitch + 255) / 256, 64), dim3(256), 0, stream, v, z, y, lo, hi, ub, N, nb, m, pitch);
+}
+
 void launch_pv_to_zy(hipStream_t stream, const double* v, double* z, double* y, const double* lo, const double* hi, size_t count) {
   hipLaunchKernelGGL(pv_to_zy_kernel, dim3(2048), dim3(256), 0, stream, v, z, y, lo, hi, count);
 }

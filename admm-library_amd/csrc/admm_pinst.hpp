@@ -191,6 +191,18 @@ __global__ __launch_bounds__(PI_THREADS) void pfactor_kernel(
   if (bad && real) atomicOr(fail, 1);
 }
 
+// Thrust-magnitude bound ||u_k||_2 <= ub_k on the control rows of a block: the factor c with z_u = c v_u.
+// sqrt and the division are the correctly rounded fp64 forms, accumulated in row order with fma -- the oracle's operations.
+// ub = +inf (no bound at this stage) gives exactly 1.
+template <int NU, int NB>
+__device__ __forceinline__ double pi_soc_scale(const double (&vblk)[NB], double ub) {
+  double ss = 0.0;
+#pragma unroll
+  for (int j = 0; j < NU; ++j) ss = fma(vblk[j], vblk[j], ss);
+  const double nrm = sqrt(ss);
+  return nrm > ub ? ub / nrm : 1.0;
+}
+
 // ---------------------------------------------------------------------------
 // Stage operands of one QP, fetched as ONE batch of independent loads (the first version read each operand where it
 // was used: ~100 dependent round trips per stage, 18-30 us per stage; batched: one round trip).  The sweeps keep TWO of
@@ -246,15 +258,16 @@ struct PiStage {
 // ---------------------------------------------------------------------------
 // SEG (segments in time, see pseg_kernel): blockIdx.y = segment s, stages seg_start[s] .. seg_start[s+1]-1, zero tail;
 // the segment also accumulates e = sum_k Omega_k d0_k and leaves (t, e) in tseg / eseg [s][n][pitch] for pscan_kernel.
-template <int NX, int NU, bool HASQ, bool VFORM, bool PB, bool SEG = false>
+template <int NX, int NU, bool HASQ, bool VFORM, bool PB, bool SEG = false, bool SOC = false>
 __global__ __launch_bounds__(PI_THREADS) void pxb_kernel(
     const double* __restrict__ z, const double* __restrict__ y, const double* __restrict__ q,
     const double* __restrict__ Ad, const double* __restrict__ Bd, const double* __restrict__ Kd,
     const double* __restrict__ Sd, const double* __restrict__ lo, const double* __restrict__ hi,
     double* __restrict__ dbuf, const double* __restrict__ rhov, int N, int pitch,
     const double* __restrict__ Omd = nullptr, const int* __restrict__ seg_start = nullptr, double* __restrict__ tseg = nullptr,
-    double* __restrict__ eseg = nullptr) {
+    double* __restrict__ eseg = nullptr, const double* __restrict__ ubd = nullptr) {
   constexpr int NB = NX + NU;
+  static_assert(!SOC || VFORM, "the (z, y) form carries the projected z: only the v-form projects");
   typedef PiStage<NX, NU, true, HASQ, !VFORM, PB, VFORM, false, SEG> Stage;
   const int col = blockIdx.x * PI_THREADS + threadIdx.x;
   if (col >= pitch) return;
@@ -269,11 +282,13 @@ __global__ __launch_bounds__(PI_THREADS) void pxb_kernel(
   for (int i = 0; i < (SEG ? NX : 1); ++i) es[i] = 0.0;
   auto body = [&](const Stage& s, int k) {
     double g[NB];
+    double cs = 1.0;                               // thrust-magnitude bound of this stage (branch-free: +inf -> 1)
+    if constexpr (SOC) cs = pi_soc_scale<NU, NB>(s.s0, ubd[k]);
 #pragma unroll
     for (int r = 0; r < NB; ++r) {
       double zz = s.s0[r], yy;
       if (VFORM) {
-        zz = fmin(fmax(s.s0[r], s.lo[r]), s.hi[r]);
+        zz = fmin(fmax((SOC && r < NU) ? s.s0[r] * cs : s.s0[r], s.lo[r]), s.hi[r]);
         yy = s.s0[r] - zz;
       } else {
         yy = s.s1[r];
@@ -345,16 +360,17 @@ __global__ __launch_bounds__(PI_THREADS) void pxb_kernel(
 // ---------------------------------------------------------------------------
 // SEG: blockIdx.y = segment s; the rollout starts from x_in(s) with d_k = d0_k + Psi_k t_in(s) (xin / tin [s][n][pitch] from
 // pscan_kernel); residual partials go to part[s][5][pitch] and are summed over the segments by the finalise kernel.
-template <int NX, int NU, bool ZUP, bool RESID, bool RELAX, bool VIN, bool PB, bool STOREW, bool SEG = false>
+template <int NX, int NU, bool ZUP, bool RESID, bool RELAX, bool VIN, bool PB, bool STOREW, bool SEG = false, bool SOC = false>
 __global__ __launch_bounds__(PI_THREADS) void pxfz_kernel(
     const double* __restrict__ dbuf, const double* __restrict__ x0, const double* __restrict__ Ad,
     const double* __restrict__ Bd, const double* __restrict__ Kd, const double* __restrict__ lo,
     const double* __restrict__ hi, const double* __restrict__ zin, const double* __restrict__ yin,
     double* __restrict__ v, double* __restrict__ w, double* __restrict__ part, double alpha, int N, int pitch,
     const double* __restrict__ Psd = nullptr, const int* __restrict__ seg_start = nullptr, const double* __restrict__ tin = nullptr,
-    const double* __restrict__ xin = nullptr) {
+    const double* __restrict__ xin = nullptr, const double* __restrict__ ubd = nullptr) {
   constexpr int NB = NX + NU;
   constexpr bool NEEDZ = RESID || RELAX;
+  static_assert(!SOC || ZUP, "the read-out form projects nothing");
   // state operands: VIN: s0 = v;  else s0 = y and (NEEDZ) s1 = z
   typedef PiStage<NX, NU, false, false, ZUP && !VIN && NEEDZ, PB, ZUP, true, SEG> Stage;
   const int col = blockIdx.x * PI_THREADS + threadIdx.x;
@@ -392,14 +408,38 @@ __global__ __launch_bounds__(PI_THREADS) void pxfz_kernel(
     }
 #pragma unroll
     for (int i = 0; i < NX; ++i) x[i] = wv[NU + i];
+    // thrust-magnitude bound (as in xfz_kernel): the factors of the state before and after this z-update, branch-free
+    double cs_old = 1.0, cs_new = 1.0;
+    if constexpr (SOC) {
+      const double ub = ubd[k];
+      if (VIN) cs_old = pi_soc_scale<NU, NB>(s.s0, ub);
+      if (RESID) {                                  // z+ needs ||v+_u||: the control rows of v+ first
+        double vnew[NB];
+#pragma unroll
+        for (int r = 0; r < NB; ++r) {
+          if (r < NU) {
+            double zo, yo;
+            if (VIN) { zo = fmin(fmax(s.s0[r] * cs_old, s.lo[r]), s.hi[r]); yo = s.s0[r] - zo; }
+            else { yo = s.s0[r]; zo = NEEDZ ? s.s1[NEEDZ ? r : 0] : 0.0; }
+            double wh = wv[r];
+            if (RELAX) wh = fma(alpha, wv[r], (1.0 - alpha) * zo);
+            vnew[r] = wh + yo;
+          } else {
+            vnew[r] = 0.0;
+          }
+        }
+        cs_new = pi_soc_scale<NU, NB>(vnew, ub);
+      }
+    }
 #pragma unroll
     for (int r = 0; r < NB; ++r) {
       const size_t o = ((size_t)k * NB + r) * P_ + col;
+      const bool ball = SOC && r < NU;
       if (STOREW) w[o] = wv[r];
       if (ZUP) {
         double zo, yo;
         if (VIN) {
-          zo = fmin(fmax(s.s0[r], s.lo[r]), s.hi[r]);
+          zo = fmin(fmax(ball ? s.s0[r] * cs_old : s.s0[r], s.lo[r]), s.hi[r]);
           yo = s.s0[r] - zo;
         } else {
           yo = s.s0[r];
@@ -410,7 +450,7 @@ __global__ __launch_bounds__(PI_THREADS) void pxfz_kernel(
         const double vn = wh + yo;
         v[o] = vn;
         if (RESID) {
-          const double zn = fmin(fmax(vn, s.lo[r]), s.hi[r]);
+          const double zn = fmin(fmax(ball ? vn * cs_new : vn, s.lo[r]), s.hi[r]);
           const double yn = vn - zn;
           const double dr = wv[r] - zn, ds = zn - zo;
           a_r = fma(dr, dr, a_r);
@@ -714,6 +754,29 @@ static __global__ __launch_bounds__(256) void padapt_scale_kernel(double* __rest
   if (col >= pitch || !todo[col]) return;
   const double c = cscale[col];
   for (int r = blockIdx.y; r < rows; r += gridDim.y) y[(size_t)r * pitch + col] *= c;
+}
+
+// ... with the thrust-magnitude bound: one thread per (stage, QP) walks its block (the norm needs the m control rows together)
+static __global__ __launch_bounds__(256) void pv_to_zy_soc_kernel(const double* __restrict__ v, double* __restrict__ z,
+                                                                  double* __restrict__ y, const double* __restrict__ lo,
+                                                                  const double* __restrict__ hi, const double* __restrict__ ub,
+                                                                  int N, int nb, int m, int pitch) {
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= pitch) return;
+  for (int k = blockIdx.y; k < N; k += gridDim.y) {
+    const size_t base = (size_t)k * nb * pitch + col;
+    double ss = 0.0;
+    for (int j = 0; j < m; ++j) { const double vu = v[base + (size_t)j * pitch]; ss = fma(vu, vu, ss); }
+    const double nrm = sqrt(ss), ubk = ub[k];
+    const double cs = nrm > ubk ? ubk / nrm : 1.0;
+    for (int r = 0; r < nb; ++r) {
+      const size_t o = base + (size_t)r * pitch;
+      const double vv = v[o];
+      const double zz = fmin(fmax(r < m ? vv * cs : vv, lo[o]), hi[o]);
+      z[o] = zz;
+      y[o] = vv - zz;
+    }
+  }
 }
 
 static __global__ __launch_bounds__(256) void pv_to_zy_kernel(const double* __restrict__ v, double* __restrict__ z,

@@ -38,6 +38,14 @@ void launch_dim(const PLaunch& l, PKernel k) {
     else if (l.rows)                                                                                                             \
       hipLaunchKernelGGL((pxb_rows_kernel<NX, NU, HQ, VF, PB_, false>), rgrid, block, 0, l.stream, l.vform ? l.v : l.z, l.y, l.q, \
                          l.Ad, l.Bd, l.Kd, l.Sd, l.lo, l.hi, l.dbuf, l.rhov, l.N, l.pitch, nullptr, nullptr, nullptr, nullptr);   \
+    else if (l.has_soc && (VF) && seg)                                                                                           \
+      hipLaunchKernelGGL((pxb_kernel<NX, NU, HQ, VF, PB_, true, (VF)>), sgrid, block, 0, l.stream, l.vform ? l.v : l.z, l.y, l.q, \
+                         l.Ad, l.Bd, l.Kd, l.Sd, l.lo, l.hi, l.dbuf, l.rhov, l.N, l.pitch, l.Omd, l.seg_start, l.tseg, l.eseg,    \
+                         l.ub);                                                                                                  \
+    else if (l.has_soc && (VF))                                                                                                  \
+      hipLaunchKernelGGL((pxb_kernel<NX, NU, HQ, VF, PB_, false, (VF)>), grid, block, 0, l.stream, l.vform ? l.v : l.z, l.y, l.q, \
+                         l.Ad, l.Bd, l.Kd, l.Sd, l.lo, l.hi, l.dbuf, l.rhov, l.N, l.pitch, nullptr, nullptr, nullptr, nullptr,    \
+                         l.ub);                                                                                                  \
     else if (seg)                                                                                                                \
       hipLaunchKernelGGL((pxb_kernel<NX, NU, HQ, VF, PB_, true>), sgrid, block, 0, l.stream, l.vform ? l.v : l.z, l.y, l.q, l.Ad, \
                          l.Bd, l.Kd, l.Sd, l.lo, l.hi, l.dbuf, l.rhov, l.N, l.pitch, l.Omd, l.seg_start, l.tseg, l.eseg);         \
@@ -81,6 +89,14 @@ void launch_dim(const PLaunch& l, PKernel k) {
       hipLaunchKernelGGL((pxfz_rows_kernel<NX, NU, true, RS, RX, VI, PB_, false, false>), rgrid, block, 0, l.stream, l.dbuf, l.x0, \
                          l.Ad, l.Bd, l.Kd, l.lo, l.hi, l.z, l.y, l.v, l.w, l.part, l.alpha, l.N, l.pitch, nullptr, nullptr,        \
                          nullptr, nullptr);                                                                                        \
+    else if (l.has_soc && seg)                                                                                                     \
+      hipLaunchKernelGGL((pxfz_kernel<NX, NU, true, RS, RX, VI, PB_, false, true, true>), sgrid, block, 0, l.stream, l.dbuf, l.x0, \
+                         l.Ad, l.Bd, l.Kd, l.lo, l.hi, l.z, l.y, l.v, l.w, l.part, l.alpha, l.N, l.pitch, l.Psd, l.seg_start,      \
+                         l.tin, l.xin, l.ub);                                                                                      \
+    else if (l.has_soc)                                                                                                            \
+      hipLaunchKernelGGL((pxfz_kernel<NX, NU, true, RS, RX, VI, PB_, false, false, true>), grid, block, 0, l.stream, l.dbuf, l.x0, \
+                         l.Ad, l.Bd, l.Kd, l.lo, l.hi, l.z, l.y, l.v, l.w, l.part, l.alpha, l.N, l.pitch, nullptr, nullptr,        \
+                         nullptr, nullptr, l.ub);                                                                                  \
     else if (seg)                                                                                                                  \
       hipLaunchKernelGGL((pxfz_kernel<NX, NU, true, RS, RX, VI, PB_, false, true>), sgrid, block, 0, l.stream, l.dbuf, l.x0, l.Ad, \
                          l.Bd, l.Kd, l.lo, l.hi, l.z, l.y, l.v, l.w, l.part, l.alpha, l.N, l.pitch, l.Psd, l.seg_start, l.tin,    \

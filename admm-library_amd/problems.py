@@ -113,22 +113,21 @@ class Problem:
             raise ValueError("lo and hi must have the same shape")
         if self.lo.ndim == 3 and not self.per_instance:
             raise ValueError("per-instance bounds need per-instance dynamics")
-        if self.per_instance and self.unorm is not None:
-            raise ValueError("the thrust-magnitude bound is not available with per-instance dynamics")
         if np.any(np.isnan(self.lo)) or np.any(np.isnan(self.hi)) or np.any(self.lo > self.hi):
             raise ValueError("bounds must satisfy lo <= hi and contain no NaN")
         if self.q is not None and self.q.shape != (self.batch, self.L):
             raise ValueError("q must be (batch, L)")
         if self.unorm is not None:
             un = np.asarray(self.unorm, np.float64)
-            if un.ndim > 1 or (un.ndim == 1 and (self.lo.ndim != 2 or un.shape != (N,))):
+            if un.ndim > 1 or (un.ndim == 1 and (self.lo.ndim < 2 or un.shape != (N,))):
                 raise ValueError("unorm must be a scalar, or (N,) together with per-stage bounds")
             if np.any(np.isnan(un)) or np.any(un <= 0):
                 raise ValueError("unorm must be positive (inf = off)")
-            lo_u = np.atleast_2d(self.lo)[:, :m]           # (1 or N, m)   (per-instance problems were refused above)
-            hi_u = np.atleast_2d(self.hi)[:, :m]
-            fin = np.isfinite(np.broadcast_to(un, (lo_u.shape[0],)))
-            if np.any(np.isfinite(lo_u[fin])) or np.any(np.isfinite(hi_u[fin])):
+            # (stages, m) control-row bounds of every QP: (1 | N, m) shared, (batch, N, m) per instance
+            lo_u = (self.lo if self.lo.ndim == 3 else np.atleast_2d(self.lo)[None])[..., :m]
+            hi_u = (self.hi if self.hi.ndim == 3 else np.atleast_2d(self.hi)[None])[..., :m]
+            fin = np.isfinite(np.broadcast_to(un, (lo_u.shape[1],)))
+            if np.any(np.isfinite(lo_u[:, fin])) or np.any(np.isfinite(hi_u[:, fin])):
                 raise ValueError("control rows must be unbounded (-inf, inf) where unorm is finite")
         for a in (self.A, self.B, self.Q, self.R, self.QN, self.x0):
             if not np.all(np.isfinite(a)):
@@ -287,11 +286,11 @@ def random_ltv(N: int, n: int, m: int, batch: int, seed: int = SEED0,
 
 
 def random_instances(N: int, n: int, m: int, batch: int, seed: int = SEED0, with_q: bool = True,
-                     instance_bounds: bool = True) -> Problem:
+                     instance_bounds: bool = True, thrust_norm: bool = False) -> Problem:
     """Per-instance time-varying dynamics (admm_problem.time_varying = 2): every QP is its own
     perturbation of a common random LTV plant, with its own per-stage box (instance_bounds) and linear term --
     the QP class a batched successive-convexification loop produces."""
-    base = random_ltv(N, n, m, batch, seed, with_q=with_q)
+    base = random_ltv(N, n, m, batch, seed, with_q=with_q, thrust_norm=thrust_norm)
     rng = np.random.default_rng(seed + 7)
     A = base.A[None] + 0.05 * rng.standard_normal((batch, N, n, n)) / np.sqrt(n)
     B = base.B[None] + 0.05 * rng.standard_normal((batch, N, n, m))

@@ -56,8 +56,7 @@ typedef struct admm_problem {
                              2: PER-INSTANCE dynamics, A is n*n*N*batch, B is n*m*N*batch (QP b's stages are contiguous):
                                 the KKT system of every QP is factored on the device and the sweeps stream their stage
                                 operators from HBM per QP (the (n, m) pairs of csrc/admm_pinst.hip and
-                                admm_pinst_g1.hip, n <= 6; no
-                                thrust-magnitude bound, precision_mode FP64 only) */
+                                admm_pinst_g1.hip, n <= 6; precision_mode FP64 only) */
   int32_t stage_bounds;   /* 0: lo/hi are (m+n);     1: lo/hi are (m+n)*N;   2 (with time_varying = 2 only): per
                              instance, lo/hi are (m+n)*N*batch */
   const double* A;

@@ -169,3 +169,41 @@ def test_adaptive_rho_per_qp_through_the_pieces_api(gpu):
         np.testing.assert_array_equal(s.rho_per_qp(), ref["rho"])
         assert int(info.iters_run) == ref["iters_run"]
         assert _close(s.get(), ref)
+
+
+@pytest.mark.parametrize("case", [dict(N=30, n=6, m=3, batch=70, seed=61), dict(N=24, n=6, m=3, batch=9, seed=62, instance_bounds=False),
+                                  dict(N=20, n=4, m=2, batch=5, seed=63, with_q=False), dict(N=16, n=6, m=4, batch=65, seed=64)],
+                         ids=["6_3_per_qp_box", "6_3_shared_box", "4_2", "6_4"])
+@pytest.mark.parametrize("alpha", [1.0, 1.6])
+@pytest.mark.parametrize("segments", [0, 1])
+def test_thrust_magnitude_bound_with_per_instance_dynamics(gpu, case, alpha, segments):
+    """||u_k||_2 <= ub_k on per-instance problems: per-stage bounds on most stages (shared by the batch),
+    the box on the rest, every QP with its own dynamics -- iterates and residuals against the one-QP oracle, a solve, the
+    read-out of (z, y) from v, and a rho change."""
+    p = pkg.random_instances(thrust_norm=True, **case)
+    assert p.unorm is not None and np.isfinite(p.unorm).any() and np.isinf(p.unorm).any()
+    with pkg.Solver(p, pkg.Options(rho=0.3, alpha=alpha, segments=segments)) as s:
+        done = 0
+        for upto in (1, 2, 9, 30):
+            s.run(upto - done, residual_every=3)
+            done = upto
+            ref = oc.solve(p, rho=0.3, alpha=alpha, max_iter=upto, check_interval=3, stop=False)
+            assert _close(s.get(), ref), upto
+        r, sd = s.residuals()[:2]
+        assert np.abs(r - ref["r"]).max() <= 1e-10 and np.abs(sd - ref["s"]).max() <= 1e-10
+        # the thrust really is on its bound somewhere, and never beyond it
+        z = s.get(False, True, False)[1].reshape(p.batch, p.N, p.n + p.m)
+        nrm = np.linalg.norm(z[:, :, :p.m], axis=2)
+        fin = np.isfinite(p.unorm)
+        assert (nrm[:, fin] <= p.unorm[fin] * (1 + 1e-12)).all() and (nrm[:, fin] >= p.unorm[fin] * (1 - 1e-12)).any()
+        s.set_rho(0.9)
+        s.iterate(4)
+        ref2 = oc.solve(p, rho=0.9, alpha=alpha, max_iter=4, stop=False, z0=ref["z"], y0=ref["y"] * (0.3 / 0.9))
+        assert _close(s.get(), ref2)
+    kw = dict(rho=0.3, alpha=alpha, eps_abs=1e-7, eps_rel=1e-7, max_iter=1500, check_interval=10, adapt_interval=20, adapt_mu=2.0)
+    ref = oc.solve(p, **kw)
+    with pkg.Solver(p, pkg.Options(segments=segments, **kw)) as s:
+        info = s.solve()
+        assert int(info.iters_run) == ref["iters_run"]
+        np.testing.assert_array_equal(s.rho_per_qp(), ref["rho"])
+        assert _close(s.get(), ref)

@@ -20,8 +20,9 @@ for trial in range(trials):
     segs = int(rng.choice([0, 0, 1, 2, 3, 7, 32]))
     alpha = float(rng.choice([1.0, 1.0, 1.6]))
     rho = float(rng.choice([0.05, 0.3, 1.0]))
+    soc = bool(rng.integers(3) == 0)                 # thrust-magnitude bound on most stages (one-lane kernels)
     p = pkg.random_instances(N=N, n=n, m=m, batch=batch, seed=1000 + trial, with_q=bool(rng.integers(2)),
-                             instance_bounds=bool(rng.integers(2)))
+                             instance_bounds=bool(rng.integers(2)), thrust_norm=soc)
     form = str(rng.choice(["auto", "lane_per_qp", "rows"]))          # csrc/admm_pinst.hpp / admm_pinst_rows.hpp, forced either way
     os.environ.pop("ADMM_PI_LANE_PER_QP", None)
     os.environ.pop("ADMM_PI_ROWS", None)
@@ -29,7 +30,7 @@ for trial in range(trials):
         os.environ["ADMM_PI_LANE_PER_QP"] = "1"
     elif form == "rows":
         os.environ["ADMM_PI_ROWS"] = "1"
-    desc = dict(trial=trial, n=n, m=m, N=N, batch=batch, segs=segs, alpha=alpha, rho=rho, form=form)
+    desc = dict(trial=trial, n=n, m=m, N=N, batch=batch, segs=segs, alpha=alpha, rho=rho, form=form, soc=soc)
     try:
         if rng.integers(3) == 0:                      # a solve with the per-QP adaptive rule
             ci = int(rng.choice([1, 5, 10]))
