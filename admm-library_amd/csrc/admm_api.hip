@@ -1081,7 +1081,8 @@ int admm_setup(admm_handle** out, const admm_problem* p, const admm_options* o_i
     const bool compiled = admm::mfma_dims(p->n, p->m) && admm::launch_mfma(lq, admm::XKernel::XFZE, false, true);
     std::string why;
     if (!compiled) why = "(n, m) has no MFMA instantiation; compiled: " + std::string(admm::dims_mfma());
-    else if (h->has_q) why = "a linear term q is not supported by the MFMA forms";
+    else if (h->has_q && !(p->n == 6 && p->m == 3 && h->pitch <= 128 && o.precision_mode != ADMM_PRECISION_MIXED))
+      why = "a linear term q is supported by the fp64 MFMA forms of (6, 3) for batches of up to 128 QPs only";
     else if (h->has_soc) why = "a thrust-magnitude bound is not supported by the MFMA forms";
     else if (o.flags & (ADMM_FLAG_UNFUSED | ADMM_FLAG_SCAN_CHAIN)) why = "ADMM_FLAG_UNFUSED / ADMM_FLAG_SCAN_CHAIN exclude the MFMA forms";
     if (o.precision_mode != ADMM_PRECISION_FP64) {

@@ -28,6 +28,33 @@ bool launch_dim(const XLaunch& l, XKernel k, bool resid, bool query_only) {
   const bool nt1 = l.pitch <= 128;
   const dim3 grid((l.pitch + mf_cols(nt1 ? 1 : 2) - 1) / mf_cols(nt1 ? 1 : 2), l.S), block(MF_THREADS);
   const bool relax = l.alpha != 1.0;
+  if (l.has_q) {
+    // A linear term q: HASQ forms of the fp64 alternating pair with one tile per wave (small batches), for the shape of the
+    // successive-convexification QPs only -- every form doubles the compile time of this unit, and at n = 12 the extra
+    // prefetch registers do not fit under the 256-register cap of two waves per SIMD.  (admm_setup picks the one-lane kernels
+    // for every other problem with q.)
+    if constexpr (NX == 6 && NU == 3) {
+      if (!nt1 || mixed || !(k == XKernel::XFZE || k == XKernel::XBZE)) return false;
+#define QF(RS, RX, XF) hipLaunchKernelGGL((xfzem_kernel<NX, NU, 1, double, double, RS, RX, true, XF, true>), grid, block, 0, l.stream, \
+                                          l.dbuf, l.tin, l.xin, l.recMF, l.seg_start, l.v, l.mvec, l.tseg, l.eseg, l.part, l.alpha, l.rho, \
+                                          l.pitch, l.nsplit, l.split_stride, l.batch, l.q)
+#define QB(RS, RX, XF) hipLaunchKernelGGL((xbzem_kernel<NX, NU, 1, double, double, RS, RX, true, XF, true>), grid, block, 0, l.stream, \
+                                          l.mvec, l.tin, l.xin, l.recMB, l.seg_start, l.v, l.dbuf, l.tseg, l.eseg, l.part, l.alpha, l.rho, \
+                                          l.pitch, l.nsplit, l.split_stride, l.batch, l.q)
+#define QK(RS, RX, XF) do { if (k == XKernel::XFZE) QF(RS, RX, XF); else QB(RS, RX, XF); } while (0)
+      if (resid) { if (relax) QK(true, true, 0); else QK(true, false, 0); }
+      else if (relax) QK(false, true, 0);
+      else if (l.xfree == 2) QK(false, false, 2);
+      else if (l.xfree == 1) QK(false, false, 1);
+      else QK(false, false, 0);
+#undef QK
+#undef QB
+#undef QF
+      return true;
+    } else {
+      return false;
+    }
+  }
 #define FWD0(NT_, TS, TE, RS, RX, EL, XF)                                                                               \
   hipLaunchKernelGGL((xfzem_kernel<NX, NU, NT_, TS, TE, RS, RX, EL, XF>), grid, block, 0, l.stream, l.dbuf, l.tin, l.xin, l.recMF, \
                      l.seg_start, l.v, l.mvec, l.tseg, l.eseg, l.part, l.alpha, l.rho, l.pitch, l.nsplit, l.split_stride, l.batch)

@@ -157,12 +157,13 @@ __device__ __forceinline__ double mf_colsum(double x) {
 //     ELIM_F:  [mu+ ; deps ; db_k] = M [mu ; g^x ; g^u],  eps += deps,  db_k -> dbb          (ELIM only)
 // and on exit mu -> mseg[s], eps -> epsseg[s] (ELIM), residual partials -> part (RESID).
 // ---------------------------------------------------------------------------
-template <int NX, int NU, int NT, class TS, class TE, bool RESID, bool RELAX, bool ELIM, int XFREE = 0>
+// HASQ: a linear cost term q (block rows like v): g = -rho (z+ - y+) + q.
+template <int NX, int NU, int NT, class TS, class TE, bool RESID, bool RELAX, bool ELIM, int XFREE = 0, bool HASQ = false>
 __global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void xfzem_kernel(
     const double* __restrict__ dbuf, const double* __restrict__ tin, const double* __restrict__ xin,
     const unsigned char* __restrict__ recMF, const int* __restrict__ seg_start_, double* __restrict__ v,
     double* __restrict__ dbb, double* __restrict__ mseg, double* __restrict__ epsseg, double* __restrict__ part,
-    double alpha, double rho, int pitch, int nsplit, size_t split_stride, int batch) {
+    double alpha, double rho, int pitch, int nsplit, size_t split_stride, int batch, const double* __restrict__ qlin = nullptr) {
   typedef MfmaOps<TS> OpsS;
   typedef MfmaOps<TE> OpsE;
   typedef typename OpsS::acc_t accs_t;
@@ -190,6 +191,7 @@ __global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
   const RowView vv(v, (size_t)k0 * NB * P, (size_t)(k1 - k0) * NB * P * 8);
   const RowView vd(dbuf, (size_t)k0 * NU * P, (size_t)(k1 - k0) * NU * P * 8);
   const RowView vm(dbb, (size_t)k0 * NU * P, (size_t)(k1 - k0) * NU * P * 8);
+  const RowView vq(HASQ ? qlin : v, (size_t)k0 * NB * P, (size_t)(k1 - k0) * NB * P * 8);
 
   // slot validity of this lane group (compile-time in r, run-time in g)
   bool okx[NR];
@@ -233,7 +235,7 @@ __global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     for (int q = 0; q < 5; ++q) racc[nt][q] = 0.0;
 
   // operand prefetch ring, MF_PF stages deep: v rows (5 registers) and d rows (2) per tile and slot
-  double pv[MF_PF][NT][5], pd[MF_PF][NT][2];
+  double pv[MF_PF][NT][5], pd[MF_PF][NT][2], pq[HASQ ? MF_PF : 1][NT][5];
   auto load_stage = [&](int k, int j, int nt) {
     const int kk = k < k1 ? k : k1 - 1;
     const unsigned r0 = (unsigned)(kk - k0) * NB * PB;
@@ -241,6 +243,12 @@ __global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     for (int r = 0; r < NR; ++r) pv[j][nt][r] = XFREE ? 0.0 : vv.load(lbl[nt], r0 + (unsigned)(NU + 4 * r) * PB);
     pv[j][nt][3] = vv.load(lbl[nt], r0);
     pv[j][nt][4] = XT ? vv.load(lbl[nt], r0 + 4u * PB) : 0.0;
+    if (HASQ) {
+#pragma unroll
+      for (int r = 0; r < NR; ++r) pq[HASQ ? j : 0][nt][r] = vq.load(lbl[nt], r0 + (unsigned)(NU + 4 * r) * PB);
+      pq[HASQ ? j : 0][nt][3] = vq.load(lbl[nt], r0);
+      pq[HASQ ? j : 0][nt][4] = XT ? vq.load(lbl[nt], r0 + 4u * PB) : 0.0;
+    }
     const unsigned d0 = (unsigned)(kk - k0) * NU * PB;
     pd[j][nt][0] = vd.load(lbl[nt], d0);
     pd[j][nt][1] = XT ? vd.load(lbl[nt], d0 + 4u * PB) : 0.0;
@@ -267,7 +275,7 @@ __global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
       const unsigned char* rec = lds[buf] + (k - kc) * RM;
       const TS* af = reinterpret_cast<const TS*>(rec);
       const double* lohi = reinterpret_cast<const double*>(rec + O_LOHI);
-      double c0[NT][5], dk[NT][2];
+      double c0[NT][5], dk[NT][2], qk[HASQ ? NT : 1][5];
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
@@ -276,6 +284,12 @@ __global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         c0[nt][4] = (XT && oku1) ? pv[j][nt][4] : 0.0;
         dk[nt][0] = oku0 ? pd[j][nt][0] : 0.0;
         dk[nt][1] = (XT && oku1) ? pd[j][nt][1] : 0.0;
+        if (HASQ) {
+#pragma unroll
+          for (int r = 0; r < NR; ++r) qk[HASQ ? nt : 0][r] = okx[r] ? pq[HASQ ? j : 0][nt][r] : 0.0;
+          qk[HASQ ? nt : 0][3] = oku0 ? pq[HASQ ? j : 0][nt][3] : 0.0;
+          qk[HASQ ? nt : 0][4] = (XT && oku1) ? pq[HASQ ? j : 0][nt][4] : 0.0;
+        }
         load_stage(k + MF_PF, j, nt);
       }
       // ---- SUB_F ----
@@ -325,6 +339,11 @@ __global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
           vv.store(vn, oku1 ? lbs[nt] : ROWVIEW_OOB, r0 + 4u * PB);
         } else {
           gg[nt][4] = 0.0;
+        }
+        if (HASQ) {
+#pragma unroll
+          for (int q5 = 0; q5 < 5; ++q5)
+            if (q5 < NR || q5 >= 3) gg[nt][q5] += qk[HASQ ? nt : 0][q5];
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -396,12 +415,12 @@ __global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 //     ELIM_B:  [t+ ; de ; d0_k] = M [g^x + t ; g^u],  e += de,  d0_k -> dbuf
 // and on exit t -> tseg[s], e -> eseg[s]: what xb_kernel / xbze_kernel leave for the plain scan.
 // ---------------------------------------------------------------------------
-template <int NX, int NU, int NT, class TS, class TE, bool RESID, bool RELAX, bool SUBST, int XFREE = 0>
+template <int NX, int NU, int NT, class TS, class TE, bool RESID, bool RELAX, bool SUBST, int XFREE = 0, bool HASQ = false>
 __global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void xbzem_kernel(
     const double* __restrict__ dbb, const double* __restrict__ min_, const double* __restrict__ xend,
     const unsigned char* __restrict__ recMB, const int* __restrict__ seg_start_, double* __restrict__ v,
     double* __restrict__ dbuf, double* __restrict__ tseg, double* __restrict__ eseg, double* __restrict__ part,
-    double alpha, double rho, int pitch, int nsplit, size_t split_stride, int batch) {
+    double alpha, double rho, int pitch, int nsplit, size_t split_stride, int batch, const double* __restrict__ qlin = nullptr) {
   typedef MfmaOps<TS> OpsS;
   typedef MfmaOps<TE> OpsE;
   typedef typename OpsS::acc_t accs_t;
@@ -429,6 +448,7 @@ __global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
   const RowView vv(v, (size_t)k0 * NB * P, (size_t)(k1 - k0) * NB * P * 8);
   const RowView vd(dbuf, (size_t)k0 * NU * P, (size_t)(k1 - k0) * NU * P * 8);
   const RowView vm(dbb, (size_t)k0 * NU * P, (size_t)(k1 - k0) * NU * P * 8);
+  const RowView vq(HASQ ? qlin : v, (size_t)k0 * NB * P, (size_t)(k1 - k0) * NB * P * 8);
 
   bool okx[NR];
 #pragma unroll
@@ -475,7 +495,7 @@ __global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
     for (int q = 0; q < 5; ++q) racc[nt][q] = 0.0;
 
-  double pv[MF_PF][NT][5], pd[MF_PF][NT][2];
+  double pv[MF_PF][NT][5], pd[MF_PF][NT][2], pq[HASQ ? MF_PF : 1][NT][5];
   auto load_stage = [&](int k, int j, int nt) {
     const int kk = k > k0 ? k : k0;
     const unsigned r0 = (unsigned)(kk - k0) * NB * PB;
@@ -483,6 +503,12 @@ __global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     for (int r = 0; r < NR; ++r) pv[j][nt][r] = XFREE ? 0.0 : vv.load(lbl[nt], r0 + (unsigned)(NU + 4 * r) * PB);
     pv[j][nt][3] = vv.load(lbl[nt], r0);
     pv[j][nt][4] = XT ? vv.load(lbl[nt], r0 + 4u * PB) : 0.0;
+    if (HASQ) {
+#pragma unroll
+      for (int r = 0; r < NR; ++r) pq[HASQ ? j : 0][nt][r] = vq.load(lbl[nt], r0 + (unsigned)(NU + 4 * r) * PB);
+      pq[HASQ ? j : 0][nt][3] = vq.load(lbl[nt], r0);
+      pq[HASQ ? j : 0][nt][4] = XT ? vq.load(lbl[nt], r0 + 4u * PB) : 0.0;
+    }
     if (SUBST) {
       const unsigned d0 = (unsigned)(kk - k0) * NU * PB;
       pd[j][nt][0] = vm.load(lbl[nt], d0);
@@ -517,7 +543,7 @@ __global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
       const unsigned char* rec = lds[buf] + (k - klo) * RM;
       const TS* af = reinterpret_cast<const TS*>(rec);
       const double* lohi = reinterpret_cast<const double*>(rec + O_LOHI);
-      double c0[NT][5], dk[NT][2];
+      double c0[NT][5], dk[NT][2], qk[HASQ ? NT : 1][5];
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
@@ -526,6 +552,12 @@ __global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         c0[nt][4] = (XT && oku1) ? pv[j][nt][4] : 0.0;
         dk[nt][0] = oku0 ? pd[j][nt][0] : 0.0;
         dk[nt][1] = (XT && oku1) ? pd[j][nt][1] : 0.0;
+        if (HASQ) {
+#pragma unroll
+          for (int r = 0; r < NR; ++r) qk[HASQ ? nt : 0][r] = okx[r] ? pq[HASQ ? j : 0][nt][r] : 0.0;
+          qk[HASQ ? nt : 0][3] = oku0 ? pq[HASQ ? j : 0][nt][3] : 0.0;
+          qk[HASQ ? nt : 0][4] = (XT && oku1) ? pq[HASQ ? j : 0][nt][4] : 0.0;
+        }
         load_stage(k - MF_PF, j, nt);
       }
       double gg[NT][5];
@@ -588,6 +620,13 @@ __global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
             const double zz = fmin(fmax(c0[nt][q], lohi[slot]), lohi[20 + slot]);
             gg[nt][q] = ((q < NR || q == 3) || (q == 4 && XT)) ? -rho * (zz - (c0[nt][q] - zz)) : 0.0;
           }
+      }
+      if (HASQ) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int q5 = 0; q5 < 5; ++q5)
+            if (q5 < NR || q5 == 3 || (q5 == 4 && XT)) gg[nt][q5] += qk[HASQ ? nt : 0][q5];
       }
       __builtin_amdgcn_sched_barrier(0);
       // ---- ELIM_B ----

@@ -113,8 +113,8 @@ typedef struct admm_options {
    *              iterates in this form until the stopping rule holds with eps_abs, eps_rel raised to at least 1e-4,
    *              then continues with the FP64_MFMA kernels until it holds as given (admm_info.mixed_iters = length
    *              of the first phase).  admm_run / admm_iterate always run the mixed form.
-   * The two MFMA forms exist for the (n, m) pairs of csrc/admm_mfma.hip, without q and without a thrust-magnitude
-   * bound: ADMM_ERR_UNSUPPORTED otherwise. */
+   * The two MFMA forms exist for the (n, m) pairs of csrc/admm_mfma.hip, without a thrust-magnitude bound and without q
+   * (except FP64 / FP64_MFMA at (6, 3) with a batch of up to 128 QPs, where q is supported): ADMM_ERR_UNSUPPORTED otherwise. */
   int32_t precision_mode;
   int32_t reserved;       /* must be 0 */
 } admm_options;

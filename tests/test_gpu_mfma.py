@@ -149,3 +149,41 @@ def test_unsupported_combinations_fail_loudly(gpu):
         assert e.value.code == unsup
     with pytest.raises(pkg.AdmmError):
         pkg.Solver(pkg.cw_rendezvous(N=40, batch=3), pkg.Options(rho=0.1, precision_mode=7))
+
+
+@pytest.mark.parametrize("make", [lambda: pkg.random_ltv(N=40, n=6, m=3, batch=1, seed=71), lambda: pkg.random_ltv(N=33, n=6, m=3, batch=70, seed=72),
+                                  lambda: pkg.random_ltv(N=25, n=6, m=3, batch=17, seed=73, state_bounds=False)],
+                         ids=["one_qp", "two_waves", "state_rows_unbounded"])
+@pytest.mark.parametrize("alpha", [1.0, 1.6])
+def test_fp64_mfma_with_a_linear_term(gpu, make, alpha):
+    """The HASQ forms of the fp64 MFMA kernels ((6, 3), batches of up to 128 QPs: the default there, and what the
+    single-trajectory successive-convexification QPs run): iterates, residuals and a solve against the oracle, and against the
+    one-lane kernels (ADMM_FLAG_NO_MFMA)."""
+    p = make()
+    assert p.q is not None
+    with pkg.Solver(p, pkg.Options(rho=0.3, alpha=alpha, precision_mode=FP64_MFMA)) as s, \
+            pkg.Solver(p, pkg.Options(rho=0.3, alpha=alpha, flags=_abi.FLAG_NO_MFMA)) as s1:
+        done = 0
+        for upto in (1, 2, 3, 8, 9, 30):
+            s.run(upto - done, residual_every=4)
+            s1.run(upto - done, residual_every=4)
+            done = upto
+            ref = oc.solve(p, rho=0.3, alpha=alpha, max_iter=upto, check_interval=4, stop=False)
+            assert _err(s.get(), ref) <= 1e-10 and _err(s1.get(), ref) <= 1e-10, upto
+    with pkg.Solver(p, pkg.Options(rho=0.3, alpha=alpha, precision_mode=FP64_MFMA)) as s:
+        s.run(28, residual_every=4)
+        ref = oc.solve(p, rho=0.3, alpha=alpha, max_iter=28, check_interval=4, stop=False)
+        r, sd = s.residuals()[:2]
+        assert np.abs(r - ref["r"]).max() <= 1e-10 and np.abs(sd - ref["s"]).max() <= 1e-10
+    kw = dict(rho=0.3, alpha=alpha, eps_abs=1e-7, eps_rel=1e-7, max_iter=2000, check_interval=10, adapt_interval=50)
+    ref = oc.solve(p, **kw)
+    with pkg.Solver(p, pkg.Options(**kw)) as s:                      # the default picks the MFMA form for these batches
+        info = s.solve()
+        assert int(info.iters_run) == ref["iters_run"] and float(info.rho) == ref["rho"]
+        assert _err(s.get(), ref) <= 1e-10
+    # not available: mixed precision with q, q at n = 12, q with a batch beyond 128
+    unsup = {v: k for k, v in _abi.STATUS_NAMES.items()}["ADMM_ERR_UNSUPPORTED"]
+    for bad, opt in ((p, dict(precision_mode=MIXED)), (pkg.random_ltv(N=10, n=6, m=3, batch=200, seed=1), dict(precision_mode=FP64_MFMA))):
+        with pytest.raises(pkg.AdmmError) as e:
+            pkg.Solver(bad, pkg.Options(rho=0.3, **opt))
+        assert e.value.code == unsup
