@@ -23,6 +23,7 @@
 namespace {
 
 thread_local std::string g_err;
+thread_local std::string g_warn;     // admm_last_warning(): a call succeeded but changed the kernels a handle runs
 
 int fail(int code, const std::string& msg) {
   g_err = msg;

@@ -78,45 +78,71 @@ def parse():
     return ap.parse_args()
 
 
-def pmc_traffic(kernel_substr):
-    """HBM bytes per launch of a kernel from the newest committed PMC summary under profiles/
-    (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of this same command,
-    FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md §HBM; profiles/summarize.py).
-    bench.py cannot collect counters on itself, so it reports the stored measurement or None."""
-    import csv
+def newest_profile(suffix, workload_tag=""):
+    """Newest committed summary profiles/r<NN><x>[_<workload_tag>]<suffix> (tags sort by round, then letter)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.csv")))
-    for f in reversed(files):
-        for row in csv.DictReader(open(f)):
-            if kernel_substr in row["kernel"] and float(row["hbm_MB_per_launch"]) > 0:
-                return float(row["hbm_MB_per_launch"]) * 1e6, os.path.relpath(f, ROOT)
-    return None, None
+    import re
+    pat = re.compile(r"^r(\d+)([a-z]*)" + (f"_{workload_tag}" if workload_tag else "") + re.escape(suffix) + "$")
+    hits = [(int(m.group(1)), m.group(2), f) for f in glob.glob(os.path.join(ROOT, "profiles", "*" + suffix))
+            for m in [pat.match(os.path.basename(f))] if m]
+    return max(hits)[2] if hits else None
+
+
+def pmc_rows(path, base, lead_args):
+    """Rows of a profiles/*.csv whose kernel is admm::<base><lead_args..., ...>: matched on the kernel's BASE NAME and its
+    LEADING template arguments, so a template parameter appended later does not silently break the match (r02: the names
+    gained a trailing XFREE argument and the lookup walked back to an older file)."""
+    import csv
+    want = f"admm::{base}<" + ", ".join(lead_args)
+    out = []
+    for row in csv.DictReader(open(path)):
+        k = row["kernel"].replace("void ", "")
+        if k.startswith(want) and k[len(want):len(want) + 1] in (",", ">"):
+            out.append(row)
+    return out
+
+
+def pmc_traffic(base, lead_args, workload_tag=""):
+    """HBM bytes per launch of a kernel from the NEWEST committed PMC summary under profiles/ (rocprofv3 --pmc FETCH_SIZE and
+    --pmc WRITE_SIZE in separate passes of this same command, FETCH_SIZE doubled per the gfx950 correction of
+    MI355X_MICROARCH.md §HBM; profiles/summarize.py).  bench.py cannot collect counters on itself, so it reports the stored
+    measurement.  RAISES if the newest summary does not hold the kernel: a stale file must never be cited in its place."""
+    path = newest_profile("_hbm_traffic.csv", workload_tag)
+    if path is None:
+        return None, None
+    rows = [r for r in pmc_rows(path, base, lead_args) if float(r["hbm_MB_per_launch"]) > 0]
+    if not rows:
+        raise RuntimeError(f"bench.py: {os.path.relpath(path, ROOT)} (the newest PMC summary) has no row for admm::{base}<"
+                           f"{', '.join(lead_args)}, ...>: re-run tools/gpu_profile.sh and commit the summary")
+    row = max(rows, key=lambda r: int(r["launches_fetch_pass"]))          # the form the timed region launches most
+    return float(row["hbm_MB_per_launch"]) * 1e6, f"{os.path.relpath(path, ROOT)}: {row['kernel']}"
+
+
+def pmc_mfma(base, lead_args, workload_tag=""):
+    """Measured matrix-pipe counters of a kernel from the newest profiles/*_mfma.csv (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES
+    GRBM_GUI_ACTIVE and --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_VALU_MFMA_MOPS_F32, separate passes; summarize.py)."""
+    path = newest_profile("_mfma.csv", workload_tag)
+    if path is None:
+        return None
+    rows = pmc_rows(path, base, lead_args)
+    if not rows:
+        return None
+    row = max(rows, key=lambda r: int(r["launches"]))
+    out = {k: (float(v) if k not in ("kernel",) else v) for k, v in row.items()}
+    out["source"] = os.path.relpath(path, ROOT)
+    return out
 
 
 def cpu_baseline(N, target_s, workload="cw_rendezvous"):
-    """Time the CPU oracle (C/OpenMP restatement) on a bounded sample of the same workload."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import admm_library_amd as pkg
-    import oracle_c
-    cores = oracle_c.max_threads()
-    sample_batch = max(cores * 4, 16)
-    make = pkg.cw_formation if workload == "cw_formation" else pkg.cw_rendezvous
-    p = make(N=N, batch=sample_batch, **({"thrust_norm": True} if workload == "cw_rendezvous_soc" else {}))
-    oracle_c.solve(p, rho=0.05, max_iter=2, check_interval=1, stop=False, nthreads=cores)   # spin up threads
-    t0 = time.perf_counter()
-    oracle_c.solve(p, rho=0.05, max_iter=10, check_interval=1, stop=False, nthreads=cores)
-    t_it = (time.perf_counter() - t0) / 10
-    for _ in range(3):                      # the calibration run is colder than the timed one: re-aim if short
-        iters = int(max(10, min(100000, target_s / max(t_it, 1e-6))))
-        t0 = time.perf_counter()
-        oracle_c.solve(p, rho=0.05, max_iter=iters, check_interval=1, stop=False, nthreads=cores)
-        dt = time.perf_counter() - t0
-        if dt >= 0.66 * target_s:
-            break
-        t_it = dt / iters
-    return {"value": sample_batch * iters / dt, "unit": "QP-iterations/s", "cores": cores, "kind": "port",
-            "sample": f"{iters} iterations of {sample_batch} QPs ({workload}, N={N}, n={p.n}, m={p.m}), C/OpenMP oracle, "
-                      f"residuals every iteration, {dt:.1f} s"}
+    """Time the CPU oracle (C/OpenMP restatement) on a bounded sample of the same workload: oracle/cpu_baseline.py as a child
+    process (its OpenMP runtime starts with the thread count this box really offers -- affinity and cgroup quota -- and
+    bound threads, whatever this process has loaded)."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_baseline.py"), "--workload", workload,
+                        "--horizon", str(N), "--seconds", str(target_s)], capture_output=True, text=True, timeout=600)
+    if r.returncode != 0:
+        raise RuntimeError("bench.py: oracle/cpu_baseline.py failed:\n" + r.stderr[-2000:])
+    return json.loads(r.stdout.strip().splitlines()[-1])
 
 
 def launch_ranks(a):
@@ -315,16 +341,19 @@ def main():
                                                            and (n_, m_) in ((12, 6), (6, 3), (10, 4)) and full.q is None and full.unorm is None)
     b_xfz = 8.0 * m_ / (n_ + m_) + 16.0          # d read + v read + v+ written
     xfz_ms = prof["xfz_ms"]
-    pmc_ok = (a.batch, a.horizon, a.workload, a.precision) == (4096, 1000, "cw_rendezvous", "fp64")   # the stored PMC runs are of this workload only
+    # the stored PMC runs (profiles/r<NN><x>[_formation_mixed]_hbm_traffic.csv) are of these two workloads only
+    pmc_tag = {(4096, 1000, "cw_rendezvous", "fp64"): "", (4096, 1000, "cw_formation", "mixed"): "formation_mixed"}.get(
+        (a.batch, a.horizon, a.workload, a.precision))
     pmc_note = " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE x2)"
+    tf = {True: "true", False: "false"}
 
-    def kernel_roofline(name, desc, bytes_per_elem, ms, pmc_name):
+    def kernel_roofline(name, desc, bytes_per_elem, ms, pmc_id):
         ach = bytes_per_elem * elems / (ms * 1e-3) / 1e9
         r = {"kernel": f"{name} ({desc})", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "frac": ach / HBM_PEAK_GBS, "traffic": None, "bytes_per_launch": bytes_per_elem * elems,
              "bytes_per_element": bytes_per_elem, "avg_launch_ms": ms}
-        if pmc_ok:
-            tr, src = pmc_traffic(pmc_name)
+        if pmc_tag is not None:
+            tr, src = pmc_traffic(pmc_id[0], pmc_id[1], pmc_tag)
             r["traffic"] = tr
             if src:
                 r["traffic_source"] = src + pmc_note
@@ -332,16 +361,25 @@ def main():
 
     roofline_xfz = kernel_roofline(f"xfz_kernel<{n_},{m_},RESID=true,RELAX=false,VIN=true>",
                                    "plain path: forward rollout fused with z-update + dual ascent + residual partials, "
-                                   "state in v-form", b_xfz, xfz_ms, "xfz_kernel<6, 3, true, false, true")
+                                   "state in v-form", b_xfz, xfz_ms, ("xfz_kernel", [str(n_), str(m_), "true", "false", "true"]))
     if prof_alt is not None:
         b_alt = 16.0 + 16.0 * m_ / (n_ + m_) + (8.0 if full.q is not None else 0.0)   # v, v+, d and db rows (+ q)
         kf = "xfzem_kernel" if uses_mfma else "xfze_kernel"
         kb = "xbzem_kernel" if uses_mfma else "xbze_kernel"
+        if uses_mfma:       # <NX, NU, NT, TS, TE, RESID, RELAX, ELIM / SUBST, ...>: csrc/admm_mfma.hpp
+            nt = "1" if geo["pitch"] <= 128 else "2"
+            mixed = a.precision == "mixed"
+            id_f = (kf, [str(n_), str(m_), nt, "float" if mixed else "double", "double", "true", "false", "true"])
+            id_b = (kb, [str(n_), str(m_), nt, "double", "float" if mixed else "double", "true", "false", "true"])
+        else:               # <n, m, RESID, RELAX, HASQ, SOC, ...>: csrc/admm_kernels_alt.hpp
+            lead = [str(n_), str(m_), "true", "false", tf[full.q is not None], tf[full.unorm is not None]]
+            id_f, id_b = (kf, lead), (kb, lead)
         rf = kernel_roofline(f"{kf}<{n_},{m_},RESID=true,RELAX=false,HASQ=false,SOC=false>",
                              "forward rollout + z-update + dual ascent + residual partials + forward elimination of v+",
-                             b_alt, prof_alt["xfze_ms"], "xfze_kernel<6, 3, true, false, false, false>")
+                             b_alt, prof_alt["xfze_ms"], id_f)
         rb = kernel_roofline(f"{kb}<{n_},{m_},RESID=true,RELAX=false,HASQ=false,SOC=false>",
-                             "backward rollout + z-update + dual ascent + residual partials + backward elimination of v+", b_alt, prof_alt["xbze_ms"], "xbze_kernel<6, 3, true, false, false, false>")
+                             "backward rollout + z-update + dual ascent + residual partials + backward elimination of v+",
+                             b_alt, prof_alt["xbze_ms"], id_b)
         pair_ms = prof_alt["xfze_ms"] + prof_alt["xbze_ms"]
         ach = 2 * b_alt * elems / (pair_ms * 1e-3) / 1e9
         roofline = {"kernel": f"xfze_kernel / xbze_kernel <{n_},{m_},RESID=true,RELAX=false> (the alternating pair: one of them "

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ADMM_HIP_ABI_VERSION 5
+#define ADMM_HIP_ABI_VERSION 6
 
 typedef enum admm_status {
   ADMM_OK = 0,
@@ -275,6 +275,35 @@ int admm_get_rho(admm_handle* h, double* rho);
 /* Geometry chosen at setup, for roofline accounting: pitch = padded batch,
  * segs = x-update segments, zrows = rows per z-kernel chunk, zchunks. */
 int admm_get_geometry(admm_handle* h, int32_t* pitch, int32_t* segs, int32_t* zrows, int32_t* zchunks);
+
+/* Which kernels the handle runs, and the measured margin of the default path (ABI v6).  The default iteration alternates
+ * the elimination direction; its forward-elimination factor carries large early-stage gains, so admm_setup
+ * (and every refactor: admm_set_rho, the adaptive rule, admm_update_problem) verifies it on the host -- one x-update with a
+ * random linear term through both forms -- and falls back to the plain fused path (29.33 instead of 21.33 B per stacked
+ * element and iteration at n = 6, m = 3) when the relative mismatch alt_check exceeds alt_gate.  That fallback is reported
+ * here and through admm_last_warning(), never silently. */
+typedef struct admm_path_info {
+  int32_t alternating;     /* 1: the alternating-direction fused kernels run; 0: the plain fused (or unfused) path */
+  int32_t alt_requested;   /* 1: options / compiled kernels allow alternation for this problem class (0: ADMM_FLAG_NO_ALTERNATE,
+                              _UNFUSED, _SCAN_CHAIN, per-instance dynamics, (n, m) without the fused kernels) */
+  int32_t mfma;            /* kernel family of the fused sweeps: 0 one lane per QP (fp64 VALU), 1 MIXED, 2 fp64 MFMA */
+  int32_t xfree;           /* 1: every state row is unbounded at every stage: iterations without residuals neither read nor
+                              write v of those rows (XFREE forms) */
+  int32_t segments;        /* parallel-in-time segments of the x-update */
+  int32_t auto_segments;   /* 1: chosen by admm_setup (and guarded by the conditioning bound on every refactor) */
+  int32_t scan_form;       /* segment scan: 0 fp64-MFMA GEMM, 1 matrix-vector (batches <= 4), 2 sequential chain, 3 per-QP (per-instance) */
+  int32_t per_instance;    /* 1: time_varying = 2 (device factor, operands per QP from HBM) */
+  double  alt_check;       /* relative mismatch of the forward-elimination form on the host verification vector; -1: not run
+                              (alternation not requested, or the form could not be built: a singular A_k or covariance) */
+  double  alt_gate;        /* the bound alt_check must meet (5e-12) */
+  double  scan_growth;     /* largest |entry| of the segment-scan matrices (conditioning bound: <= 100 with automatic segments) */
+} admm_path_info;
+int admm_get_path(admm_handle* h, admm_path_info* info);
+
+/* Thread-local diagnostic of the last admm_setup / admm_set_rho / admm_update_problem / admm_solve* call on this thread that
+ * SUCCEEDED but changed the kernels a handle runs (the forward-elimination gate above; the adaptive rule refused a rho); ""
+ * if there was nothing to report.  Cleared at the start of each of those calls. */
+const char* admm_last_warning(void);
 
 void admm_free(admm_handle* h);
 

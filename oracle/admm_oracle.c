@@ -236,6 +236,11 @@ int oracle_solve(const admm_problem* p, const admm_options* o, int32_t stop,
 #ifdef _OPENMP
   if (nthreads > 0) omp_set_num_threads(nthreads);
 #endif
+  int nthr = 1;
+#ifdef _OPENMP
+  nthr = omp_get_max_threads();
+#endif
+  double* dscr = (double*)malloc(sizeof(double) * (size_t)nthr * N * m);   /* x-update scratch (d), one slab per thread */
   const double sqrtL = sqrt((double)L);
   int it = 0;
   for (it = 1; it <= o->max_iter; ++it) {
@@ -246,42 +251,46 @@ int oracle_solve(const admm_problem* p, const admm_options* o, int32_t stop,
       double* zb = z + (size_t)b * L;
       double* yb = y + (size_t)b * L;
       double* wb = w + (size_t)b * L;
-      double* d = (double*)malloc(sizeof(double) * (size_t)N * m);
+#ifdef _OPENMP
+      double* d = dscr + (size_t)omp_get_thread_num() * N * m;   /* per-thread scratch, allocated once per solve */
+#else
+      double* d = dscr;
+#endif
       x_update_one(p, &f, AB, rho, zb, yb, p->q ? p->q + (size_t)b * L : NULL,
                    p->x0 + (size_t)b * n, wb, d);
-      free(d);
       double a_r = 0, a_s = 0, a_w = 0, a_z = 0, a_y = 0;
-      double cscale = 1.0;      /* thrust-magnitude projection factor of the current block */
-      int soc = 0;
-      for (size_t e = 0; e < L; ++e) {
-        const size_t blk = e / nb, row = e % nb;
-        const double lo = p->lo[(p->stage_bounds ? blk * nb : 0) + row];
-        const double hi = p->hi[(p->stage_bounds ? blk * nb : 0) + row];
-        if (row == 0) {           /* block start: ||v_u|| of this block decides the scaling of its control rows */
-          const double ub = p->unorm ? p->unorm[p->stage_bounds ? blk : 0] : INFINITY;
-          soc = isfinite(ub);
-          cscale = 1.0;
-          if (soc) {
-            double ss = 0.0;
-            for (int j = 0; j < m; ++j) {
-              const double wj = wb[e + j], zj = zb[e + j];
-              const double whj = (alpha == 1.0) ? wj : alpha * wj + (1.0 - alpha) * zj;
-              const double vj = whj + yb[e + j];
-              ss = fma(vj, vj, ss);
-            }
-            const double nrm = sqrt(ss);
-            if (nrm > ub) cscale = ub / nrm;
+      for (int blk = 0; blk < N; ++blk) {       /* block by block, rows in order: the element order e = blk * nb + row */
+        const size_t e0 = (size_t)blk * nb;
+        const double* lob = p->lo + (p->stage_bounds ? e0 : 0);
+        const double* hib = p->hi + (p->stage_bounds ? e0 : 0);
+        /* block start: ||v_u|| of this block decides the scaling of its control rows */
+        const double ub = p->unorm ? p->unorm[p->stage_bounds ? blk : 0] : INFINITY;
+        const int soc = isfinite(ub);
+        double cscale = 1.0;      /* thrust-magnitude projection factor of the current block */
+        if (soc) {
+          double ss = 0.0;
+          for (int j = 0; j < m; ++j) {
+            const double wj = wb[e0 + j], zj = zb[e0 + j];
+            const double whj = (alpha == 1.0) ? wj : alpha * wj + (1.0 - alpha) * zj;
+            const double vj = whj + yb[e0 + j];
+            ss = fma(vj, vj, ss);
           }
+          const double nrm = sqrt(ss);
+          if (nrm > ub) cscale = ub / nrm;
         }
-        const double wv = wb[e], zo = zb[e];
-        const double wh = (alpha == 1.0) ? wv : alpha * wv + (1.0 - alpha) * zo;
-        const double v = wh + yb[e];
-        const double zn = (soc && (int)row < m) ? ((cscale == 1.0) ? v : v * cscale) : fmin(fmax(v, lo), hi);
-        const double yn = v - zn;
-        zb[e] = zn; yb[e] = yn;
-        if (check) {
-          const double dr = wv - zn, ds = zn - zo;
-          a_r += dr * dr; a_s += ds * ds; a_w += wv * wv; a_z += zn * zn; a_y += yn * yn;
+        for (int row = 0; row < nb; ++row) {
+          const size_t e = e0 + row;
+          const double lo = lob[row], hi = hib[row];
+          const double wv = wb[e], zo = zb[e];
+          const double wh = (alpha == 1.0) ? wv : alpha * wv + (1.0 - alpha) * zo;
+          const double v = wh + yb[e];
+          const double zn = (soc && row < m) ? ((cscale == 1.0) ? v : v * cscale) : fmin(fmax(v, lo), hi);
+          const double yn = v - zn;
+          zb[e] = zn; yb[e] = yn;
+          if (check) {
+            const double dr = wv - zn, ds = zn - zo;
+            a_r += dr * dr; a_s += ds * ds; a_w += wv * wv; a_z += zn * zn; a_y += yn * yn;
+          }
         }
       }
       if (check) {
@@ -311,7 +320,7 @@ int oracle_solve(const admm_problem* p, const admm_options* o, int32_t stop,
         const double c = rho / rho_new;
         for (size_t e = 0; e < L * (size_t)batch; ++e) y[e] *= c;
         free(f.K); free(f.Sinv);
-        if (factorise(p, rho_new, &f)) { free(rr); free(ss); free(st); free(itv); free(AB); return 1; }
+        if (factorise(p, rho_new, &f)) { free(rr); free(ss); free(st); free(itv); free(AB); free(dscr); return 1; }
         rho = rho_new;
         ++n_updates;
       }
@@ -324,7 +333,7 @@ int oracle_solve(const admm_problem* p, const admm_options* o, int32_t stop,
   free(rr); free(ss);
   if (iters) memcpy(iters, itv, sizeof(int32_t) * batch);
   if (status) memcpy(status, st, sizeof(int32_t) * batch);
-  free(st); free(itv); free(AB); free(f.K); free(f.Sinv);
+  free(st); free(itv); free(AB); free(dscr); free(f.K); free(f.Sinv);
   return 0;
 }
 

@@ -1,0 +1,104 @@
+#!/usr/bin/env python3
+"""Timed CPU baseline of bench.py: the C/OpenMP oracle on a bounded sample of the benchmark's workload.
+
+TEST INFRASTRUCTURE (see admm_oracle.c): run only by bench.py's cpu_baseline leg, as a CHILD PROCESS, so that the
+OpenMP runtime starts with the environment chosen here (thread count, binding) whatever the parent loaded.
+
+    python oracle/cpu_baseline.py --workload cw_rendezvous --horizon 1000 --seconds 15     -> one JSON line
+
+Thread count = the CPUs this process may actually use: sched_getaffinity intersected with the cgroup CPU quota
+(cpu.max / cfs_quota_us).  omp_get_max_threads() reports the machine's core count on a box whose share is smaller; idle
+OpenMP threads then spin against the working ones (r02: 29.6 k QP-iterations/s on "128 cores", 5 % parallel efficiency).
+The sweep times {that count, half of it} and one thread, and reports the best rate with its parallel efficiency.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def usable_cpus():
+    n = len(os.sched_getaffinity(0))
+    src = "sched_getaffinity"
+    quota = None
+    try:                                         # cgroup v2
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:                                     # cgroup v1
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota is not None and quota < n:
+        n, src = max(1, int(math.floor(quota + 1e-9))), "cgroup cpu quota"
+    return n, src
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="cw_rendezvous")
+    ap.add_argument("--horizon", type=int, default=1000)
+    ap.add_argument("--seconds", type=float, default=15.0)
+    ap.add_argument("--threads", type=int, default=0, help="0 = the usable CPUs (and half of them)")
+    a = ap.parse_args()
+    cores, src = usable_cpus()
+    if a.threads > 0:
+        cores, src = a.threads, "--threads"
+    if os.environ.get("ADMM_CPU_BASELINE_CHILD") != "1":
+        # re-run ourselves with the OpenMP environment fixed BEFORE libgomp loads
+        import subprocess
+        env = dict(os.environ, ADMM_CPU_BASELINE_CHILD="1", OMP_NUM_THREADS=str(cores), OMP_PROC_BIND="close",
+                   OMP_PLACES="cores", OMP_WAIT_POLICY="active", OMP_DYNAMIC="false")
+        raise SystemExit(subprocess.run([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env).returncode)
+    sys.path[:0] = [os.path.dirname(HERE), HERE]
+    import admm_library_amd as pkg
+    import oracle_c
+
+    def make(batch):
+        if a.workload == "cw_formation":
+            return pkg.cw_formation(N=a.horizon, batch=batch)
+        return pkg.cw_rendezvous(N=a.horizon, batch=batch, **({"thrust_norm": True} if a.workload == "cw_rendezvous_soc" else {}))
+
+    def rate(threads, seconds):
+        batch = 2 * threads           # per-thread working set (w, z, y, d of 2 QPs + the shared factor) stays in the core's L2
+        p = make(batch)
+        kw = dict(rho=0.05, check_interval=1, stop=False, nthreads=threads)
+        oracle_c.solve(p, max_iter=5, **kw)                      # thread start-up, page faults
+        t0 = time.perf_counter()
+        oracle_c.solve(p, max_iter=20, **kw)
+        t_it = (time.perf_counter() - t0) / 20
+        for _ in range(3):                                       # re-aim if the calibration was off
+            iters = int(max(20, min(1000000, seconds / max(t_it, 1e-7))))
+            t0 = time.perf_counter()
+            oracle_c.solve(p, max_iter=iters, **kw)
+            dt = time.perf_counter() - t0
+            if dt >= 0.66 * seconds:
+                break
+            t_it = dt / iters
+        return {"threads": threads, "QP_iterations_per_s": batch * iters / dt, "iterations": iters, "batch": batch, "seconds": dt}
+
+    legs = sorted({cores, max(1, cores // 2)}, reverse=True)
+    one = rate(1, 0.15 * a.seconds)
+    sweep = [rate(t, 0.85 * a.seconds / len(legs)) if t > 1 else one for t in legs]
+    best = max(sweep, key=lambda r: r["QP_iterations_per_s"])
+    p = make(1)
+    print(json.dumps({
+        "value": best["QP_iterations_per_s"], "unit": "QP-iterations/s", "cores": best["threads"], "kind": "port",
+        "sample": (f"{best['iterations']} iterations of {best['batch']} QPs ({a.workload}, N={a.horizon}, n={p.n}, m={p.m}), C/OpenMP "
+                   f"oracle, residuals every iteration, {best['seconds']:.1f} s; threads bound (OMP_PROC_BIND=close), count from {src}"),
+        "usable_cpus": cores, "usable_cpus_source": src, "machine_cpus": os.cpu_count(),
+        "one_core_QP_iterations_per_s": one["QP_iterations_per_s"],
+        "parallel_efficiency": best["QP_iterations_per_s"] / (best["threads"] * one["QP_iterations_per_s"]),
+        "sweep": sweep}))
+
+
+if __name__ == "__main__":
+    main()

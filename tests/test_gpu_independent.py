@@ -1,0 +1,116 @@
+"""ORACLE-FREE checks of the HIP path at BASELINE's sizes.
+
+Every other -m gpu test compares the HIP path with the build's CPU oracle.  These compare it with routines that share
+no code with either (tests/_indep.py -- NumPy / SciPy only, written from the QP's definition):
+  (a) configs[0] solved on the GPU vs scipy.optimize.lsq_linear (BVLS) on the condensed problem;
+  (b) the QP's optimality conditions over ALL 4096 QPs of a converged GPU solve of configs[2] and of configs[4];
+  (c) one GPU x-update at N = 1000, n = 6 / n = 12, full batch, vs ONE banded LU (scipy.linalg.solve_banded) of the
+      KKT system; and four whole default-path iterations (start form, xfze, xbze: DESIGN.md §4.8) vs an ADMM loop whose
+      x-update is that banded solve.
+Nothing in this file imports oracle/.  PARITY UNPINNED regardless: these pin the HIP path to the QP, not to a
+reference implementation, because none exists."""
+import numpy as np
+import pytest
+
+import admm_library_amd as pkg
+from admm_library_amd import _abi
+import _indep as ind
+
+pytestmark = pytest.mark.gpu
+
+
+def test_config0_gpu_solve_vs_scipy_bvls(gpu):
+    """configs[0]: N = 50 double integrator, |u| <= 1 -- the GPU's converged controls equal SciPy's bounded least squares."""
+    p = pkg.double_integrator(N=50, batch=3)
+    with pkg.Solver(p, pkg.Options(rho=1.0, eps_abs=1e-10, eps_rel=1e-10, max_iter=20000, check_interval=10)) as s:
+        info = s.solve()
+        _, z, _ = s.get()
+    assert info.status.all()
+    n_active = 0
+    for b in range(p.batch):
+        u_ref = ind.condensed_bvls(p, b)
+        u_gpu = z[b].reshape(p.N, p.nb)[:, :p.m].reshape(-1)
+        assert np.abs(u_gpu - u_ref).max() < 1e-6
+        n_active += int((np.abs(np.abs(u_ref) - 1.0) < 1e-9).sum())
+    assert n_active >= 10
+
+
+FULL = {
+    "configs2_n6": (lambda: pkg.cw_rendezvous(N=1000, batch=4096), _abi.PRECISION_FP64),
+    "configs4_n12_fp64_mfma": (lambda: pkg.cw_formation(N=1000, batch=4096), _abi.PRECISION_FP64),
+    "configs4_n12_mixed": (lambda: pkg.cw_formation(N=1000, batch=4096), _abi.PRECISION_MIXED),
+}
+
+
+@pytest.mark.parametrize("case", FULL)
+def test_optimality_of_every_qp_of_a_converged_full_batch(gpu, case):
+    """All 4096 QPs of configs[2] / configs[4] (the latter on its default fp64-MFMA form and in the mixed mode with fp64
+    refinement), solved to eps = 1e-8 with the adaptive rule: every QP converged, and every QP's (z, rho y) satisfies
+    dynamics defect < 1e-6, box violation == 0, stationarity < 1e-6, complementarity < 1e-6 (variables are O(1))."""
+    make, mode = FULL[case]
+    p = make()
+    opt = pkg.Options(rho=0.05, alpha=1.6, eps_abs=1e-8, eps_rel=1e-8, max_iter=20000, check_interval=10,
+                      adapt_interval=50, precision_mode=mode)
+    with pkg.Solver(p, opt) as s:
+        info = s.solve()
+        _, z, y = s.get()
+    assert int(info.n_converged) == p.batch and info.status.all()
+    feas_dyn, feas_box, stat, comp, n_active = ind.kkt_certificate_batch(p, z, y, float(info.rho))
+    worst = dict(feas_dyn=feas_dyn.max(), feas_box=feas_box.max(), stat=stat.max(), comp=comp.max())
+    print(case, "iterations", info.iters_run, "rho", info.rho, worst, "active", n_active)
+    assert feas_box.max() == 0.0, worst
+    assert feas_dyn.max() < 1e-6 and stat.max() < 1e-6 and comp.max() < 1e-6, worst
+    assert n_active > 100 * p.batch // 10                                          # the thrust box binds throughout the batch
+
+
+XCASES = {
+    "n6": lambda: pkg.cw_rendezvous(N=1000, batch=4096),
+    "n12": lambda: pkg.cw_formation(N=1000, batch=4096),
+}
+
+
+def _state(p, seed):
+    rng = np.random.default_rng(seed)
+    return rng.standard_normal((p.batch, p.L)), 0.3 * rng.standard_normal((p.batch, p.L))
+
+
+@pytest.mark.parametrize("case", XCASES)
+def test_x_update_vs_banded_kkt_at_full_size(gpu, case):
+    """w = x-update(z, y) of the whole 4096-QP batch (segmented sweeps + MFMA scan) vs one banded LU solve with 4096 right-hand sides."""
+    p = XCASES[case]()
+    rho = 0.05
+    z0, y0 = _state(p, 11)
+    with pkg.Solver(p, pkg.Options(rho=rho)) as s:
+        assert s.geometry()["segments"] > 1
+        s.set_state(z=z0, y=y0)
+        s.step_x()
+        w, _, _ = s.get()
+    ref, backward_err = ind.banded_x_update(p, -rho * (z0 - y0), rho)
+    assert backward_err < 1e-12
+    err = np.abs(w - ref).max()
+    print(case, "x-update vs banded KKT:", err, "|w|", np.abs(ref).max())
+    assert err <= 1e-10 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("case", XCASES)
+def test_default_path_iterations_vs_banded_admm(gpu, case):
+    """Four iterations of the default path from a random (z, y) -- a start form, then the fused alternating kernels in both
+    directions (n = 6: xfze / xbze; n = 12: their MFMA forms) -- vs the textbook loop of DESIGN.md §2 with the banded
+    KKT solve as x-update.  1e-10 on w, z, y of all 4096 QPs."""
+    p = XCASES[case]()
+    rho, iters = 0.05, 4
+    z, y = _state(p, 12)
+    with pkg.Solver(p, pkg.Options(rho=rho)) as s:
+        s.set_state(z=z, y=y)
+        s.iterate(iters)
+        wg, zg, yg = s.get()
+    lo, hi = (np.tile(b, p.N) for b in (p.lo, p.hi))
+    for _ in range(iters):
+        w, _ = ind.banded_x_update(p, -rho * (z - y), rho)
+        v = w + y
+        z = np.minimum(np.maximum(v, lo), hi)
+        y = v - z
+    for name, a, r in (("w", wg, w), ("z", zg, z), ("y", yg, y)):
+        err = np.abs(a - r).max()
+        print(case, name, err)
+        assert err <= 1e-10 * max(1.0, np.abs(r).max()), (name, err)
