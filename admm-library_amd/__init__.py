@@ -11,10 +11,10 @@ built library or without a GPU the solver raises.
 from .problems import (Problem, double_integrator, cw_rendezvous, cw_formation, cw_matrices,
                        random_ltv, random_instances, cw_rendezvous_instances, mean_motion, SEED0)
 from .solver import (AdmmError, Options, Solver, admm_setup, admm_solve,
-                     library_path, load_library, device_count)
+                     library_path, load_library, device_count, last_warning)
 from .sharding import shard_bounds, shard_problem, gather_batch, global_residual_max, solve_sharded
 
-__all__ = ["Problem", "double_integrator", "cw_rendezvous", "cw_formation", "cw_matrices", "random_ltv", "random_instances", "cw_rendezvous_instances",
+__all__ = ["last_warning", "Problem", "double_integrator", "cw_rendezvous", "cw_formation", "cw_matrices", "random_ltv", "random_instances", "cw_rendezvous_instances",
            "mean_motion", "SEED0", "AdmmError", "Options", "Solver", "admm_setup",
            "admm_solve", "library_path", "load_library", "device_count",
            "shard_bounds", "shard_problem", "gather_batch", "global_residual_max", "solve_sharded"]

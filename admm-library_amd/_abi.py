@@ -12,7 +12,7 @@ import numpy as np
 
 from .problems import Problem
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 ADMM_OK = 0
 STATUS_NAMES = {0: "ADMM_OK", 1: "ADMM_ERR_INVALID", 2: "ADMM_ERR_UNSUPPORTED",
@@ -57,6 +57,16 @@ class CInfo(C.Structure):
     _fields_ = [("iters_run", C.c_int32), ("n_converged", C.c_int32),
                 ("max_r", C.c_double), ("max_s", C.c_double), ("solve_ms", C.c_double),
                 ("rho", C.c_double), ("rho_updates", C.c_int32), ("mixed_iters", C.c_int32)]
+
+
+class CPathInfo(C.Structure):
+    _fields_ = [("alternating", C.c_int32), ("alt_requested", C.c_int32), ("mfma", C.c_int32), ("xfree", C.c_int32),
+                ("segments", C.c_int32), ("auto_segments", C.c_int32), ("scan_form", C.c_int32), ("per_instance", C.c_int32),
+                ("alt_check", C.c_double), ("alt_gate", C.c_double), ("scan_growth", C.c_double)]
+
+
+SCAN_FORMS = {0: "mfma_gemm", 1: "matrix_vector", 2: "sequential_chain", 3: "per_qp"}
+KERNEL_FAMILIES = {0: "one_lane_fp64", 1: "mfma_mixed", 2: "mfma_fp64"}
 
 
 def dptr(a):

@@ -100,6 +100,7 @@ struct admm_handle {
   bool mfma_on = false;
   bool mfma_refine = false;      // MIXED, refinement phase: the fp64 MFMA kernels on recMF64 / recMB64
   bool alt_allowed = false;      // alternation permitted by the options / compiled kernels (before the precision mode)
+  bool alt_requested = false;    // ... whether or not the forward-elimination form passed its host check (admm_get_path)
   // MIXED solve: phase 1 (fp32) checks the stopping rule with raised tolerances on scratch status arrays
   bool mixed_phase1 = false;
   int mixed_iters = 0;
@@ -527,6 +528,21 @@ void set_mixed_form(admm_handle* h, bool fp32) {
   h->alt_state = admm_handle::ALT_NONE;
 }
 
+// admm_last_warning(): the forward-elimination form of a factor failed its host check, so the handle runs (or falls back
+// to) the plain fused path.  `when` names the call.
+constexpr double ALT_GATE = 5e-12;      // the bound build_alternating applies (csrc/admm_factor.cpp)
+void warn_alt_gate(const admm::Factor& f, double rho, const char* when) {
+  char buf[512];
+  if (f.alt_check >= 0.0)
+    std::snprintf(buf, sizeof buf, "%s: the forward-elimination form failed its host check at rho = %g (relative mismatch %.3g > %.1g): "
+                  "the handle runs the plain fused path (xb + xfz kernels, no alternation: ~8 B per stacked element and iteration more)",
+                  when, rho, f.alt_check, ALT_GATE);
+  else
+    std::snprintf(buf, sizeof buf, "%s: the forward-elimination form could not be built at rho = %g (a singular A_k or filter covariance): "
+                  "the handle runs the plain fused path (xb + xfz kernels, no alternation)", when, rho);
+  g_warn = buf;
+}
+
 // Conditioning guard of the parallel-in-time form (see admm_setup): largest entry of the dense scan matrices.
 constexpr double SCAN_GROWTH_MAX = 100.0;
 double scan_growth(const admm::Factor& f) {
@@ -636,7 +652,10 @@ int upload_factor(admm_handle* h) {
   int rc;
   if (h->scan_gemv && (rc = upload_scan_dense(h->fac.scanW, h->fac.scanM, h->fac.scanK, h->scanWd, h->scan_rows))) return rc;
   h->alt_state = admm_handle::ALT_NONE;
-  if (!h->fac.alt_ok) { h->alt = false; h->alt_allowed = false; }   // the forward-elimination form did not survive the refactor
+  if (!h->fac.alt_ok) {                                             // the forward-elimination form did not survive the refactor
+    if (h->alt_allowed) warn_alt_gate(h->fac, h->fac.rho, "refactor");
+    h->alt = false; h->alt_allowed = false;
+  }
   if (h->mfma_mode) {
     HIP_TRY(hipMemcpy(h->recMF, h->fac.recMF.data(), h->fac.recMF.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->recMB, h->fac.recMB.data(), h->fac.recMB.size(), hipMemcpyHostToDevice));
@@ -901,6 +920,7 @@ void admm_default_options(admm_options* o) {
 }
 
 const char* admm_last_error(void) { return g_err.c_str(); }
+const char* admm_last_warning(void) { return g_warn.c_str(); }
 int admm_abi_version(void) { return ADMM_HIP_ABI_VERSION; }
 
 int admm_device_count(void) {
@@ -994,6 +1014,7 @@ int admm_host_factor_mfma(const admm_problem* p, double rho, int32_t segments, i
 int admm_setup(admm_handle** out, const admm_problem* p, const admm_options* o_in) {
   if (!out || !p) return fail(ADMM_ERR_INVALID, "NULL argument");
   *out = nullptr;
+  g_warn.clear();
   admm_options o;
   if (o_in) o = *o_in; else admm_default_options(&o);
   int rc;
@@ -1173,6 +1194,9 @@ int admm_setup(admm_handle** out, const admm_problem* p, const admm_options* o_i
                    !(h->opt.flags & (ADMM_FLAG_SCAN_CHAIN | ADMM_FLAG_NO_ALTERNATE)) &&
                    dispatch_x(xlaunch_of(h), admm::XKernel::XFZE, false, false, /*query_only=*/true);
   h->alt = h->alt_allowed;
+  h->alt_requested = fused(h) && !(h->opt.flags & (ADMM_FLAG_SCAN_CHAIN | ADMM_FLAG_NO_ALTERNATE)) &&
+                     dispatch_x(xlaunch_of(h), admm::XKernel::XFZE, false, false, /*query_only=*/true);
+  if (h->alt_requested && !h->fac.alt_ok) warn_alt_gate(h->fac, o.rho, "admm_setup");
   h->mfma_on = h->mfma_mode != 0 && (o.precision_mode == ADMM_PRECISION_MIXED || h->alt);
   if (h->mfma_mode) {
     // (+ 1 KiB: the LDS-DMA copy of a chunk moves whole KiB pieces, admm_mfma.hpp)
@@ -1459,12 +1483,14 @@ static int set_rho_internal(admm_handle* h, double rho_new) {
 
 int admm_set_rho(admm_handle* h, double rho) {
   if (!h) return fail(ADMM_ERR_INVALID, "NULL handle");
+  g_warn.clear();
   HIP_TRY(hipSetDevice(h->device));
   return set_rho_internal(h, rho);
 }
 
 int admm_update_problem(admm_handle* h, const admm_problem* p) {
   if (!h || !p) return fail(ADMM_ERR_INVALID, "NULL argument");
+  g_warn.clear();
   HIP_TRY(hipSetDevice(h->device));
   int rc;
   if ((rc = validate_problem(p))) return rc;
@@ -1648,6 +1674,7 @@ int admm_sync(admm_handle* h) {
 }
 
 int admm_solve_begin(admm_handle* h, const double* z0, const double* y0) {
+  g_warn.clear();
   if (!h) return fail(ADMM_ERR_INVALID, "NULL handle");
   HIP_TRY(hipSetDevice(h->device));
   h->solve_t0 = std::chrono::steady_clock::now();
@@ -1783,6 +1810,8 @@ int admm_solve_adapt(admm_handle* h, double R, double S, int32_t* changed) {
   if (rho_new != h->opt.rho) {
     int rc = set_rho_internal(h, rho_new);
     if (rc == ADMM_ERR_NUMERIC) {          // refused (conditioning guard / factorisation): keep rho, stop adapting
+      g_warn = "adaptive rho: the change to rho = " + std::to_string(rho_new) + " was refused (" + g_err + "); rho stays at " +
+               std::to_string(h->opt.rho) + " and the rule stops adapting for this solve";
       h->rho_updates = h->opt.adapt_max;
       spec_start(h);
       return ADMM_OK;
@@ -2062,6 +2091,23 @@ int admm_get_geometry(admm_handle* h, int32_t* pitch, int32_t* segs, int32_t* zr
   if (segs) *segs = h->S;
   if (zrows) *zrows = h->zrows;
   if (zchunks) *zchunks = h->zchunks;
+  return ADMM_OK;
+}
+
+int admm_get_path(admm_handle* h, admm_path_info* info) {
+  if (!h || !info) return fail(ADMM_ERR_INVALID, "NULL argument");
+  std::memset(info, 0, sizeof *info);
+  info->alternating = h->alt ? 1 : 0;
+  info->alt_requested = h->alt_requested ? 1 : 0;
+  info->mfma = h->mfma_mode != 0 && (h->opt.precision_mode == ADMM_PRECISION_MIXED || h->alt) ? h->mfma_mode : 0;
+  info->xfree = h->xfree ? 1 : 0;
+  info->segments = h->S;
+  info->auto_segments = h->auto_segments ? 1 : 0;
+  info->scan_form = h->pinst ? 3 : (h->opt.flags & ADMM_FLAG_SCAN_CHAIN) ? 2 : h->scan_gemv ? 1 : 0;
+  info->per_instance = h->pinst ? 1 : 0;
+  info->alt_check = h->pinst ? -1.0 : h->fac.alt_check;
+  info->alt_gate = ALT_GATE;
+  info->scan_growth = h->pinst ? 0.0 : scan_growth(h->fac);
   return ADMM_OK;
 }
 

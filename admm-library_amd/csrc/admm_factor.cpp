@@ -338,6 +338,8 @@ void build_alternating(Factor& f, const std::vector<Mat>& A, const std::vector<M
                        const Mat& R, const Mat& QN, double rho, bool pack_scan_mfma) {
   const int N = f.N, n = f.n, m = f.m, S = f.S;
   f.alt_ok = false;
+  f.alt_check = -1.0;
+  f.rho = rho;
   f.RFE = rec_fe_size(n, m);
   f.RBE = rec_be_size(n, m);
   f.recFE.assign((size_t)N * f.RFE, 0.0);
@@ -787,7 +789,7 @@ int factorise(const admm_problem& p, double rho, int segments, Factor& f, std::s
   if (S < 1) S = 1;
   if (S > N) S = N;
 
-  f.N = N; f.n = n; f.m = m; f.S = S;
+  f.N = N; f.n = n; f.m = m; f.S = S; f.rho = rho;
   f.RB = rec_b_size(n, m); f.RF = rec_f_size(n, m); f.RS = rec_s_size(n);
   f.seg_start.resize(S + 1);
   for (int s = 0; s <= S; ++s) f.seg_start[s] = (int32_t)(((int64_t)s * N) / S);

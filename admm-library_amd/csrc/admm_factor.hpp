@@ -39,6 +39,7 @@ namespace admm {
 //   Th  [n][n]   Acl_{b-1} ... Acl_a            x_out += Th x_in
 struct Factor {
   int N = 0, n = 0, m = 0, S = 0;
+  double rho = 0.0;                 // the rho this factor was computed for
   int RB = 0, RF = 0, RS = 0;
   std::vector<int32_t> seg_start;   // S + 1 entries, seg_start[S] = N
   std::vector<double> recB;         // N * RB

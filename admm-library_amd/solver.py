@@ -62,8 +62,10 @@ _SIGNATURES = {
     "admm_get_geometry": (C.c_int, [C.c_void_p] + [c_int32_p] * 4),
     "admm_get_rho": (C.c_int, [C.c_void_p, c_double_p]),
     "admm_get_history": (C.c_int, [C.c_void_p, C.c_int32, c_int32_p, c_int32_p, c_int32_p, c_double_p, c_double_p, c_double_p]),
+    "admm_get_path": (C.c_int, [C.c_void_p, C.POINTER(_abi.CPathInfo)]),
     "admm_free": (None, [C.c_void_p]),
     "admm_last_error": (C.c_char_p, []),
+    "admm_last_warning": (C.c_char_p, []),
     "admm_abi_version": (C.c_int, []),
     "admm_device_count": (C.c_int, []),
     "admm_record_sizes": (C.c_int, [C.c_int32, C.c_int32, c_int32_p, c_int32_p, c_int32_p]),
@@ -106,6 +108,12 @@ def load_library(path: Optional[str] = None):
 def _check(lib, rc: int):
     if rc != 0:
         raise AdmmError(rc, lib.admm_last_error().decode())
+
+
+def last_warning() -> str:
+    """admm_last_warning(): what the last setup / set_rho / update_problem / solve call on this thread changed about the
+    kernels a handle runs ('' = nothing) -- e.g. the forward-elimination gate of the default path failing."""
+    return load_library().admm_last_warning().decode()
 
 
 def device_count() -> int:
@@ -163,6 +171,15 @@ class Solver:
         _check(self._lib, self._lib.admm_setup(C.byref(self._h), C.byref(cp), C.byref(co)))
         del keep
         self.batch, self.L = problem.batch, problem.L
+        self._warn()
+
+    def _warn(self):
+        """Surface admm_last_warning() (the library never changes the kernel path silently)."""
+        msg = self._lib.admm_last_warning().decode()
+        self.last_warning = msg
+        if msg:
+            import warnings
+            warnings.warn(msg, RuntimeWarning, stacklevel=3)
 
     # -- lifetime ---------------------------------------------------------
     def close(self):
@@ -204,9 +221,11 @@ class Solver:
         _check(self._lib, self._lib.admm_update_problem(self._h, C.byref(cp)))
         del keep
         self.problem = problem
+        self._warn()
 
     def set_rho(self, rho: float):
         _check(self._lib, self._lib.admm_set_rho(self._h, float(rho)))
+        self._warn()
 
     def set_state(self, w=None, z=None, y=None):
         w, z, y = self._vec(w), self._vec(z), self._vec(y)
@@ -225,6 +244,7 @@ class Solver:
         z0, y0 = self._vec(z0), self._vec(y0)
         ci = CInfo()
         _check(self._lib, self._lib.admm_solve(self._h, dptr(z0), dptr(y0), C.byref(ci)))
+        self._warn()
         return self._info(ci)
 
     # admm_solve in pieces (global stop / adaptive-rho decisions of a sharded solve)
@@ -249,6 +269,7 @@ class Solver:
     def solve_end(self) -> SolveInfo:
         ci = CInfo()
         _check(self._lib, self._lib.admm_solve_end(self._h, C.byref(ci)))
+        self._warn()
         return self._info(ci)
 
     def iterate(self, iters: int, sync: bool = True):
@@ -318,6 +339,16 @@ class Solver:
         v = [C.c_int32() for _ in range(4)]
         _check(self._lib, self._lib.admm_get_geometry(self._h, *[C.byref(x) for x in v]))
         return {"pitch": v[0].value, "segments": v[1].value, "zrows": v[2].value, "zchunks": v[3].value}
+
+    def path(self) -> dict:
+        """admm_get_path: which kernels this handle runs and the measured margin of the default path."""
+        pi = _abi.CPathInfo()
+        _check(self._lib, self._lib.admm_get_path(self._h, C.byref(pi)))
+        return {"alternating": bool(pi.alternating), "alt_requested": bool(pi.alt_requested),
+                "kernel_family": _abi.KERNEL_FAMILIES[pi.mfma], "xfree": bool(pi.xfree), "segments": pi.segments,
+                "auto_segments": bool(pi.auto_segments), "scan_form": _abi.SCAN_FORMS[pi.scan_form],
+                "per_instance": bool(pi.per_instance), "alt_check": pi.alt_check, "alt_gate": pi.alt_gate,
+                "scan_growth": pi.scan_growth}
 
 
 def admm_setup(problem: Problem, options: Optional[Options] = None) -> Solver:

@@ -71,9 +71,13 @@ def parse():
     ap.add_argument("--warm-seconds", type=float, default=0.6,
                     help="after the --warmup steps, keep iterating until at least this much wall time has been spent "
                          "warming up, so that the timed region runs at steady clocks however small --warmup is")
+    ap.add_argument("--min-timed-seconds", type=float, default=1.0,
+                    help="the timed region (all blocks of the headline leg together) spans at least this long: the number of "
+                         "blocks is raised beyond --repeats as needed, each block stays EXACTLY --steps steps")
     ap.add_argument("--profile-launches", type=int, default=200,
                     help="launches of each kernel averaged by the HIP-event per-kernel timing (admm_profile)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs4", action="store_true", help="skip the compact configs[4] side object of the default line")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
 
@@ -143,6 +147,55 @@ def cpu_baseline(N, target_s, workload="cw_rendezvous"):
     if r.returncode != 0:
         raise RuntimeError("bench.py: oracle/cpu_baseline.py failed:\n" + r.stderr[-2000:])
     return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def mfma_accounting(n_, m_, precision, pitch, stages, fwd_ms, bwd_ms, pmc_tag=None):
+    """MFMA accounting of the fused pair xfzem / xbzem (configs[4]): instructions per 16-QP tile and stage from
+    the layout (csrc/admm_mfma_layout.hpp), padding counted as waste: "useful" = the multiply-adds of the one-lane kernels'
+    operator list, "issued" = 16 x 16 x 4 per MFMA.  Beside the host count, the MEASURED matrix-pipe counters of the same
+    kernels from the newest profiles/*_mfma.csv (SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE, SQ_INSTS_VALU_MFMA_MOPS_*)."""
+    mode = 1 if precision == "mixed" else 2
+    xt = 1 if m_ > 4 else 0
+    nm = {"fwd": {"sub": 7 + xt, "elim": 2 * (7 + xt)}, "bwd": {"sub": 7 + xt, "elim": 2 * (4 + xt)}}
+    es = {"fwd": {"sub": 4 if mode == 1 else 8, "elim": 8}, "bwd": {"sub": 8, "elim": 4 if mode == 1 else 8}}
+    alg = {"fwd": {"sub": 3 * m_ * n_ + n_ * n_, "elim": 3 * m_ * n_ + m_ * m_ + 2 * n_ * n_},
+           "bwd": {"sub": 3 * m_ * n_ + n_ * n_, "elim": 3 * m_ * n_ + m_ * m_ + n_ * n_}}
+    PEAK = {4: 157.3, 8: 78.6}                    # dense TFLOP/s: v_mfma_f32_16x16x4_f32 / v_mfma_f64_16x16x4_f64 (MI355X_MICROARCH.md)
+    CYC = {4: 32, 8: 64}                          # issue cycles per MFMA and SIMD
+    tiles, qps = pitch // 16, pitch
+    nt = "1" if pitch <= 128 else "2"
+    ids = {"xfzem": ("xfzem_kernel", [str(n_), str(m_), nt, "float" if mode == 1 else "double", "double", "true", "false", "true"]),
+           "xbzem": ("xbzem_kernel", [str(n_), str(m_), nt, "double", "float" if mode == 1 else "double", "true", "false", "true"])}
+    per = {}
+    for kname, d, ms in (("xfzem", "fwd", fwd_ms), ("xbzem", "bwd", bwd_ms)):
+        useful = sum(2.0 * alg[d][p] for p in ("sub", "elim")) * qps * stages
+        issued = sum(nm[d][p] for p in ("sub", "elim")) * 2048.0 * tiles * stages
+        t_peak = sum(2.0 * alg[d][p] * qps * stages / (PEAK[es[d][p]] * 1e12) for p in ("sub", "elim"))
+        pipe_cyc = sum(nm[d][p] * CYC[es[d][p]] for p in ("sub", "elim")) * tiles * stages
+        per[kname] = {"avg_launch_ms": ms, "mfma_per_tile_stage": nm[d], "element_bytes": es[d],
+                      "useful_flop": useful, "issued_flop": issued, "useful_over_issued": useful / issued,
+                      "useful_TFLOPs": useful / (ms * 1e-3) / 1e12, "issued_TFLOPs": issued / (ms * 1e-3) / 1e12,
+                      "peak_TFLOPs_for_this_mix": useful / t_peak / 1e12,
+                      "matrix_pipe_busy_at_2p4GHz": pipe_cyc / (1024 * 2.4e9 * ms * 1e-3),
+                      "measured_counters": None if pmc_tag is None else pmc_mfma(ids[kname][0], ids[kname][1], pmc_tag)}
+    tot_ms = fwd_ms + bwd_ms
+    useful = per["xfzem"]["useful_flop"] + per["xbzem"]["useful_flop"]
+    t_peak = sum(per[k]["useful_flop"] / (per[k]["peak_TFLOPs_for_this_mix"] * 1e12) for k in per)
+    ach = useful / (tot_ms * 1e-3) / 1e12
+    meas = [per[k]["measured_counters"] for k in per]
+    return {"kernel": f"xfzem_kernel / xbzem_kernel <{n_},{m_}> ({precision}): the alternating pair with the stage "
+                      "operators as v_mfma_*_16x16x4 chains over 16-QP panels",
+            "bound": "mfma", "achieved": ach, "peak": useful / t_peak / 1e12, "unit": "TFLOP/s",
+            "frac": ach / (useful / t_peak / 1e12), "traffic": None,
+            "mfma_util_measured": (None if any(x is None for x in meas) else
+                                   sum(x["MfmaUtil_pct"] * x["launches"] for x in meas) / sum(x["launches"] for x in meas) / 100.0),
+            "note": ("achieved = USEFUL flops (the one-lane kernels' operator list, padding and folded blocks "
+                     "counted as waste) / measured kernel time; peak = dense MFMA peak of the element types, weighted "
+                     "by each product's useful flops.  The kernels are HBM-bound (roofline_hbm): the matrix pipe is "
+                     "busy for the fraction per_kernel.*.matrix_pipe_busy_at_2p4GHz of the launch by the host's count of issued "
+                     "MFMAs x their issue cycles at an ASSUMED 2.4 GHz, and for mfma_util_measured = SQ_VALU_MFMA_BUSY_CYCLES / "
+                     "(GRBM_GUI_ACTIVE x SIMDs) by the hardware counters of the stored rocprofv3 pass (per_kernel.*.measured_counters)."),
+            "per_kernel": per}
 
 
 def launch_ranks(a):
@@ -237,14 +290,15 @@ def main():
     if not os.path.exists(pkg.library_path()):
         ge.build()
     pkg.load_library()
-    if pkg.device_count() < 1:
-        raise SystemExit("bench.py: no HIP device visible; the solver has no CPU fallback")
 
-    # The CPU baseline runs FIRST (rank 0, N = 1 only): ~15 s of host work between the GPU legs would leave the
-    # GPU at idle clocks for whatever is timed next (r01: the driver's 3.3 ms timed region ran on a 0.8 %-busy GPU).
+    # The CPU baseline runs FIRST (rank 0, N = 1 only), as a child process started before this process makes any HIP call:
+    # ~15 s of host work between the GPU legs would leave the GPU at idle clocks for whatever is timed next (r01: the
+    # driver's 3.3 ms timed region ran on a 0.8 %-busy GPU).
     cpu_base = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu_base = cpu_baseline(a.horizon, a.cpu_seconds, a.workload)
+    if pkg.device_count() < 1:
+        raise SystemExit("bench.py: no HIP device visible; the solver has no CPU fallback")
 
     # One process per GPU.  ADMM_BENCH_BACKEND=gloo (+ several ranks sharing one GPU) exists only to
     # rehearse the N > 1 code path on a 1-GPU box; the driver's runs use RCCL ("nccl").
@@ -292,6 +346,7 @@ def main():
                       precision_mode=PM[a.precision], flags=PFLAGS[a.precision])
     solver = pkg.Solver(full, opt)
     geo = solver.geometry()
+    path = solver.path()            # which kernels the handle runs + the margin of the default path (admm_get_path, ABI v6)
 
     def warm(sv, seconds, every=1):
         """steady clocks: iterate until `seconds` of wall time have gone by (the state simply keeps converging)"""
@@ -299,11 +354,12 @@ def main():
         while time.perf_counter() < t_end:
             sv.run(200, residual_every=every, sync=True)
 
-    def timed_blocks(sv, every):
-        """`repeats` blocks of EXACTLY --steps steps, each bracketed by barrier + synchronize on both sides and
-        reduced with MAX over the ranks; returns the per-block seconds."""
+    def timed_blocks(sv, every, min_seconds=0.0):
+        """Blocks of EXACTLY --steps steps, each bracketed by barrier + synchronize on both sides and reduced with MAX over
+        the ranks: at least --repeats of them, and as many more as it takes for the blocks to add up to `min_seconds` (decided
+        from the MAX-reduced times, so every rank runs the same number).  Returns the per-block seconds."""
         out = []
-        for _ in range(a.repeats):
+        while len(out) < a.repeats or (sum(out) < min_seconds and len(out) < 100000):
             barrier()
             t0 = time.perf_counter()
             sv.run(a.steps, residual_every=every, sync=True)
@@ -313,7 +369,9 @@ def main():
 
     solver.run(a.warmup, residual_every=1)          # the W untimed warmup steps ...
     warm(solver, a.warm_seconds)                    # ... and then by time, whatever W was
-    blocks = timed_blocks(solver, 1)
+    t_region = time.perf_counter()
+    blocks = timed_blocks(solver, 1, a.min_timed_seconds)
+    t_region = time.perf_counter() - t_region
     dt = float(np.median(blocks))
 
     ms_per_step = dt / a.steps * 1e3
@@ -336,9 +394,7 @@ def main():
     L = full.L
     elems = L * geo["pitch"]
     n_, m_ = full.n, full.m
-    # whether the timed handle runs the MFMA form (include/admm_hip.h: ADMM_FLAG_NO_MFMA)
-    uses_mfma = a.precision in ("mixed", "fp64_mfma") or (a.precision == "fp64" and (n_ >= 9 or geo["pitch"] <= 128)
-                                                           and (n_, m_) in ((12, 6), (6, 3), (10, 4)) and full.q is None and full.unorm is None)
+    uses_mfma = path["kernel_family"] != "one_lane_fp64"      # reported by the library, not re-derived here
     b_xfz = 8.0 * m_ / (n_ + m_) + 16.0          # d read + v read + v+ written
     xfz_ms = prof["xfz_ms"]
     # the stored PMC runs (profiles/r<NN><x>[_formation_mixed]_hbm_traffic.csv) are of these two workloads only
@@ -393,44 +449,10 @@ def main():
             roofline["traffic_source"] = rf["traffic_source"] + "; mean of the two kernels"
     else:
         roofline = roofline_xfz
-    # MFMA accounting of the timed kernels (configs[4]): instructions per 16-QP tile and stage from the
-    # layout (csrc/admm_mfma_layout.hpp), padding counted as waste: "useful" = the multiply-adds of the one-lane kernels'
-    # operator list, "issued" = 16 x 16 x 4 per MFMA.
     roofline_mfma = None
     if uses_mfma and prof_alt is not None:
-        mode = 1 if a.precision == "mixed" else 2
-        xt = 1 if m_ > 4 else 0
-        nm = {"fwd": {"sub": 7 + xt, "elim": 2 * (7 + xt)}, "bwd": {"sub": 7 + xt, "elim": 2 * (4 + xt)}}
-        es = {"fwd": {"sub": 4 if mode == 1 else 8, "elim": 8}, "bwd": {"sub": 8, "elim": 4 if mode == 1 else 8}}
-        alg = {"fwd": {"sub": 3 * m_ * n_ + n_ * n_, "elim": 3 * m_ * n_ + m_ * m_ + 2 * n_ * n_},
-               "bwd": {"sub": 3 * m_ * n_ + n_ * n_, "elim": 3 * m_ * n_ + m_ * m_ + n_ * n_}}
-        PEAK = {4: 157.3, 8: 78.6}                    # dense TFLOP/s: v_mfma_f32_16x16x4_f32 / v_mfma_f64_16x16x4_f64 (MI355X_MICROARCH.md)
-        CYC = {4: 32, 8: 64}                          # issue cycles per MFMA and SIMD
-        tiles, stages, qps = geo["pitch"] // 16, full.N, geo["pitch"]
-        per = {}
-        for kname, d, ms in (("xfzem", "fwd", prof_alt["xfze_ms"]), ("xbzem", "bwd", prof_alt["xbze_ms"])):
-            useful = sum(2.0 * alg[d][p] for p in ("sub", "elim")) * qps * stages
-            issued = sum(nm[d][p] for p in ("sub", "elim")) * 2048.0 * tiles * stages
-            t_peak = sum(2.0 * alg[d][p] * qps * stages / (PEAK[es[d][p]] * 1e12) for p in ("sub", "elim"))
-            pipe_cyc = sum(nm[d][p] * CYC[es[d][p]] for p in ("sub", "elim")) * tiles * stages
-            per[kname] = {"avg_launch_ms": ms, "mfma_per_tile_stage": nm[d], "element_bytes": es[d],
-                          "useful_flop": useful, "issued_flop": issued, "useful_over_issued": useful / issued,
-                          "useful_TFLOPs": useful / (ms * 1e-3) / 1e12, "issued_TFLOPs": issued / (ms * 1e-3) / 1e12,
-                          "peak_TFLOPs_for_this_mix": useful / t_peak / 1e12,
-                          "matrix_pipe_busy_at_2p4GHz": pipe_cyc / (1024 * 2.4e9 * ms * 1e-3)}
-        tot_ms = prof_alt["xfze_ms"] + prof_alt["xbze_ms"]
-        useful = per["xfzem"]["useful_flop"] + per["xbzem"]["useful_flop"]
-        t_peak = sum(per[k]["useful_flop"] / (per[k]["peak_TFLOPs_for_this_mix"] * 1e12) for k in per)
-        ach = useful / (tot_ms * 1e-3) / 1e12
-        roofline_mfma = {"kernel": f"xfzem_kernel / xbzem_kernel <{n_},{m_}> ({a.precision}): the alternating pair with the stage "
-                                   "operators as v_mfma_*_16x16x4 chains over 16-QP panels",
-                         "bound": "mfma", "achieved": ach, "peak": useful / t_peak / 1e12, "unit": "TFLOP/s",
-                         "frac": ach / (useful / t_peak / 1e12), "traffic": None,
-                         "note": ("achieved = USEFUL flops (the one-lane kernels' operator list, padding and folded blocks "
-                                  "counted as waste) / measured kernel time; peak = dense MFMA peak of the element types, weighted "
-                                  "by each product's useful flops.  The kernels are HBM-bound (roofline_hbm): the matrix pipe is "
-                                  "busy for the fraction per_kernel.*.matrix_pipe_busy_at_2p4GHz of the launch."),
-                         "per_kernel": per}
+        roofline_mfma = mfma_accounting(n_, m_, "mixed" if path["kernel_family"] == "mfma_mixed" else "fp64_mfma", geo["pitch"], full.N,
+                                        prof_alt["xfze_ms"], prof_alt["xbze_ms"], pmc_tag)
     zs_ms = prof_unf["zdual_ms"]
     zs = BYTES_PER_ELEM_ZDUAL * elems / (zs_ms * 1e-3) / 1e9
     standalone = {"kernel": "zdual_kernel<RESID=true> (standalone fused z-update + dual + residual, ADMM_FLAG_UNFUSED path)",
@@ -463,7 +485,7 @@ def main():
     b_iter_nostore = (32.0 * m_ / (n_ + m_) + (8.0 if full.q is not None else 0.0)) if xfree else b_iter
     # mixed mode a solver would normally run: residuals every 10th iteration
     warm(solver, 0.25 * a.warm_seconds, every=10)
-    dt10 = float(np.median(timed_blocks(solver, 10)))
+    dt10 = float(np.median(timed_blocks(solver, 10, 0.5 * a.min_timed_seconds)))
 
     # configs[4]: the three precision modes side by side on this workload (rate with residuals every iteration)
     precision_modes = None
@@ -479,6 +501,42 @@ def main():
             except pkg.AdmmError as e:
                 precision_modes[name] = {"error": str(e)}
 
+    # configs[4] beside the headline, so that its numbers are driver-observed (VERDICT r02 next #2e): the n = 12, m = 6 formation
+    # workload at the same batch and horizon, fp64-MFMA (exact) and mixed, ~1.5 s each: rate with residuals every iteration, HBM
+    # roofline of the fused pair (21.33 B/element), host-counted and measured matrix-pipe utilisation.
+    configs4 = None
+    if a.workload == "cw_rendezvous" and rank == 0 and world == 1 and not a.no_configs4:
+        configs4 = {"workload": f"configs[4]: batch of {a.batch} N={a.horizon} n=12 m=6 Clohessy-Wiltshire formation QPs, x-update as "
+                                "MFMA batched GEMM, residuals every iteration"}
+        form = pkg.cw_formation(N=a.horizon, batch=a.batch)
+        for name in ("fp64_mfma", "mixed"):
+            with pkg.Solver(form, pkg.Options(rho=0.05, check_interval=1, device=dev_index, precision_mode=PM[name])) as sp:
+                g4, p4 = sp.geometry(), sp.path()
+                warm(sp, 0.3)
+                b4 = timed_blocks(sp, 1, 0.3)
+                b4_10 = timed_blocks(sp, 10, 0.2)
+                pr = sp.profile(min(npf, 50), residuals=True, alternating=True)
+            d4 = float(np.median(b4))
+            e4 = form.L * g4["pitch"]
+            pair_ms = pr["xfze_ms"] + pr["xbze_ms"]
+            hbm = 2 * (16.0 + 16.0 * 6 / 18) * e4 / (pair_ms * 1e-3) / 1e9
+            acc = mfma_accounting(12, 6, name, g4["pitch"], form.N, pr["xfze_ms"], pr["xbze_ms"],
+                                  "formation_mixed" if (name, a.batch, a.horizon) == ("mixed", 4096, 1000) else None)
+            configs4[name] = {"batch_iterations_per_s": a.steps / d4, "ms_per_step": d4 / a.steps * 1e3, "timed_blocks": len(b4),
+                              "batch_iterations_per_s_check_interval_10": a.steps / float(np.median(b4_10)),
+                              "kernel_family": p4["kernel_family"], "alternating": p4["alternating"], "alt_check": p4["alt_check"],
+                              "segments": g4["segments"],
+                              "xfzem_ms": pr["xfze_ms"], "xbzem_ms": pr["xbze_ms"], "xscan_ms": pr["xscan_ms"],
+                              "hbm": {"achieved": hbm, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm / HBM_PEAK_GBS,
+                                      "bytes_per_element": 16.0 + 16.0 * 6 / 18},
+                              "mfma": {"useful_TFLOPs": acc["achieved"], "peak_TFLOPs_for_this_mix": acc["peak"], "frac": acc["frac"],
+                                       "useful_over_issued": {k: v["useful_over_issued"] for k, v in acc["per_kernel"].items()},
+                                       "matrix_pipe_busy_at_2p4GHz": {k: v["matrix_pipe_busy_at_2p4GHz"] for k, v in acc["per_kernel"].items()},
+                                       "mfma_util_measured": acc["mfma_util_measured"],
+                                       "measured_counters_source": next((v["measured_counters"]["source"] for v in acc["per_kernel"].values()
+                                                                         if v["measured_counters"]), None)}}
+        del form
+
     # iterations-to-epsilon (second half of BASELINE.json's metric; "vs MATLAB" -> vs the CPU oracle):
     # a full admm_solve of this rank's shard to eps_abs = eps_rel = 1e-6, stop test every 10 iterations,
     # once with fixed rho and once with the batch-level adaptive rule.
@@ -486,6 +544,8 @@ def main():
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import oracle_c
+        from cpu_baseline import usable_cpus
+        oracle_threads = usable_cpus()[0]      # never more OpenMP threads than this box's CPU share
     else:
         oracle_c = None
 
@@ -513,7 +573,7 @@ def main():
         if oracle_c is not None and adapt.get("precision_mode", 0) == 0 and "flags" not in adapt:
             ns = min(64, full.batch)     # the rule is batch-level, so the sample is solved as its own batch on both sides
             sub = full.slice(0, ns)
-            ref = oracle_c.solve(sub, **base, **adapt)
+            ref = oracle_c.solve(sub, nthreads=min(oracle_threads, ns), **base, **adapt)
             with pkg.Solver(sub, pkg.Options(device=dev_index, **base, **adapt)) as sv:
                 gi = sv.solve()
             out["oracle_sample"] = {"qps": ns, "per_qp_iters_equal": int((ref["iters"] == gi.iters).sum()),
@@ -537,9 +597,12 @@ def main():
             "value": value, "unit": "QP-iterations/s",
             "batch_iterations_per_s": a.steps / dt,
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
-            "repeats": a.repeats, "ms_per_step_blocks": [b / a.steps * 1e3 for b in blocks],
-            "timing": (f"median of {a.repeats} blocks of exactly {a.steps} steps, each bracketed by barrier + "
-                       f"synchronize and reduced with MAX over ranks; warm-up = {a.warmup} steps + {a.warm_seconds} s"),
+            "repeats": len(blocks), "timed_region_s": t_region, "timed_steps_total": len(blocks) * a.steps,
+            "ms_per_step_blocks": {"min": min(blocks) / a.steps * 1e3, "median": dt / a.steps * 1e3, "max": max(blocks) / a.steps * 1e3,
+                                   "first": [b / a.steps * 1e3 for b in blocks[:5]]},
+            "timing": (f"median of {len(blocks)} blocks of exactly {a.steps} steps (>= {a.repeats}, as many as it takes to time "
+                       f">= {a.min_timed_seconds} s), each bracketed by barrier + synchronize and reduced with MAX over ranks; "
+                       f"warm-up = {a.warmup} steps + {a.warm_seconds} s"),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64" if a.precision != "mixed" else "f64 state + f32/f64 x-update (mixed)", "data": "synthetic",
             "config": {"workload": (f"configs[2]: batch of {a.batch} independent N={a.horizon} n=6 m=3 "
@@ -551,10 +614,11 @@ def main():
                         f"Clohessy-Wiltshire QPs per GPU, residuals every iteration"),
                        "N": a.horizon, "n": n_, "m": m_, "batch_per_gpu": a.batch, "global_batch": gbatch,
                        "rho": 0.05, "sharding": f"batch/{world}, no collective in the iteration",
-                       **geo},
+                       **geo, "path": path},
             "roofline": roofline if roofline_mfma is None else roofline_mfma,
             "roofline_hbm": None if roofline_mfma is None else roofline,
             "precision": a.precision,
+            "configs4": configs4,
             "precision_modes": precision_modes,
             "iters_to_eps_precision_modes": iters_to_eps_modes,
             "roofline_zdual_standalone": standalone,

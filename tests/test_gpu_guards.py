@@ -104,3 +104,68 @@ def test_per_instance_segments_keep_the_conditioning_bound(gpu):
     assert np.abs(z - ref["z"]).max() <= 1e-10 and np.abs(w - ref["w"]).max() <= 1e-10
     with pkg.Solver(p, pkg.Options(rho=0.1, segments=4)) as s:
         s.set_rho(1e-4)
+
+
+# ---- the kernel path and its margin are reported, never silent (ABI v6: admm_get_path, admm_last_warning)
+
+def test_path_of_the_headline_handle(gpu):
+    p = pkg.cw_rendezvous(N=1000, batch=256)
+    import warnings
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        s = pkg.Solver(p, pkg.Options(rho=0.05))
+    with s:
+        path = s.path()
+    assert not [w for w in rec if issubclass(w.category, RuntimeWarning)] and s.last_warning == ""
+    assert path["alternating"] and path["alt_requested"] and path["kernel_family"] == "one_lane_fp64" and path["xfree"]
+    assert path["scan_form"] == "mfma_gemm" and path["segments"] == s.geometry()["segments"] and path["auto_segments"]
+    assert 0.0 <= path["alt_check"] <= path["alt_gate"] == 5e-12          # the measured margin of the forward-elimination form
+    assert 0.0 < path["scan_growth"] <= 100.0
+
+
+@pytest.mark.parametrize("make,rho,segments", [
+    (lambda: pkg.cw_rendezvous(N=1000, batch=8), 32.0, 0),                      # CW at N = 1000 with rho = 32
+    (lambda: pkg.random_ltv(N=40, n=6, m=1, batch=2, seed=5), 0.05, 4),         # a random n = 6, m = 1 system at rho = 0.05
+], ids=["cw_rho32", "random_n6_m1"])
+def test_forward_elimination_gate_failure_is_reported(gpu, make, rho, segments):
+    """The two known problems whose forward-elimination form misses its host check: the handle runs the plain fused path,
+    SAYS so (warning + admm_get_path), and its iterates are the oracle's."""
+    p = make()
+    with pytest.warns(RuntimeWarning, match="forward-elimination form failed its host check"):
+        s = pkg.Solver(p, pkg.Options(rho=rho, segments=segments))
+    with s:
+        path = s.path()
+        assert path["alt_requested"] and not path["alternating"]
+        assert path["alt_check"] > path["alt_gate"]
+        assert "plain fused path" in s.last_warning and "plain fused path" in pkg.last_warning()
+        with pytest.raises(pkg.AdmmError):                       # admm_profile of the alternating pair: unsupported on this handle
+            s.profile(2, alternating=True)
+        s.iterate(12)
+        w, z, y = s.get()
+    ref = oc.solve(p, rho=rho, max_iter=12, stop=False)
+    for a, k in ((w, "w"), (z, "z"), (y, "y")):
+        assert np.abs(a - ref[k]).max() <= 1e-10 * max(1.0, np.abs(ref[k]).max())
+
+
+def test_losing_the_alternating_form_on_a_rho_change_is_reported(gpu):
+    """admm_set_rho to a rho whose forward form fails: the call succeeds, the handle falls back, the warning says so; a later
+    setup at a good rho reports nothing."""
+    p = pkg.cw_rendezvous(N=1000, batch=8)
+    with pkg.Solver(p, pkg.Options(rho=0.05, segments=16)) as s:
+        assert s.path()["alternating"] and s.last_warning == ""
+        s.iterate(4)
+        with pytest.warns(RuntimeWarning, match="refactor: the forward-elimination form failed"):
+            s.set_rho(32.0)
+        assert not s.path()["alternating"] and s.path()["alt_check"] > 5e-12
+        s.iterate(4)
+        w, z, y = s.get()
+    ref = oc.solve(p, rho=0.05, max_iter=4, stop=False)
+    ref2 = oc.solve(p, rho=32.0, max_iter=4, stop=False, z0=ref["z"], y0=ref["y"] * (0.05 / 32.0))
+    assert np.abs(z - ref2["z"]).max() <= 1e-10 and np.abs(w - ref2["w"]).max() <= 1e-10
+
+
+def test_flags_that_exclude_alternation_are_not_warnings(gpu):
+    p = pkg.cw_rendezvous(N=100, batch=8)
+    with pkg.Solver(p, pkg.Options(rho=0.05, flags=_abi.FLAG_NO_ALTERNATE)) as s:
+        path = s.path()
+        assert not path["alt_requested"] and not path["alternating"] and s.last_warning == ""
