@@ -182,6 +182,73 @@ __device__ __forceinline__ void lds_matvec_acc(const double* blk, const double (
   }
 }
 
+// ---------------------------------------------------------------------------
+// Stage operators DISTRIBUTED over the lanes of a row, applied with DPP (round 3; DESIGN.md §4.5 "operand delivery").
+//
+// lds_matvec_acc above delivers every wave-uniform operator entry to all 64 lanes: one ds_read_b128 writes 1 KiB of
+// registers for two FMAs, and the LDS return path (measured: >= 6.8 cycles per broadcast b128 and CU with four waves,
+// tools/micro/lds_bcast.hip) -- 120 such reads per stage and wave at n = 6, m = 3 -- is what the fused kernels wait for
+// once their HBM bytes are cut (XFREE forms).  gfx90a+ has ONE data-parallel-primitive control for fp64:
+//     v_fmac_f64_dpp  acc, op, x  row_newbcast:k      acc += op[lane k of this lane's 16-lane row] * x
+// at the full fp64 FMA rate (tools/micro/dpp_fma_rate.hip: 2.35 vs 2.38 ns).  So lane l keeps record entry 16 i + (l & 15)
+// in register i -- ONE ds_read_b64 per 16 entries and wave (the four rows read the same words: LDS broadcast within a bank)
+// -- and every FMA names its entry by (register, k).  The record of a stage at (6, 3) is 15 registers instead of 120
+// 16-byte reads; products and their order are those of lds_matvec_acc (bit-identical results).
+// Only v_fmac_f64 and v_mov_b64 take the control, so the box (v_min / v_max operands) stays on the broadcast path.
+// ---------------------------------------------------------------------------
+#ifndef ADMM_NO_DPP_OPERANDS
+#define ADMM_DPP_OPERANDS 1
+#else
+#define ADMM_DPP_OPERANDS 0
+#endif
+
+template <int K, bool NEG>
+__device__ __forceinline__ void fmac_row_bcast(double& acc, double op, double x) {
+  static_assert(K >= 0 && K < 16, "row_newbcast lane");
+  // (not volatile: a pure register-to-register operation the scheduler may move like any FMA; the LDS wait for `op` is
+  //  inserted by the compiler, which tracks the registers of inline-asm operands)
+  if (NEG) asm("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(op), "v"(x), "n"(K));
+  else     asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(op), "v"(x), "n"(K));
+}
+
+// Registers [R0, R1) of a stage record: v[i] = rec[16 i + (lane & 15)].  `rec_l16` = the stage's LDS address + (lane & 15).
+template <int R0, int R1, int NREG>
+__device__ __forceinline__ void dpp_rec_load(const double* rec_l16, double (&v)[NREG]) {
+  static_assert(R0 >= 0 && R1 <= NREG, "register range");
+#pragma unroll
+  for (int i = R0; i < R1; ++i) v[i] = rec_l16[16 * i];
+}
+
+// The registers that hold the SIZE entries of one operator at record offset OFF.  Kernels issue these one or two operators
+// AHEAD of the operator's FMAs (software pipeline over the operator list of a stage): at most three operators' registers are
+// live at a time -- 6-8 registers at (6, 3), ~20 at (12, 6), where the whole record would be 57 -- and the LDS latency
+// (~105 cycles) hides under the FMAs of the operators in between.  A register shared by two neighbouring operators is simply
+// read twice (same stage, same value).
+template <int OFF, int SIZE, int NREG>
+__device__ __forceinline__ void dpp_op_load(const double* rec_l16, double (&v)[NREG]) {
+  dpp_rec_load<OFF / 16, (OFF + SIZE - 1) / 16 + 1, NREG>(rec_l16, v);
+}
+
+namespace detail {
+template <int ROWS, int COLS, bool NEG, int OFF, int E, int NREG>
+__device__ __forceinline__ void dpp_mv_step(const double (&v)[NREG], const double (&x)[COLS], double (&acc)[ROWS]) {
+  if constexpr (E < ROWS * COLS) {
+    // column-major over the matrix: consecutive FMAs go to different accumulators (independent chains), while each
+    // accumulator still receives its products in column order -- the order of a plain row loop and of lds_matvec_acc
+    constexpr int c = E / ROWS, r = E % ROWS, flat = OFF + r * COLS + c;
+    static_assert(flat / 16 < NREG, "operator entry beyond the loaded registers");
+    fmac_row_bcast<flat % 16, NEG>(acc[r], v[flat / 16], x[c]);
+    dpp_mv_step<ROWS, COLS, NEG, OFF, E + 1, NREG>(v, x, acc);
+  }
+}
+}  // namespace detail
+
+// acc[r] (+|-)= sum_c M[r][c] x[c] with M (ROWS x COLS, row-major) at record offset OFF of the distributed record v.
+template <int ROWS, int COLS, bool NEG, int OFF, int NREG>
+__device__ __forceinline__ void dpp_matvec_acc(const double (&v)[NREG], const double (&x)[COLS], double (&acc)[ROWS]) {
+  detail::dpp_mv_step<ROWS, COLS, NEG, OFF, 0, NREG>(v, x, acc);
+}
+
 // Thrust-magnitude (second-order-cone) projection factor of one block: the control
 // rows u of a stage with a finite bound ub are scaled onto the ball ||u||_2 <= ub,
 //     c = ||u|| > ub ? ub / ||u|| : 1,      z_u = c u.
@@ -232,7 +299,20 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_X_OCCUPANCY void xb_kernel(
   constexpr int RB = LB.SIZE;
   constexpr int PF = prefetch_depth(NB);
   constexpr int CH = stage_chunk(RB, PF);        // stages whose records are staged in LDS at once
-  __shared__ __attribute__((aligned(16))) double rec[CH * RB];
+  __shared__ __attribute__((aligned(16))) double rec[CH * RB + 16];
+  // operators distributed over the lanes of a row and read two operators ahead of their FMAs (dpp_matvec_acc above):
+  // BT, SI, AT, KT, OM, then BT, SI of the next (= previous in time) stage
+  constexpr int NREG = (LB.LO + 15) / 16;
+  double ops[NREG];
+  const double* rec16 = rec + (threadIdx.x & 15);
+#if ADMM_DPP_OPERANDS
+#define ADMM_MV(R_, C_, NEG_, BLK_, X_, ACC_) dpp_matvec_acc<R_, C_, NEG_, LB.BLK_, NREG>(ops, X_, ACC_)
+#define ADMM_LD(R_, C_, BLK_, PTR_) dpp_op_load<LB.BLK_, (R_) * (C_), NREG>(PTR_, ops)
+#else
+#define ADMM_MV(R_, C_, NEG_, BLK_, X_, ACC_) lds_matvec_acc<R_, C_, NEG_>(rb + LB.BLK_, X_, ACC_)
+#define ADMM_LD(R_, C_, BLK_, PTR_) (void)(PTR_)
+  (void)rec16; (void)ops;
+#endif
 
   // No early return (every wave must reach the barriers) and no store branches: lanes past the
   // pitch are clamped onto the last column for their LOADS (so they compute finite values) and
@@ -289,6 +369,9 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_X_OCCUPANCY void xb_kernel(
         const int k = kb - j;
         if (k < klo) break;
         const double* rb = rec + (k - klo) * RB;     // wave-uniform address: LDS broadcast reads
+        const double* rb16 = rec16 + (k - klo) * RB;
+        ADMM_LD(NU, NX, BT, rb16);                   // (the z-update below covers their latency)
+        ADMM_LD(NU, NU, SI, rb16);
         double mLO[even_up(NB)], mHI[even_up(NB)];
         double cs = 1.0;
         if (VFORM) {
@@ -332,10 +415,12 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_X_OCCUPANCY void xb_kernel(
 #pragma unroll
         for (int jj = 0; jj < NU; ++jj) h[jj] = g[jj];
         __builtin_amdgcn_sched_barrier(0);                        // region boundary (see xfz_kernel)
-        lds_matvec_acc<NU, NX, false>(rb + LB.BT, p, h);          // h = g^u + B' p
+        ADMM_LD(NX, NX, AT, rb16);
+        ADMM_MV(NU, NX, false, BT, p, h);          // h = g^u + B' p
 #pragma unroll
         for (int jj = 0; jj < NU; ++jj) d[jj] = 0.0;
-        lds_matvec_acc<NU, NU, false>(rb + LB.SI, h, d);          // d = Si h
+        ADMM_LD(NX, NU, KT, rb16);
+        ADMM_MV(NU, NU, false, SI, h, d);          // d = Si h
         if (st) {
           const unsigned d0 = (unsigned)(k - k0) * NU * PB;
 #pragma unroll
@@ -344,9 +429,10 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_X_OCCUPANCY void xb_kernel(
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < NX; ++i) t[i] = 0.0;
-        lds_matvec_acc<NX, NX, false>(rb + LB.AT, p, t);          // t = A' p
-        lds_matvec_acc<NX, NU, true>(rb + LB.KT, h, t);           //       - K' h
-        lds_matvec_acc<NX, NU, false>(rb + LB.OM, d, e);          // e += Omega d
+        ADMM_LD(NX, NU, OM, rb16);
+        ADMM_MV(NX, NX, false, AT, p, t);          // t = A' p
+        ADMM_MV(NX, NU, true, KT, h, t);           //       - K' h
+        ADMM_MV(NX, NU, false, OM, d, e);          // e += Omega d
         // keep the unrolled stages apart: without this the scheduler hoists the next stage's
         // LDS matrix reads across the boundary and the register file overflows into AGPR moves
         __builtin_amdgcn_sched_barrier(0);
@@ -362,6 +448,9 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_X_OCCUPANCY void xb_kernel(
     }
   }
 }
+
+#undef ADMM_MV
+#undef ADMM_LD
 
 // ---------------------------------------------------------------------------
 // Segment scan.  One lane = one QP, all segments, sequential in S (S is small):
@@ -765,7 +854,19 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_X_OCCUPANCY void xf_kernel(
   constexpr int RF = LF.SIZE;
   constexpr int PF = prefetch_depth(NB);
   constexpr int CH = stage_chunk(RF, PF);
-  __shared__ __attribute__((aligned(16))) double rec[CH * RF];
+  __shared__ __attribute__((aligned(16))) double rec[CH * RF + 16];
+  // operators distributed over the lanes of a row, read ahead of their FMAs (dpp_matvec_acc above): PSI, K, A, B
+  constexpr int NREG = (LF.LO + 15) / 16;
+  double ops[NREG];
+  const double* rec16 = rec + (threadIdx.x & 15);
+#if ADMM_DPP_OPERANDS
+#define ADMM_MV(R_, C_, NEG_, BLK_, X_, ACC_) dpp_matvec_acc<R_, C_, NEG_, LF.BLK_, NREG>(ops, X_, ACC_)
+#define ADMM_LD(R_, C_, BLK_, PTR_) dpp_op_load<LF.BLK_, (R_) * (C_), NREG>(PTR_, ops)
+#else
+#define ADMM_MV(R_, C_, NEG_, BLK_, X_, ACC_) lds_matvec_acc<R_, C_, NEG_>(rf + LF.BLK_, X_, ACC_)
+#define ADMM_LD(R_, C_, BLK_, PTR_) (void)(PTR_)
+  (void)rec16; (void)ops;
+#endif
   const int col_raw = blockIdx.x * XB_THREADS + threadIdx.x;
   const int col = col_raw < pitch ? col_raw : pitch - 1;      // clamped lanes: loads only (see xb_kernel)
   const unsigned lb_st = col_raw < pitch ? (unsigned)col * 8u : ROWVIEW_OOB;
@@ -813,12 +914,16 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_X_OCCUPANCY void xf_kernel(
     __syncthreads();
     stage_records<XB_THREADS>(rec, recF + (size_t)kc * RF, (khi - kc + 1) * RF, threadIdx.x);
     __syncthreads();
+    ADMM_LD(NU, NX, PSI, rec16);
     for (int kb = kc; kb <= khi; kb += PF) {
 #pragma unroll
       for (int j = 0; j < PF; ++j) {
         const int k = kb + j;
         if (k > khi) break;
         const double* rf = rec + (k - kc) * RF;
+        const double* rf16 = rec16 + (k - kc) * RF;
+        ADMM_LD(NU, NX, K, rf16);
+        ADMM_LD(NX, NX, A, rf16);
         double uacc[NU], xn[NX], uu[NU];
 #pragma unroll
         for (int jj = 0; jj < NU; ++jj) uacc[jj] = ld[j][jj];
@@ -828,14 +933,17 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_X_OCCUPANCY void xf_kernel(
 #pragma unroll
           for (int jj = 0; jj < NU; ++jj) ld[j][jj] = vd.load(lb, d0 + jj * PB);
         }
-        lds_matvec_acc<NU, NX, false>(rf + LF.PSI, t, uacc);    // d0 + Psi t_in
-        lds_matvec_acc<NU, NX, false>(rf + LF.K, x, uacc);      //      + K x
+        ADMM_MV(NU, NX, false, PSI, t, uacc);    // d0 + Psi t_in
+        ADMM_LD(NX, NU, B, rf16);
+        ADMM_MV(NU, NX, false, K, x, uacc);      //      + K x
 #pragma unroll
         for (int jj = 0; jj < NU; ++jj) uu[jj] = -uacc[jj];
 #pragma unroll
         for (int i = 0; i < NX; ++i) xn[i] = 0.0;
-        lds_matvec_acc<NX, NX, false>(rf + LF.A, x, xn);        // x+ = A x
-        lds_matvec_acc<NX, NU, false>(rf + LF.B, uu, xn);       //      + B u
+        ADMM_MV(NX, NX, false, A, x, xn);        // x+ = A x
+        ADMM_MV(NX, NU, false, B, uu, xn);       //      + B u
+        __builtin_amdgcn_sched_barrier(0);
+        ADMM_LD(NU, NX, PSI, rec16 + ((k < khi ? k + 1 : khi) - kc) * RF);      // the next stage's first operator (after A, B: they may share a register)
         const unsigned r0 = (unsigned)(k - k0) * NB * PB;
 #pragma unroll
         for (int jj = 0; jj < NU; ++jj) vw.store(uu[jj], lb_st, r0 + jj * PB);
@@ -849,6 +957,9 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_X_OCCUPANCY void xf_kernel(
     }
   }
 }
+
+#undef ADMM_MV
+#undef ADMM_LD
 
 // ---------------------------------------------------------------------------
 // Fused forward rollout + z-update + dual ascent + residual partials (the
@@ -879,7 +990,20 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_X_OCCUPANCY void xfz_kernel(
   constexpr bool NEEDZ = RESID || RELAX;
   constexpr int PF = prefetch_depth(NB);
   constexpr int CH = stage_chunk(RF, PF);
-  __shared__ __attribute__((aligned(16))) double rec[CH * RF];
+  __shared__ __attribute__((aligned(16))) double rec[CH * RF + 16];
+  // operators distributed over the lanes of a row, read ahead of their FMAs (dpp_matvec_acc above): PSI, K, A, B; the next
+  // stage's PSI, K under this stage's z-update
+  constexpr int NREG = (LF.LO + 15) / 16;
+  double ops[NREG];
+  const double* rec16 = rec + (threadIdx.x & 15);
+#if ADMM_DPP_OPERANDS
+#define ADMM_MV(R_, C_, NEG_, BLK_, X_, ACC_) dpp_matvec_acc<R_, C_, NEG_, LF.BLK_, NREG>(ops, X_, ACC_)
+#define ADMM_LD(R_, C_, BLK_, PTR_) dpp_op_load<LF.BLK_, (R_) * (C_), NREG>(PTR_, ops)
+#else
+#define ADMM_MV(R_, C_, NEG_, BLK_, X_, ACC_) lds_matvec_acc<R_, C_, NEG_>(rf + LF.BLK_, X_, ACC_)
+#define ADMM_LD(R_, C_, BLK_, PTR_) (void)(PTR_)
+  (void)rec16; (void)ops;
+#endif
 
   const int col_raw = blockIdx.x * XB_THREADS + threadIdx.x;
   const int col = col_raw < pitch ? col_raw : pitch - 1;      // clamped lanes: loads only (see xb_kernel)
@@ -951,12 +1075,15 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_X_OCCUPANCY void xfz_kernel(
     __syncthreads();
     stage_records<XB_THREADS>(rec, recF + (size_t)kc * RF, (khi - kc + 1) * RF, threadIdx.x);
     __syncthreads();
+    ADMM_LD(NU, NX, PSI, rec16);
+    ADMM_LD(NU, NX, K, rec16);
     for (int kb = kc; kb <= khi; kb += PF) {
 #pragma unroll
       for (int j = 0; j < PF; ++j) {
         const int k = kb + j;
         if (k > khi) break;
         const double* rf = rec + (k - kc) * RF;      // wave-uniform address: LDS broadcast reads
+        const double* rf16 = rec16 + (k - kc) * RF;
         double d[NU], c0[NB], c1[NB];
 #pragma unroll
         for (int jj = 0; jj < NU; ++jj) d[jj] = ld[j][jj];
@@ -991,8 +1118,10 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_X_OCCUPANCY void xfz_kernel(
           double uacc[NU], xn[NX];
 #pragma unroll
           for (int jj = 0; jj < NU; ++jj) uacc[jj] = d[jj];
-          lds_matvec_acc<NU, NX, false>(rf + LF.PSI, t, uacc);    // d0 + Psi t_in
-          lds_matvec_acc<NU, NX, false>(rf + LF.K, x, uacc);      //      + K x
+          ADMM_LD(NX, NX, A, rf16);
+          ADMM_MV(NU, NX, false, PSI, t, uacc);    // d0 + Psi t_in
+          ADMM_LD(NX, NU, B, rf16);
+          ADMM_MV(NU, NX, false, K, x, uacc);      //      + K x
 #pragma unroll
           for (int jj = 0; jj < NU; ++jj) wv[jj] = -uacc[jj];     // u = -(...)
           double uu[NU];
@@ -1000,8 +1129,8 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_X_OCCUPANCY void xfz_kernel(
           for (int jj = 0; jj < NU; ++jj) uu[jj] = wv[jj];
 #pragma unroll
           for (int i = 0; i < NX; ++i) xn[i] = 0.0;
-          lds_matvec_acc<NX, NX, false>(rf + LF.A, x, xn);        // x+ = A x
-          lds_matvec_acc<NX, NU, false>(rf + LF.B, uu, xn);       //      + B u
+          ADMM_MV(NX, NX, false, A, x, xn);        // x+ = A x
+          ADMM_MV(NX, NU, false, B, uu, xn);       //      + B u
 #pragma unroll
           for (int i = 0; i < NX; ++i) wv[NU + i] = xn[i];
         }
@@ -1011,6 +1140,11 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_X_OCCUPANCY void xfz_kernel(
         // fall back to its minimum-register order (every LDS read waited for immediately);
         // split into rollout | row | row | ... each region gets a latency-aware schedule.
         __builtin_amdgcn_sched_barrier(0);
+        {  // the next stage's first two operators (after A, B: K and A may share a register), under the z-update
+          const double* rn16 = rec16 + ((k < khi ? k + 1 : khi) - kc) * RF;
+          ADMM_LD(NU, NX, PSI, rn16);
+          ADMM_LD(NU, NX, K, rn16);
+        }
         const unsigned r0 = (unsigned)(k - k0) * NB * PB;
         // thrust-magnitude bound on this stage's control rows, branch-free: ub = +inf (no bound here) gives both
         // factors = 1 exactly; where ub is finite the control rows' box is (-inf, inf) (see xfze_kernel)
@@ -1135,6 +1269,9 @@ static __global__ __launch_bounds__(Z_THREADS) void v_to_zy_kernel(
     *reinterpret_cast<double2*>(y + o) = yy;
   }
 }
+
+#undef ADMM_MV
+#undef ADMM_LD
 
 // ---------------------------------------------------------------------------
 // Fused z-update + dual ascent + residual partial sums -- the HBM-bound kernel

@@ -34,18 +34,34 @@ namespace admm {
 // register fit: 0 spills / no accumulator-register traffic on the operand ring, tools/alt_sweep.sh).
 // A macro, where defined, overrides the rule (A/B sweeps).
 //   prefetch depth (stages) and LDS operand pairs read ahead of their FMAs, forward / backward kernel
-constexpr int alt_pf_f(int nb, bool hasq, bool soc) {
+constexpr int alt_pf_f(int nb, bool hasq, bool soc, int xfree = 0) {
+#ifdef ADMM_ALT_PF_F_XFREE
+  if (xfree && !hasq && !soc) return ADMM_ALT_PF_F_XFREE;
+#endif
 #ifdef ADMM_ALT_PF_F
   return ADMM_ALT_PF_F;
 #else
-  (void)soc;
+  (void)soc; (void)xfree;
+#if ADMM_DPP_OPERANDS
+  // With the operators distributed over the lanes (dpp_matvec_acc) the kernels no longer wait on the LDS return path, and a
+  // second stage of state rows in flight buys nothing (round 3 A/B at configs[2], residual / XFREE = 2 forms: depth 2
+  // 131.9 / 74.9 us, depth 1 130.3 / 73.9 us; depths 2..4 of the XFREE forms were level before that too) -- while the
+  // 2-stage unrolled body of the general non-residual form needs 256 registers + scratch next to the 30 operator registers.
+  (void)nb; (void)hasq;
+  return 1;
+#else
   return (nb <= 9 && !hasq) ? 2 : 1;        // the q rows ride in the ring too
 #endif
+#endif
 }
-constexpr int alt_pf_b(int nb) {
+constexpr int alt_pf_b(int nb, int xfree = 0, bool hasq = false, bool soc = false) {
+#ifdef ADMM_ALT_PF_B_XFREE
+  if (xfree && !hasq && !soc) return ADMM_ALT_PF_B_XFREE;
+#endif
 #ifdef ADMM_ALT_PF_B
   return ADMM_ALT_PF_B;
 #else
+  (void)xfree; (void)hasq; (void)soc;
   return 1;
 #endif
 }
@@ -115,10 +131,23 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY(NX + NU, HASQ, SOC) 
   constexpr int NB = NX + NU;
   constexpr RecFELayout LF = rec_fe_layout(NX, NU);
   constexpr int RF = LF.SIZE;
-  constexpr int PF = alt_pf_f(NB, HASQ, SOC);
-  constexpr int ALT_G = alt_g_f(NB);
+  constexpr int PF = alt_pf_f(NB, HASQ, SOC, XFREE);
+  [[maybe_unused]] constexpr int ALT_G = alt_g_f(NB);
   constexpr int CH = stage_chunk(RF, PF);
-  __shared__ __attribute__((aligned(16))) double rec[CH * RF];
+  __shared__ __attribute__((aligned(16))) double rec[CH * RF + 16];      // (+ 16: the distributed read of the last stage's last register)
+  // operators distributed over the lanes of a row (dpp_matvec_acc, admm_kernels.hpp), read from LDS two operators ahead of
+  // their FMAs (ADMM_LD): PSI, K, A, B | z-update | DK, DG, OB, FM, GA, PI, then PSI, K of the next stage
+  constexpr int NREG = (LF.LO + 15) / 16;
+  double ops[NREG];
+  const double* rec16 = rec + (threadIdx.x & 15);
+#if ADMM_DPP_OPERANDS
+#define ADMM_MV(R_, C_, NEG_, BLK_, X_, ACC_) dpp_matvec_acc<R_, C_, NEG_, LF.BLK_, NREG>(ops, X_, ACC_)
+#define ADMM_LD(R_, C_, BLK_, PTR_) dpp_op_load<LF.BLK_, (R_) * (C_), NREG>(PTR_, ops)
+#else
+#define ADMM_MV(R_, C_, NEG_, BLK_, X_, ACC_) lds_matvec_acc<R_, C_, NEG_, ALT_G>(rf + LF.BLK_, X_, ACC_)
+#define ADMM_LD(R_, C_, BLK_, PTR_) (void)(PTR_)
+  (void)rec16; (void)ops;
+#endif
 
   const int col_raw = blockIdx.x * XB_THREADS + threadIdx.x;
   const int col = col_raw < pitch ? col_raw : pitch - 1;      // clamped lanes: loads only (see xb_kernel)
@@ -171,12 +200,16 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY(NX + NU, HASQ, SOC) 
     __syncthreads();
     stage_records<XB_THREADS>(rec, recFE + (size_t)kc * RF, (khi - kc + 1) * RF, threadIdx.x);
     __syncthreads();
+    ADMM_LD(NU, NX, PSI, rec16);                       // the chunk's first stage (later ones: at the end of their predecessor)
+    ADMM_LD(NU, NX, K, rec16);
     for (int kb = kc; kb <= khi; kb += PF) {
 #pragma unroll
       for (int j = 0; j < PF; ++j) {
         const int k = kb + j;
         if (k > khi) break;
         const double* rf = rec + (k - kc) * RF;
+        const double* rf16 = rec16 + (k - kc) * RF;
+        const double* rn16 = rec16 + ((k < khi ? k + 1 : khi) - kc) * RF;      // the next stage's record (clamped: re-read, unused)
         double d[NU], c0[NB], cq[NB];
 #pragma unroll
         for (int jj = 0; jj < NU; ++jj) d[jj] = ld[j][jj];
@@ -203,15 +236,19 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY(NX + NU, HASQ, SOC) 
           double uacc[NU], xn[NX];
 #pragma unroll
           for (int jj = 0; jj < NU; ++jj) uacc[jj] = d[jj];
-          lds_matvec_acc<NU, NX, false, ALT_G>(rf + LF.PSI, t, uacc);
-          lds_matvec_acc<NU, NX, false, ALT_G>(rf + LF.K, x, uacc);
+          ADMM_LD(NX, NX, A, rf16);
+          ADMM_MV(NU, NX, false, PSI, t, uacc);
+          ADMM_LD(NX, NU, B, rf16);
+          ADMM_MV(NU, NX, false, K, x, uacc);
           double uu[NU];
 #pragma unroll
           for (int jj = 0; jj < NU; ++jj) { wv[jj] = -uacc[jj]; uu[jj] = wv[jj]; }
 #pragma unroll
           for (int i = 0; i < NX; ++i) xn[i] = 0.0;
-          lds_matvec_acc<NX, NX, false, ALT_G>(rf + LF.A, x, xn);
-          lds_matvec_acc<NX, NU, false, ALT_G>(rf + LF.B, uu, xn);
+          ADMM_LD(NU, NX, DK, rf16);
+          ADMM_MV(NX, NX, false, A, x, xn);
+          ADMM_LD(NU, NU, DG, rf16);
+          ADMM_MV(NX, NU, false, B, uu, xn);
 #pragma unroll
           for (int i = 0; i < NX; ++i) { wv[NU + i] = xn[i]; x[i] = xn[i]; }
         }
@@ -253,6 +290,15 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY(NX + NU, HASQ, SOC) 
         }
 #pragma unroll
         for (int r = 0; r < NB; ++r) {
+          if (XFREE && r >= NU) {
+            // an unbounded state row: z = v, y = 0 identically, so v+ = w^ = w (no relaxation here), z+ = v+, y+ = 0 and
+            // g = -rho z+ -- the clip / dual arithmetic of the general row (2 max, 2 min, 4 adds) would reproduce exactly
+            // these values (up to the sign of a zero); the kernels without residuals are bound by fp64 issue, not by HBM
+            if (XFREE != 2) vv.store<ADMM_ALT_STORE_AUX>(wv[r], lb_st, r0 + r * PB);
+            g[r] = -rho * wv[r];
+            if (HASQ) g[r] += cq[r];
+            continue;
+          }
           const bool ball = SOC && r < NU;
           const double lo_r = SOC ? rf[LF.LO + r] : mLO[SOC ? 0 : r], hi_r = SOC ? rf[LF.HI + r] : mHI[SOC ? 0 : r];
           const double zo = fmin(fmax(ball ? c0[r] * cs_old : c0[r], lo_r), hi_r);
@@ -284,16 +330,30 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY(NX + NU, HASQ, SOC) 
           for (int jj = 0; jj < NU; ++jj) { gu[jj] = g[jj]; dn[jj] = 0.0; }
 #pragma unroll
           for (int i = 0; i < NX; ++i) { gx[i] = g[NU + i]; mn[i] = 0.0; }
-          lds_matvec_acc<NU, NX, false, ALT_G>(rf + LF.DK, mu, dn);       // db = DK mu
-          lds_matvec_acc<NU, NU, false, ALT_G>(rf + LF.DG, gu, dn);       //      + DG g^u
+          ADMM_LD(NX, NU, OB, rf16);
+          ADMM_MV(NU, NX, false, DK, mu, dn);       // db = DK mu
+          ADMM_LD(NX, NX, FM, rf16);
+          ADMM_MV(NU, NU, false, DG, gu, dn);       //      + DG g^u
           const unsigned m0 = (unsigned)(k - k0) * NU * PB;
 #pragma unroll
           for (int jj = 0; jj < NU; ++jj) vm.store<ADMM_ALT_STORE_AUX>(dn[jj], lb_st, m0 + jj * PB);
-          lds_matvec_acc<NX, NU, false, ALT_G>(rf + LF.OB, dn, eps);      // eb += OB db
+          ADMM_LD(NX, NU, GA, rf16);
+          ADMM_MV(NX, NU, false, OB, dn, eps);      // eb += OB db
           __builtin_amdgcn_sched_barrier(0);
-          lds_matvec_acc<NX, NX, false, ALT_G>(rf + LF.FM, mu, mn);
-          lds_matvec_acc<NX, NU, false, ALT_G>(rf + LF.GA, gu, mn);
-          lds_matvec_acc<NX, NX, false, ALT_G>(rf + LF.PI, gx, mn);
+          ADMM_LD(NX, NX, PI, rf16);
+          ADMM_MV(NX, NX, false, FM, mu, mn);
+          // the next stage's first two operators, while this stage's last two run -- unless they share a register with them
+          // (blocks of a few rows only: the whole record is one or two registers there)
+          constexpr bool AHEAD = (LF.K + NU * NX - 1) / 16 < LF.FM / 16;
+          if constexpr (AHEAD) ADMM_LD(NU, NX, PSI, rn16);
+          ADMM_MV(NX, NU, false, GA, gu, mn);
+          if constexpr (AHEAD) ADMM_LD(NU, NX, K, rn16);
+          ADMM_MV(NX, NX, false, PI, gx, mn);
+          if constexpr (!AHEAD) {
+            __builtin_amdgcn_sched_barrier(0);
+            ADMM_LD(NU, NX, PSI, rn16);
+            ADMM_LD(NU, NX, K, rn16);
+          }
 #pragma unroll
           for (int i = 0; i < NX; ++i) mu[i] = mn[i];
         }
@@ -319,6 +379,9 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY(NX + NU, HASQ, SOC) 
   }
 }
 
+#undef ADMM_MV
+#undef ADMM_LD
+
 // ---------------------------------------------------------------------------
 // Backward fused kernel.  One lane = one QP, blockIdx.y = segment, stages k = b-1 .. a, with
 // x = x_end(s) (the state at the segment's end), m_in = m_in(s) from the scan and t = e = 0 on entry:
@@ -340,10 +403,23 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY(NX + NU, HASQ, SOC) 
   constexpr int NB = NX + NU;
   constexpr RecBELayout LB = rec_be_layout(NX, NU);
   constexpr int RB = LB.SIZE;
-  constexpr int PF = alt_pf_b(NB);
-  constexpr int ALT_G = alt_g_b(NB);
+  constexpr int PF = alt_pf_b(NB, XFREE, HASQ, SOC);
+  [[maybe_unused]] constexpr int ALT_G = alt_g_b(NB);
   constexpr int CH = stage_chunk(RB, PF);
-  __shared__ __attribute__((aligned(16))) double rec[CH * RB];
+  __shared__ __attribute__((aligned(16))) double rec[CH * RB + 16];
+  // operators distributed over the lanes of a row, read two operators ahead of their FMAs (see xfze_kernel):
+  // PSB, KB, AI, AIB | z-update | BT, SI, AT, KT, OM, then PSB, KB of the next (= previous in time) stage
+  constexpr int NREG = (LB.LO + 15) / 16;
+  double ops[NREG];
+  const double* rec16 = rec + (threadIdx.x & 15);
+#if ADMM_DPP_OPERANDS
+#define ADMM_MV(R_, C_, NEG_, BLK_, X_, ACC_) dpp_matvec_acc<R_, C_, NEG_, LB.BLK_, NREG>(ops, X_, ACC_)
+#define ADMM_LD(R_, C_, BLK_, PTR_) dpp_op_load<LB.BLK_, (R_) * (C_), NREG>(PTR_, ops)
+#else
+#define ADMM_MV(R_, C_, NEG_, BLK_, X_, ACC_) lds_matvec_acc<R_, C_, NEG_, ALT_G>(rb + LB.BLK_, X_, ACC_)
+#define ADMM_LD(R_, C_, BLK_, PTR_) (void)(PTR_)
+  (void)rec16; (void)ops;
+#endif
 
   const int col_raw = blockIdx.x * XB_THREADS + threadIdx.x;
   const int col = col_raw < pitch ? col_raw : pitch - 1;
@@ -401,12 +477,16 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY(NX + NU, HASQ, SOC) 
     __syncthreads();
     stage_records<XB_THREADS>(rec, recBE + (size_t)klo * RB, (kc - klo + 1) * RB, threadIdx.x);
     __syncthreads();
+    ADMM_LD(NU, NX, PSB, rec16 + (kc - klo) * RB);       // the chunk's first (= last in time) stage
+    ADMM_LD(NU, NX, KB, rec16 + (kc - klo) * RB);
     for (int kb = kc; kb >= klo; kb -= PF) {
 #pragma unroll
       for (int j = 0; j < PF; ++j) {
         const int k = kb - j;
         if (k < klo) break;
         const double* rb = rec + (k - klo) * RB;
+        const double* rb16 = rec16 + (k - klo) * RB;
+        const double* rn16 = rec16 + ((k > klo ? k - 1 : klo) - klo) * RB;     // the next stage's record (clamped)
         double c0[NB], d[NU], cq[NB];
 #pragma unroll
         for (int r = 0; r < NB; ++r) {
@@ -432,17 +512,21 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY(NX + NU, HASQ, SOC) 
         double wv[NB];
         {
           double uu[NU], xk[NX];
-          lds_matvec_acc<NU, NX, false, ALT_G>(rb + LB.PSB, mi, d);       // d = db + PSB m_in
+          ADMM_LD(NX, NX, AI, rb16);
+          ADMM_MV(NU, NX, false, PSB, mi, d);       // d = db + PSB m_in
+          ADMM_LD(NX, NU, AIB, rb16);
 #pragma unroll
           for (int jj = 0; jj < NU; ++jj) uu[jj] = -d[jj];
-          lds_matvec_acc<NU, NX, true, ALT_G>(rb + LB.KB, x, uu);         // u = -d - KB x
+          ADMM_MV(NU, NX, true, KB, x, uu);         // u = -d - KB x
 #pragma unroll
           for (int jj = 0; jj < NU; ++jj) wv[jj] = uu[jj];
 #pragma unroll
           for (int i = 0; i < NX; ++i) { wv[NU + i] = x[i]; xk[i] = 0.0; }
           __builtin_amdgcn_sched_barrier(0);
-          lds_matvec_acc<NX, NX, false, ALT_G>(rb + LB.AI, x, xk);        // x_k = AI x_{k+1}
-          lds_matvec_acc<NX, NU, false, ALT_G>(rb + LB.AIB, uu, xk);      //       + AIB u
+          ADMM_LD(NU, NX, BT, rb16);
+          ADMM_MV(NX, NX, false, AI, x, xk);        // x_k = AI x_{k+1}
+          ADMM_LD(NU, NU, SI, rb16);
+          ADMM_MV(NX, NU, false, AIB, uu, xk);      //       + AIB u
 #pragma unroll
           for (int i = 0; i < NX; ++i) x[i] = xk[i];
         }
@@ -472,6 +556,12 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY(NX + NU, HASQ, SOC) 
         for (int r3 = 0; r3 < NB; r3 += 3) {
 #pragma unroll
           for (int r = r3; r < r3 + 3 && r < NB; ++r) {
+            if (XFREE && r >= NU) {             // unbounded state row: see xfze_kernel
+              if (XFREE != 2) vv.store<ADMM_ALT_STORE_AUX>(wv[r], lb_st, r0 + r * PB);
+              g[r] = -rho * wv[r];
+              if (HASQ) g[r] += cq[r];
+              continue;
+            }
             const bool ball = SOC && r < NU;
             const double lo = rb[LB.LO + r], hi = rb[LB.HI + r];
             const double zo = fmin(fmax(ball ? c0[r] * cs_old : c0[r], lo), hi);
@@ -503,17 +593,28 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY(NX + NU, HASQ, SOC) 
           for (int i = 0; i < NX; ++i) p[i] = g[NU + i] + t[i];
 #pragma unroll
           for (int jj = 0; jj < NU; ++jj) { h[jj] = g[jj]; d[jj] = 0.0; }
-          lds_matvec_acc<NU, NX, false, ALT_G>(rb + LB.BT, p, h);
-          lds_matvec_acc<NU, NU, false, ALT_G>(rb + LB.SI, h, d);
+          ADMM_LD(NX, NX, AT, rb16);
+          ADMM_MV(NU, NX, false, BT, p, h);
+          ADMM_LD(NX, NU, KT, rb16);
+          ADMM_MV(NU, NU, false, SI, h, d);
           const unsigned d0 = (unsigned)SIDX(k) * NU * PB;
 #pragma unroll
           for (int jj = 0; jj < NU; ++jj) vd.store<ADMM_ALT_STORE_AUX>(d[jj], lb_st, d0 + jj * PB);
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int i = 0; i < NX; ++i) t[i] = 0.0;
-          lds_matvec_acc<NX, NX, false, ALT_G>(rb + LB.AT, p, t);
-          lds_matvec_acc<NX, NU, true, ALT_G>(rb + LB.KT, h, t);
-          lds_matvec_acc<NX, NU, false, ALT_G>(rb + LB.OM, d, e);
+          ADMM_LD(NX, NU, OM, rb16);
+          ADMM_MV(NX, NX, false, AT, p, t);
+          constexpr bool AHEAD = (LB.KB + NU * NX - 1) / 16 < LB.AT / 16;      // see xfze_kernel
+          if constexpr (AHEAD) ADMM_LD(NU, NX, PSB, rn16);
+          ADMM_MV(NX, NU, true, KT, h, t);
+          if constexpr (AHEAD) ADMM_LD(NU, NX, KB, rn16);
+          ADMM_MV(NX, NU, false, OM, d, e);
+          if constexpr (!AHEAD) {
+            __builtin_amdgcn_sched_barrier(0);
+            ADMM_LD(NU, NX, PSB, rn16);
+            ADMM_LD(NU, NX, KB, rn16);
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -536,5 +637,8 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY(NX + NU, HASQ, SOC) 
     }
   }
 }
+
+#undef ADMM_MV
+#undef ADMM_LD
 
 }  // namespace admm

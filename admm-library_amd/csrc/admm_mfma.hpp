@@ -328,7 +328,12 @@ __global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         double vn;
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
-          mf_zupdate<RESID, RELAX>(c0[nt][r], (double)a0[nt][r], lohi[r * 4 + g], lohi[20 + r * 4 + g], alpha, rho, vn, gg[nt][r], racc[nt]);
+          if (XFREE) {            // unbounded state rows: v+ = w, z+ = v+, y+ = 0, g = -rho w (see xfze_kernel): no clip / dual arithmetic
+            vn = (double)a0[nt][r];
+            gg[nt][r] = -rho * vn;
+          } else {
+            mf_zupdate<RESID, RELAX>(c0[nt][r], (double)a0[nt][r], lohi[r * 4 + g], lohi[20 + r * 4 + g], alpha, rho, vn, gg[nt][r], racc[nt]);
+          }
           if (XFREE != 2) vv.store(vn, okx[r] ? lbs[nt] : ROWVIEW_OOB, r0 + (unsigned)(NU + 4 * r) * PB);
           X[nt][r] = a0[nt][r];
         }
@@ -597,7 +602,12 @@ __global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
           double vn;
 #pragma unroll
           for (int r = 0; r < NR; ++r) {
-            mf_zupdate<RESID, RELAX>(c0[nt][r], (double)X[nt][r], lohi[r * 4 + g], lohi[20 + r * 4 + g], alpha, rho, vn, gg[nt][r], racc[nt]);
+            if (XFREE) {          // unbounded state rows: v+ = w, z+ = v+, y+ = 0, g = -rho w (see xfze_kernel)
+              vn = (double)X[nt][r];
+              gg[nt][r] = -rho * vn;
+            } else {
+              mf_zupdate<RESID, RELAX>(c0[nt][r], (double)X[nt][r], lohi[r * 4 + g], lohi[20 + r * 4 + g], alpha, rho, vn, gg[nt][r], racc[nt]);
+            }
             if (XFREE != 2) vv.store(vn, okx[r] ? lbs[nt] : ROWVIEW_OOB, r0 + (unsigned)(NU + 4 * r) * PB);
             X[nt][r] = a0[nt][r];                                 // x_k
           }

@@ -115,10 +115,10 @@ def test_path_of_the_headline_handle(gpu):
         warnings.simplefilter("always")
         s = pkg.Solver(p, pkg.Options(rho=0.05))
     with s:
-        path = s.path()
+        path, geo = s.path(), s.geometry()
     assert not [w for w in rec if issubclass(w.category, RuntimeWarning)] and s.last_warning == ""
     assert path["alternating"] and path["alt_requested"] and path["kernel_family"] == "one_lane_fp64" and path["xfree"]
-    assert path["scan_form"] == "mfma_gemm" and path["segments"] == s.geometry()["segments"] and path["auto_segments"]
+    assert path["scan_form"] == "mfma_gemm" and path["segments"] == geo["segments"] and path["auto_segments"]
     assert 0.0 <= path["alt_check"] <= path["alt_gate"] == 5e-12          # the measured margin of the forward-elimination form
     assert 0.0 < path["scan_growth"] <= 100.0
 
