@@ -1110,8 +1110,14 @@ int admm_setup(admm_handle** out, const admm_problem* p, const admm_options* o_i
     if (o.precision_mode != ADMM_PRECISION_FP64) {
       if (!why.empty()) { release(h); return fail(ADMM_ERR_UNSUPPORTED, "precision_mode " + std::to_string(o.precision_mode) + ": " + why); }
       h->mfma_mode = lq.mfma_mode;
-    } else if (why.empty() && !(o.flags & (ADMM_FLAG_NO_MFMA | ADMM_FLAG_NO_ALTERNATE)) && (p->n >= 9 || h->pitch <= 128)) {
-      h->mfma_mode = 2;          // FP64: the fp64 MFMA form where it is the faster one (ADMM_FLAG_NO_MFMA)
+    } else if (why.empty() && !(o.flags & (ADMM_FLAG_NO_MFMA | ADMM_FLAG_NO_ALTERNATE)) &&
+               (h->pitch <= 64 || (p->n >= 9 && h->pitch <= 128))) {
+      // FP64: the fp64 MFMA form where it is the faster one (ADMM_FLAG_NO_MFMA).  Measured, round 3 (tools/family_time.py;
+      // one-lane kernels with the operators distributed over the lanes, dpp_matvec_acc): the MFMA form wins for the
+      // smallest batches only -- one wave per segment running ~15 MFMAs per stage instead of a few hundred dependent FMAs --
+      // (6, 3): 22 vs 33 us per iteration for one QP, 27 vs 35 at 64 QPs, level at 128, 59 vs 41 at 256, 187 vs 151 at 4096;
+      // (12, 6): 34 vs 72 us for one QP, 42 vs 76 at 64, 103 vs 95 at 256, 343 vs 315 at 4096.
+      h->mfma_mode = 2;
     }
   }
   // batches of a few QPs run the scan as a matrix-vector product (xscan_gemv_kernel) and need no MFMA-packed scan matrices

@@ -32,8 +32,10 @@ constexpr int Z_THREADS = 256;    // z/dual workgroup: 256 lanes x 2 QPs = 512 c
 constexpr int T_TILE = 32;        // transpose tile
 // Stages of operand prefetch in xb / xfz (register ring depth).  Measured at n = 6, m = 3:
 // 1 -> 4721, 2 -> 4844, 3 -> 4861 iterations/s; larger blocks get a shallower ring (registers).
+// (Round 3, operators distributed over the lanes -- dpp_matvec_acc below: depths 1 / 2 / 3 -> 4899 / 5042 / 5091 iterations/s on the
+// plain path; depth 3 parks the ring of the q forms in accumulator registers, depth 2 keeps every form of (6, 3) in 256.)
 constexpr int prefetch_depth(int nb) {
-  return ADMM_XB_PREFETCH > 0 ? ADMM_XB_PREFETCH : (nb <= 9 ? 3 : (nb <= 12 ? 2 : 1));
+  return ADMM_XB_PREFETCH > 0 ? ADMM_XB_PREFETCH : (nb <= 12 ? 2 : 1);
 }
 
 // The x kernels run at 1-2 waves per SIMD (grid size and the LDS record slab decide that, not
@@ -368,7 +370,7 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_X_OCCUPANCY void xb_kernel(
       for (int j = 0; j < PF; ++j) {
         const int k = kb - j;
         if (k < klo) break;
-        const double* rb = rec + (k - klo) * RB;     // wave-uniform address: LDS broadcast reads
+        [[maybe_unused]] const double* rb = rec + (k - klo) * RB;     // wave-uniform address: LDS broadcast reads
         const double* rb16 = rec16 + (k - klo) * RB;
         ADMM_LD(NU, NX, BT, rb16);                   // (the z-update below covers their latency)
         ADMM_LD(NU, NU, SI, rb16);
@@ -920,7 +922,7 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_X_OCCUPANCY void xf_kernel(
       for (int j = 0; j < PF; ++j) {
         const int k = kb + j;
         if (k > khi) break;
-        const double* rf = rec + (k - kc) * RF;
+        [[maybe_unused]] const double* rf = rec + (k - kc) * RF;
         const double* rf16 = rec16 + (k - kc) * RF;
         ADMM_LD(NU, NX, K, rf16);
         ADMM_LD(NX, NX, A, rf16);
@@ -1082,7 +1084,7 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_X_OCCUPANCY void xfz_kernel(
       for (int j = 0; j < PF; ++j) {
         const int k = kb + j;
         if (k > khi) break;
-        const double* rf = rec + (k - kc) * RF;      // wave-uniform address: LDS broadcast reads
+        [[maybe_unused]] const double* rf = rec + (k - kc) * RF;      // wave-uniform address: LDS broadcast reads
         const double* rf16 = rec16 + (k - kc) * RF;
         double d[NU], c0[NB], c1[NB];
 #pragma unroll

@@ -207,7 +207,7 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY(NX + NU, HASQ, SOC) 
       for (int j = 0; j < PF; ++j) {
         const int k = kb + j;
         if (k > khi) break;
-        const double* rf = rec + (k - kc) * RF;
+        [[maybe_unused]] const double* rf = rec + (k - kc) * RF;
         const double* rf16 = rec16 + (k - kc) * RF;
         const double* rn16 = rec16 + ((k < khi ? k + 1 : khi) - kc) * RF;      // the next stage's record (clamped: re-read, unused)
         double d[NU], c0[NB], cq[NB];
@@ -484,7 +484,7 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY(NX + NU, HASQ, SOC) 
       for (int j = 0; j < PF; ++j) {
         const int k = kb - j;
         if (k < klo) break;
-        const double* rb = rec + (k - klo) * RB;
+        [[maybe_unused]] const double* rb = rec + (k - klo) * RB;
         const double* rb16 = rec16 + (k - klo) * RB;
         const double* rn16 = rec16 + ((k > klo ? k - 1 : klo) - klo) * RB;     // the next stage's record (clamped)
         double c0[NB], d[NU], cq[NB];

@@ -506,10 +506,11 @@ def main():
     # roofline of the fused pair (21.33 B/element), host-counted and measured matrix-pipe utilisation.
     configs4 = None
     if a.workload == "cw_rendezvous" and rank == 0 and world == 1 and not a.no_configs4:
-        configs4 = {"workload": f"configs[4]: batch of {a.batch} N={a.horizon} n=12 m=6 Clohessy-Wiltshire formation QPs, x-update as "
-                                "MFMA batched GEMM, residuals every iteration"}
+        configs4 = {"workload": f"configs[4]: batch of {a.batch} N={a.horizon} n=12 m=6 Clohessy-Wiltshire formation QPs, residuals every "
+                                "iteration: fp64 (the library's choice: one-lane kernels with DPP-distributed operators), and the x-update "
+                                "as MFMA batched GEMM in fp64 (fp64_mfma) and in mixed fp32/fp64 (mixed)"}
         form = pkg.cw_formation(N=a.horizon, batch=a.batch)
-        for name in ("fp64_mfma", "mixed"):
+        for name in ("fp64", "fp64_mfma", "mixed"):          # fp64 = the library's choice at this shape and batch (the one-lane kernels)
             with pkg.Solver(form, pkg.Options(rho=0.05, check_interval=1, device=dev_index, precision_mode=PM[name])) as sp:
                 g4, p4 = sp.geometry(), sp.path()
                 warm(sp, 0.3)
@@ -520,21 +521,23 @@ def main():
             e4 = form.L * g4["pitch"]
             pair_ms = pr["xfze_ms"] + pr["xbze_ms"]
             hbm = 2 * (16.0 + 16.0 * 6 / 18) * e4 / (pair_ms * 1e-3) / 1e9
-            acc = mfma_accounting(12, 6, name, g4["pitch"], form.N, pr["xfze_ms"], pr["xbze_ms"],
-                                  "formation_mixed" if (name, a.batch, a.horizon) == ("mixed", 4096, 1000) else None)
             configs4[name] = {"batch_iterations_per_s": a.steps / d4, "ms_per_step": d4 / a.steps * 1e3, "timed_blocks": len(b4),
                               "batch_iterations_per_s_check_interval_10": a.steps / float(np.median(b4_10)),
                               "kernel_family": p4["kernel_family"], "alternating": p4["alternating"], "alt_check": p4["alt_check"],
                               "segments": g4["segments"],
-                              "xfzem_ms": pr["xfze_ms"], "xbzem_ms": pr["xbze_ms"], "xscan_ms": pr["xscan_ms"],
+                              "forward_kernel_ms": pr["xfze_ms"], "backward_kernel_ms": pr["xbze_ms"], "xscan_ms": pr["xscan_ms"],
                               "hbm": {"achieved": hbm, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm / HBM_PEAK_GBS,
-                                      "bytes_per_element": 16.0 + 16.0 * 6 / 18},
-                              "mfma": {"useful_TFLOPs": acc["achieved"], "peak_TFLOPs_for_this_mix": acc["peak"], "frac": acc["frac"],
-                                       "useful_over_issued": {k: v["useful_over_issued"] for k, v in acc["per_kernel"].items()},
-                                       "matrix_pipe_busy_at_2p4GHz": {k: v["matrix_pipe_busy_at_2p4GHz"] for k, v in acc["per_kernel"].items()},
-                                       "mfma_util_measured": acc["mfma_util_measured"],
-                                       "measured_counters_source": next((v["measured_counters"]["source"] for v in acc["per_kernel"].values()
-                                                                         if v["measured_counters"]), None)}}
+                                      "bytes_per_element": 16.0 + 16.0 * 6 / 18}}
+            if p4["kernel_family"] != "one_lane_fp64":
+                acc = mfma_accounting(12, 6, name, g4["pitch"], form.N, pr["xfze_ms"], pr["xbze_ms"],
+                                      "formation_mixed" if (name, a.batch, a.horizon) == ("mixed", 4096, 1000) else None)
+                configs4[name]["mfma"] = {
+                    "useful_TFLOPs": acc["achieved"], "peak_TFLOPs_for_this_mix": acc["peak"], "frac": acc["frac"],
+                    "useful_over_issued": {k: v["useful_over_issued"] for k, v in acc["per_kernel"].items()},
+                    "matrix_pipe_busy_at_2p4GHz": {k: v["matrix_pipe_busy_at_2p4GHz"] for k, v in acc["per_kernel"].items()},
+                    "mfma_util_measured": acc["mfma_util_measured"],
+                    "measured_counters_source": next((v["measured_counters"]["source"] for v in acc["per_kernel"].values()
+                                                      if v["measured_counters"]), None)}
         del form
 
     # iterations-to-epsilon (second half of BASELINE.json's metric; "vs MATLAB" -> vs the CPU oracle):

@@ -102,8 +102,8 @@ typedef struct admm_options {
   double adapt_tau;       /* > 1 */
   /* Arithmetic of the x-update (ABI v4; BASELINE.json configs[4]).  ADMM_PRECISION_*:
    *   FP64       fp64 throughout; the library picks the kernel form: one lane per QP with fp64 vector FMAs (every
-   *              compiled (n, m), q, thrust-magnitude bound), or FP64_MFMA's kernels where those are faster
-   *              (ADMM_FLAG_NO_MFMA).
+   *              compiled (n, m), q, thrust-magnitude bound), or FP64_MFMA's kernels where those are faster -- the
+   *              smallest batches (ADMM_FLAG_NO_MFMA).
    *   FP64_MFMA  the fused stage operators as chains of v_mfma_f64_16x16x4_f64 over 16-QP panels, always: the same
    *              fp64 iteration (iterates equal to the one-lane kernels' to rounding).
    *   MIXED      as FP64_MFMA, but the two products of the Riccati form (forward rollout, backward elimination:
@@ -137,9 +137,12 @@ typedef struct admm_options {
 #define ADMM_FLAG_NO_MFMA 32    /* ADMM_PRECISION_FP64 only: always the one-lane-per-QP kernels.  By default FP64 takes the
                                   fp64 MFMA form of the fused kernels (same iteration, iterates equal to rounding;
                                   DESIGN.md §4.9) where it is compiled for (n, m), the problem has no q and no
-                                  thrust-magnitude bound, and it is the faster of the two: n >= 9 (operand delivery binds
-                                  the one-lane kernels there), or a batch of at most 128 QPs (one wave per segment runs a
-                                  chain of ~15 MFMAs per stage instead of ~450 dependent vector instructions) */
+                                  thrust-magnitude bound, and it is the faster of the two -- measured (tools/family_time.py):
+                                  batches of at most 64 QPs, or at most 128 with n >= 9 (one wave per segment runs a chain
+                                  of ~15 MFMAs per stage instead of a few hundred dependent vector FMAs).  Larger batches
+                                  run the one-lane kernels, whose stage operators are distributed over the lanes of a row
+                                  and applied with v_fmac_f64_dpp (round 3): faster than the MFMA form at every shape
+                                  from 256 QPs on, n = 12 included */
 
 #define ADMM_FLAG_HISTORY 64     /* admm_solve records, at every stopping test, (iteration, converged QPs, max primal residual, max dual
                                    residual, rho in force) for admm_get_history; costs one read-back of the per-QP residuals per test */

@@ -225,13 +225,16 @@ def test_alternating_properties_at_full_size(gpu):
     assert np.abs(defect).max() <= 1e-10 * max(1.0, np.abs(x).max())
 
 
-@pytest.mark.parametrize("make", [lambda: pkg.cw_rendezvous(N=200, batch=300), lambda: pkg.cw_formation(N=120, batch=300),
-                                  lambda: pkg.cw_rendezvous(N=64, batch=5, thrust_norm=True),
-                                  lambda: pkg.random_ltv(N=70, n=6, m=3, batch=67, seed=77, state_bounds=False),
-                                  lambda: pkg.random_ltv(N=45, n=4, m=2, batch=9, seed=78, state_bounds=False, thrust_norm=True),
-                                  lambda: pkg.random_ltv(N=45, n=8, m=4, batch=130, seed=79, with_q=False, state_bounds=False)],
-                         ids=["one_lane_6_3", "mfma_12_6", "thrust_magnitude", "ltv_q_stage_bounds", "ltv_q_stage_thrust_bounds", "ltv_8_4"])
-def test_skipping_v_of_unbounded_state_rows_is_exact(gpu, make, monkeypatch):
+@pytest.mark.parametrize("make,opts", [(lambda: pkg.cw_rendezvous(N=200, batch=300), {}), (lambda: pkg.cw_formation(N=120, batch=300), {}),
+                                       (lambda: pkg.cw_formation(N=120, batch=300), {"precision_mode": 2}),
+                                       (lambda: pkg.cw_rendezvous(N=120, batch=40), {}),
+                                       (lambda: pkg.cw_rendezvous(N=64, batch=5, thrust_norm=True), {}),
+                                       (lambda: pkg.random_ltv(N=70, n=6, m=3, batch=67, seed=77, state_bounds=False), {}),
+                                       (lambda: pkg.random_ltv(N=45, n=4, m=2, batch=9, seed=78, state_bounds=False, thrust_norm=True), {}),
+                                       (lambda: pkg.random_ltv(N=45, n=8, m=4, batch=130, seed=79, with_q=False, state_bounds=False), {})],
+                         ids=["one_lane_6_3", "one_lane_12_6", "mfma_12_6", "mfma_6_3_small_batch", "thrust_magnitude", "ltv_q_stage_bounds",
+                              "ltv_q_stage_thrust_bounds", "ltv_8_4"])
+def test_skipping_v_of_unbounded_state_rows_is_exact(gpu, make, opts, monkeypatch):
     """XFREE kernel forms: where every state row is unbounded at every stage, the iterations that evaluate
     no residuals do not read v of those rows (y = 0 identically there) -- nor write it while the next iteration is of the same kind.  Same iterates, BIT for bit, as with the skip
     disabled (ADMM_NO_SKIPV), through a mix of residual and non-residual iterations and both kernel families."""
@@ -242,7 +245,7 @@ def test_skipping_v_of_unbounded_state_rows_is_exact(gpu, make, monkeypatch):
             monkeypatch.delenv("ADMM_NO_SKIPV", raising=False)
         else:
             monkeypatch.setenv("ADMM_NO_SKIPV", "1")
-        with pkg.Solver(p, pkg.Options(rho=0.05)) as s:
+        with pkg.Solver(p, pkg.Options(rho=0.05, **opts)) as s:
             s.run(23, residual_every=5)
             s.iterate(4)
             for k in (1, 2, 3, 7, 10):          # call lengths of both parities: the no-store form (XFREE = 2) needs its successor

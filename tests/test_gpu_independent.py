@@ -37,15 +37,16 @@ def test_config0_gpu_solve_vs_scipy_bvls(gpu):
 
 FULL = {
     "configs2_n6": (lambda: pkg.cw_rendezvous(N=1000, batch=4096), _abi.PRECISION_FP64),
-    "configs4_n12_fp64_mfma": (lambda: pkg.cw_formation(N=1000, batch=4096), _abi.PRECISION_FP64),
+    "configs4_n12_one_lane": (lambda: pkg.cw_formation(N=1000, batch=4096), _abi.PRECISION_FP64),
+    "configs4_n12_fp64_mfma": (lambda: pkg.cw_formation(N=1000, batch=4096), _abi.PRECISION_FP64_MFMA),
     "configs4_n12_mixed": (lambda: pkg.cw_formation(N=1000, batch=4096), _abi.PRECISION_MIXED),
 }
 
 
 @pytest.mark.parametrize("case", FULL)
 def test_optimality_of_every_qp_of_a_converged_full_batch(gpu, case):
-    """All 4096 QPs of configs[2] / configs[4] (the latter on its default fp64-MFMA form and in the mixed mode with fp64
-    refinement), solved to eps = 1e-8 with the adaptive rule: every QP converged, and every QP's (z, rho y) satisfies
+    """All 4096 QPs of configs[2] / configs[4] (the latter on the default one-lane kernels, on the fp64-MFMA form and in the
+    mixed mode with fp64 refinement), solved to eps = 1e-8 with the adaptive rule: every QP converged, and every QP's (z, rho y) satisfies
     dynamics defect < 1e-6, box violation == 0, stationarity < 1e-6, complementarity < 1e-6 (variables are O(1))."""
     make, mode = FULL[case]
     p = make()
@@ -64,8 +65,9 @@ def test_optimality_of_every_qp_of_a_converged_full_batch(gpu, case):
 
 
 XCASES = {
-    "n6": lambda: pkg.cw_rendezvous(N=1000, batch=4096),
-    "n12": lambda: pkg.cw_formation(N=1000, batch=4096),
+    "n6": (lambda: pkg.cw_rendezvous(N=1000, batch=4096), _abi.PRECISION_FP64),
+    "n12": (lambda: pkg.cw_formation(N=1000, batch=4096), _abi.PRECISION_FP64),
+    "n12_fp64_mfma": (lambda: pkg.cw_formation(N=1000, batch=4096), _abi.PRECISION_FP64_MFMA),
 }
 
 
@@ -77,10 +79,11 @@ def _state(p, seed):
 @pytest.mark.parametrize("case", XCASES)
 def test_x_update_vs_banded_kkt_at_full_size(gpu, case):
     """w = x-update(z, y) of the whole 4096-QP batch (segmented sweeps + MFMA scan) vs one banded LU solve with 4096 right-hand sides."""
-    p = XCASES[case]()
+    make, mode = XCASES[case]
+    p = make()
     rho = 0.05
     z0, y0 = _state(p, 11)
-    with pkg.Solver(p, pkg.Options(rho=rho)) as s:
+    with pkg.Solver(p, pkg.Options(rho=rho, precision_mode=mode)) as s:
         assert s.geometry()["segments"] > 1
         s.set_state(z=z0, y=y0)
         s.step_x()
@@ -95,12 +98,13 @@ def test_x_update_vs_banded_kkt_at_full_size(gpu, case):
 @pytest.mark.parametrize("case", XCASES)
 def test_default_path_iterations_vs_banded_admm(gpu, case):
     """Four iterations of the default path from a random (z, y) -- a start form, then the fused alternating kernels in both
-    directions (n = 6: xfze / xbze; n = 12: their MFMA forms) -- vs the textbook loop of DESIGN.md §2 with the banded
+    directions (xfze / xbze; n12_fp64_mfma: their MFMA forms) -- vs the textbook loop of DESIGN.md §2 with the banded
     KKT solve as x-update.  1e-10 on w, z, y of all 4096 QPs."""
-    p = XCASES[case]()
+    make, mode = XCASES[case]
+    p = make()
     rho, iters = 0.05, 4
     z, y = _state(p, 12)
-    with pkg.Solver(p, pkg.Options(rho=rho)) as s:
+    with pkg.Solver(p, pkg.Options(rho=rho, precision_mode=mode)) as s:
         s.set_state(z=z, y=y)
         s.iterate(iters)
         wg, zg, yg = s.get()
