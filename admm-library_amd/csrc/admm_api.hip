@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -71,6 +72,7 @@ struct admm_handle {
   std::vector<std::unique_ptr<SpecFactor>> spec;        // candidates of the adaptive rule (rho tau, rho / tau)
   std::vector<std::unique_ptr<SpecFactor>> spec_stale;  // no longer candidates; their threads are joined lazily
   int spec_hits = 0, spec_misses = 0;
+  bool solve_active = false;     // between admm_solve_begin and admm_solve_end: only then are candidate factors kept / started
   // ADMM_FLAG_HISTORY: one record per stopping test of the last admm_solve
   struct HistoryEntry { int32_t it, nconv; double max_r, max_s, rho; };
   std::vector<HistoryEntry> history;
@@ -110,6 +112,11 @@ struct admm_handle {
   double *Ad = nullptr, *Bd = nullptr, *Kd = nullptr, *Sd = nullptr, *lod = nullptr, *hid = nullptr;
   double *Qd = nullptr, *Rd = nullptr, *QNd = nullptr;
   int* pfail = nullptr;
+  // TRIAL buffers of the per-instance path (allocated on first use): a change of rho or of the problem data is factorised
+  // into these first and only then committed by swapping pointers, so that a refused change leaves the handle untouched
+  double *Ad2 = nullptr, *Bd2 = nullptr, *Kd2 = nullptr, *Sd2 = nullptr, *Qd2 = nullptr, *Rd2 = nullptr, *QNd2 = nullptr;
+  double *rho2_d = nullptr;      // [pitch] candidate rho (admm_set_rho) / the rho being left (per-QP adaptive rule)
+  int *qflag_d = nullptr, *nveto_d = nullptr;      // [pitch] per-QP verdict of a trial factorisation; [1] refused changes
   // segments in time of the per-instance path (S > 1; csrc/admm_pinst.hpp, pseg_kernel): per-QP transfer matrices
   double *Omd = nullptr, *Psd = nullptr, *Segd = nullptr;
   int* pgrow = nullptr;
@@ -129,6 +136,9 @@ struct admm_handle {
   int *seg_start = nullptr, *status = nullptr, *iters = nullptr, *nconv = nullptr;
   double* stage = nullptr;      // QP-major staging buffer, L * batch
   int* h_nconv = nullptr;       // pinned
+  // pinned bounce buffers of large host-to-device uploads (allocated on first use; upload_h2d)
+  unsigned char* pin[2] = {nullptr, nullptr};
+  hipEvent_t pin_ev[2] = {nullptr, nullptr};
   int iters_run = 0;
   bool resid_valid = false;
   // A residual-evaluating alternating iteration leaves its finalise to the NEXT scan launch (finalise
@@ -185,6 +195,7 @@ admm::PLaunch plaunch_of(const admm_handle* h) {
   l.rows = h->pi_rows;
   l.has_soc = h->has_soc; l.ub = h->ub;
   l.Ad = h->Ad; l.Bd = h->Bd; l.Q = h->Qd; l.R = h->Rd; l.QN = h->QNd; l.Kd = h->Kd; l.Sd = h->Sd; l.fail = h->pfail;
+  l.qflag = nullptr;
   l.lo = h->pbounds ? h->lod : h->lo; l.hi = h->pbounds ? h->hid : h->hi;
   l.z = h->z; l.y = h->y; l.q = h->q; l.x0 = h->x0; l.v = h->v; l.w = h->w; l.dbuf = h->dbuf; l.part = h->part;
   return l;
@@ -429,10 +440,58 @@ int step_x(admm_handle* h) {
   return ADMM_OK;
 }
 
+// Host threads for the O(problem size) host loops of the API (finiteness checks, copies into pinned memory): at most 16, never
+// more than the work is worth (one per 4 MB).  fn(begin, end) over a partition of [0, count); results are combined by the caller.
+template <class F>
+void host_parallel(size_t count, size_t bytes_per_item, F&& fn) {
+  size_t nt = std::min<size_t>(std::min<size_t>(16, std::max(1u, std::thread::hardware_concurrency())),
+                               count * bytes_per_item / ((size_t)4 << 20));
+  if (nt <= 1) { fn((size_t)0, count); return; }
+  std::vector<std::thread> th;
+  size_t started = 1;
+  try {
+    for (size_t t = 1; t < nt; ++t) {
+      th.emplace_back([&fn, t, nt, count] { fn(count * t / nt, count * (t + 1) / nt); });
+      started = t + 1;
+    }
+  } catch (...) {                                // no more threads to be had: the remaining slices run here
+  }
+  fn((size_t)0, count / nt);
+  for (size_t t = started; t < nt; ++t) fn(count * t / nt, count * (t + 1) / nt);
+  for (auto& x : th) x.join();
+}
+
+// Host -> device copy of a caller's (pageable) array.  Large ones go through two pinned bounce buffers: host threads fill one
+// while the DMA engine drains the other -- hipMemcpy from pageable memory alone ran at a few GB/s and made
+// admm_update_problem of 4096 x 1000 per-instance stages a 0.7 s call (round 2).
+constexpr size_t PIN_BYTES = (size_t)32 << 20;
+int upload_h2d(admm_handle* h, void* dst, const void* src, size_t bytes) {
+  if (bytes < 2 * PIN_BYTES) {
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream));
+    return ADMM_OK;
+  }
+  for (int i = 0; i < 2; ++i) {
+    if (!h->pin[i]) HIP_TRY(hipHostMalloc((void**)&h->pin[i], PIN_BYTES, hipHostMallocDefault));
+    if (!h->pin_ev[i]) HIP_TRY(hipEventCreateWithFlags(&h->pin_ev[i], hipEventDisableTiming));
+  }
+  int slot = 0;
+  for (size_t off = 0; off < bytes; off += PIN_BYTES, slot ^= 1) {
+    const size_t len = std::min(PIN_BYTES, bytes - off);
+    HIP_TRY(hipEventSynchronize(h->pin_ev[slot]));            // the copy that last read this buffer is done (no-op if never recorded)
+    unsigned char* pb = h->pin[slot];
+    const unsigned char* sb = static_cast<const unsigned char*>(src) + off;
+    host_parallel(len, 1, [pb, sb](size_t b, size_t e) { std::memcpy(pb + b, sb + b, e - b); });
+    HIP_TRY(hipMemcpyAsync(static_cast<unsigned char*>(dst) + off, pb, len, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipEventRecord(h->pin_ev[slot], h->stream));
+  }
+  return ADMM_OK;
+}
+
 // QP-major host array (batch x rows) -> batch-minor device array (rows x pitch)
 int upload_transposed(admm_handle* h, const double* src, double* dst, int rows) {
   if ((size_t)rows > h->stage_rows) return fail(ADMM_ERR_INVALID, "internal: staging buffer too small");
-  HIP_TRY(hipMemcpyAsync(h->stage, src, sizeof(double) * (size_t)rows * h->batch, hipMemcpyHostToDevice, h->stream));
+  int rc_up;
+  if ((rc_up = upload_h2d(h, h->stage, src, sizeof(double) * (size_t)rows * h->batch))) return rc_up;
   dim3 grid((rows + admm::T_TILE - 1) / admm::T_TILE, (h->pitch + admm::T_TILE - 1) / admm::T_TILE), block(admm::T_TILE * 8);
   hipLaunchKernelGGL(admm::to_batch_minor_kernel, grid, block, 0, h->stream, h->stage, dst, h->batch, rows, h->pitch);
   HIP_TRY(hipGetLastError());
@@ -449,10 +508,19 @@ int download_transposed(admm_handle* h, const double* src, double* dst, int rows
   return ADMM_OK;
 }
 
-bool finite_all(const double* a, size_t cnt) {
-  for (size_t i = 0; i < cnt; ++i)
-    if (!std::isfinite(a[i])) return false;
-  return true;
+bool finite_all(const double* a, size_t cnt) {          // (threaded from ~1 M entries: 2.7 GB of problem data at 4096 x 1000 stages)
+  std::atomic<bool> ok{true};
+  host_parallel(cnt, sizeof(double), [a, &ok](size_t b, size_t e) {
+    // |x| < inf  <=>  finite; the exponent test on the bit pattern vectorises (isfinite in a loop with an early exit does not)
+    uint64_t bad = 0;
+    for (size_t i = b; i < e; ++i) {
+      uint64_t u;
+      std::memcpy(&u, a + i, sizeof u);
+      bad |= ((u >> 52) & 0x7ff) == 0x7ff;
+    }
+    if (bad) ok.store(false, std::memory_order_relaxed);
+  });
+  return ok.load();
 }
 
 int validate_options(const admm_options* o) {
@@ -493,10 +561,23 @@ int validate_problem(const admm_problem* p) {
       return fail(ADMM_ERR_INVALID, "non-finite entry in A, B, Q, R or QN");
   }
   const size_t nbnd = (size_t)nb * (p->stage_bounds ? p->N : 1) * (p->stage_bounds == 2 ? p->batch : 1);
-  for (size_t i = 0; i < nbnd; ++i) {
-    if (std::isnan(p->lo[i]) || std::isnan(p->hi[i])) return fail(ADMM_ERR_INVALID, "NaN in bounds");
-    if (p->lo[i] > p->hi[i]) return fail(ADMM_ERR_INVALID, "lo > hi at bound index " + std::to_string(i));
-    if (p->lo[i] == INFINITY || p->hi[i] == -INFINITY) return fail(ADMM_ERR_INVALID, "lo = +inf or hi = -inf");
+  {
+    std::atomic<size_t> first_bad{SIZE_MAX};         // smallest offending index (threads take disjoint ranges)
+    const double *lo = p->lo, *hi = p->hi;
+    host_parallel(nbnd, 2 * sizeof(double), [lo, hi, &first_bad](size_t b, size_t e) {
+      for (size_t i = b; i < e; ++i)
+        if (!(lo[i] <= hi[i]) || lo[i] == INFINITY || hi[i] == -INFINITY) {      // (!(<=) also catches NaN)
+          size_t cur = first_bad.load();
+          while (i < cur && !first_bad.compare_exchange_weak(cur, i)) {}
+          return;
+        }
+    });
+    const size_t i = first_bad.load();
+    if (i != SIZE_MAX) {
+      if (std::isnan(p->lo[i]) || std::isnan(p->hi[i])) return fail(ADMM_ERR_INVALID, "NaN in bounds");
+      if (p->lo[i] > p->hi[i]) return fail(ADMM_ERR_INVALID, "lo > hi at bound index " + std::to_string(i));
+      return fail(ADMM_ERR_INVALID, "lo = +inf or hi = -inf");
+    }
   }
   if (p->unorm) {
     const int cnt = p->stage_bounds ? p->N : 1;
@@ -570,7 +651,10 @@ void release(admm_handle* h) {
   for (auto b : bufs)
     if (*b) { (void)hipFree(*b); *b = nullptr; }
   {
-    double** pb[] = {&h->Ad, &h->Bd, &h->Kd, &h->Sd, &h->lod, &h->hid, &h->Qd, &h->Rd, &h->QNd};
+    double** pb[] = {&h->Ad, &h->Bd, &h->Kd, &h->Sd, &h->lod, &h->hid, &h->Qd, &h->Rd, &h->QNd,
+                     &h->Ad2, &h->Bd2, &h->Kd2, &h->Sd2, &h->Qd2, &h->Rd2, &h->QNd2, &h->rho2_d};
+    if (h->qflag_d) { (void)hipFree(h->qflag_d); h->qflag_d = nullptr; }
+    if (h->nveto_d) { (void)hipFree(h->nveto_d); h->nveto_d = nullptr; }
     for (auto b : pb)
       if (*b) { (void)hipFree(*b); *b = nullptr; }
     if (h->pfail) { (void)hipFree(h->pfail); h->pfail = nullptr; }
@@ -596,6 +680,10 @@ void release(admm_handle* h) {
   for (auto b : ibufs)
     if (*b) { (void)hipFree(*b); *b = nullptr; }
   if (h->h_nconv) { (void)hipHostFree(h->h_nconv); h->h_nconv = nullptr; }
+  for (int i = 0; i < 2; ++i) {
+    if (h->pin[i]) { (void)hipHostFree(h->pin[i]); h->pin[i] = nullptr; }
+    if (h->pin_ev[i]) { (void)hipEventDestroy(h->pin_ev[i]); h->pin_ev[i] = nullptr; }
+  }
   if (h->stream) { (void)hipStreamDestroy(h->stream); h->stream = nullptr; }
   delete h;
 }
@@ -758,20 +846,26 @@ int pinst_fill_rho(admm_handle* h, double rho) {
   return ADMM_OK;
 }
 
-// shared weights as row-major device arrays; A, B, bounds per instance
-int pinst_upload(admm_handle* h, const admm_problem* p) {
+// shared weights as row-major device arrays + A, B per instance, into the given buffers (the handle's, or the trial set)
+int pinst_upload_dynamics(admm_handle* h, const admm_problem* p, double* Ad, double* Bd, double* Qd, double* Rd, double* QNd) {
   const int n = h->n, m = h->m;
   std::vector<double> Q((size_t)n * n), R((size_t)m * m), QN((size_t)n * n);
   for (int i = 0; i < n; ++i)
     for (int j = 0; j < n; ++j) { Q[(size_t)i * n + j] = 0.5 * (p->Q[(size_t)j * n + i] + p->Q[(size_t)i * n + j]); QN[(size_t)i * n + j] = 0.5 * (p->QN[(size_t)j * n + i] + p->QN[(size_t)i * n + j]); }
   for (int i = 0; i < m; ++i)
     for (int j = 0; j < m; ++j) R[(size_t)i * m + j] = 0.5 * (p->R[(size_t)j * m + i] + p->R[(size_t)i * m + j]);
-  HIP_TRY(hipMemcpy(h->Qd, Q.data(), sizeof(double) * Q.size(), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(h->Rd, R.data(), sizeof(double) * R.size(), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(h->QNd, QN.data(), sizeof(double) * QN.size(), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(Qd, Q.data(), sizeof(double) * Q.size(), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(Rd, R.data(), sizeof(double) * R.size(), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(QNd, QN.data(), sizeof(double) * QN.size(), hipMemcpyHostToDevice));
   int rc;
-  if ((rc = upload_transposed(h, p->A, h->Ad, h->N * n * n))) return rc;
-  if ((rc = upload_transposed(h, p->B, h->Bd, h->N * n * m))) return rc;
+  if ((rc = upload_transposed(h, p->A, Ad, h->N * n * n))) return rc;
+  if ((rc = upload_transposed(h, p->B, Bd, h->N * n * m))) return rc;
+  return ADMM_OK;
+}
+
+// the box (per instance or shared) and the thrust-magnitude bounds
+int pinst_upload_bounds(admm_handle* h, const admm_problem* p) {
+  int rc;
   if (h->pbounds) {
     if ((rc = upload_transposed(h, p->lo, h->lod, h->L))) return rc;
     if ((rc = upload_transposed(h, p->hi, h->hid, h->L))) return rc;
@@ -782,6 +876,69 @@ int pinst_upload(admm_handle* h, const admm_problem* p) {
   } else if ((rc = upload_bounds(h, p))) {
     return rc;
   }
+  return ADMM_OK;
+}
+
+int pinst_upload(admm_handle* h, const admm_problem* p) {
+  int rc;
+  if ((rc = pinst_upload_dynamics(h, p, h->Ad, h->Bd, h->Qd, h->Rd, h->QNd))) return rc;
+  return pinst_upload_bounds(h, p);
+}
+
+// Trial buffers (see admm_handle): K / S always, A / B / weights when the problem data change.
+int pinst_alloc_trial(admm_handle* h, bool dynamics) {
+  const size_t P = h->pitch;
+  const int n = h->n, m = h->m, N = h->N;
+  int rc;
+  if (!h->Kd2 && (rc = dalloc(&h->Kd2, (size_t)N * m * n * P))) return rc;
+  if (!h->Sd2 && (rc = dalloc(&h->Sd2, (size_t)N * m * m * P))) return rc;
+  if (!h->rho2_d && (rc = dalloc(&h->rho2_d, P))) return rc;
+  if (!h->qflag_d && (rc = dalloc(&h->qflag_d, P))) return rc;
+  if (!h->nveto_d && (rc = dalloc(&h->nveto_d, (size_t)1))) return rc;
+  if (dynamics) {
+    if (!h->Ad2 && (rc = dalloc(&h->Ad2, (size_t)N * n * n * P))) return rc;
+    if (!h->Bd2 && (rc = dalloc(&h->Bd2, (size_t)N * n * m * P))) return rc;
+    if (!h->Qd2 && (rc = dalloc(&h->Qd2, (size_t)n * n))) return rc;
+    if (!h->Rd2 && (rc = dalloc(&h->Rd2, (size_t)m * m))) return rc;
+    if (!h->QNd2 && (rc = dalloc(&h->QNd2, (size_t)n * n))) return rc;
+  }
+  return ADMM_OK;
+}
+
+// TRIAL factorisation: the Riccati recursion of the QPs marked in `todo` (NULL = all) with the given dynamics, weights and rho
+// into the trial K / S, then -- with segments -- the transfer matrices WITHOUT storing them.  Leaves one verdict per QP in
+// qflag_d (bit 0: some S_k not positive definite, bit 1: a transfer matrix beyond the conditioning bound) and returns how many
+// real QPs carry each bit.  Nothing the iteration reads is written.
+int pinst_try(admm_handle* h, const double* Ad, const double* Bd, const double* Qd, const double* Rd, const double* QNd,
+              const double* rhov, const int* todo, int* n_not_pd, int* n_grown) {
+  admm::PLaunch l = plaunch_of(h);
+  l.Ad = Ad; l.Bd = Bd; l.Q = Qd; l.R = Rd; l.QN = QNd; l.rhov = rhov; l.todo = todo;
+  l.Kd = h->Kd2; l.Sd = h->Sd2; l.qflag = h->qflag_d;
+  l.Omd = nullptr; l.Psd = nullptr; l.Segd = nullptr;
+  HIP_TRY(hipMemsetAsync(h->qflag_d, 0, sizeof(int) * (size_t)h->pitch, h->stream));
+  HIP_TRY(hipMemsetAsync(h->pfail, 0, sizeof(int), h->stream));
+  HIP_TRY(hipMemsetAsync(h->pgrow, 0, sizeof(int), h->stream));
+  if (!admm::launch_pinst(l, admm::PKernel::FACTOR, false)) return fail(ADMM_ERR_UNSUPPORTED, "no per-instance kernel for this (n, m)");
+  HIP_TRY(hipGetLastError());
+  if (h->S > 1) {
+    admm::launch_pinst(l, admm::PKernel::SEGMENTS, false);
+    HIP_TRY(hipGetLastError());
+  }
+  std::vector<int> q(h->pitch);
+  HIP_TRY(hipMemcpyAsync(q.data(), h->qflag_d, sizeof(int) * q.size(), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  *n_not_pd = *n_grown = 0;
+  for (int b = 0; b < h->batch; ++b) { *n_not_pd += q[b] & 1; *n_grown += (q[b] >> 1) & 1; }
+  return ADMM_OK;
+}
+
+// Segment transfer matrices of the factor in force (after a committed change; cannot fail: the trial run has checked them).
+int pinst_segments(admm_handle* h) {
+  if (h->S <= 1) return ADMM_OK;
+  HIP_TRY(hipMemsetAsync(h->pgrow, 0, sizeof(int), h->stream));
+  admm::PLaunch l = plaunch_of(h);
+  admm::launch_pinst(l, admm::PKernel::SEGMENTS, false);
+  HIP_TRY(hipGetLastError());
   return ADMM_OK;
 }
 
@@ -1319,7 +1476,9 @@ static admm_problem shared_problem(const admm_handle* h) {
 // so every iterate -- is the one a synchronous refactor would produce.  ADMM_NO_SPECULATE=1 turns this off.
 static bool spec_enabled(const admm_handle* h) {
   const bool off = std::getenv("ADMM_NO_SPECULATE") != nullptr;     // read per call: tests switch it within a process
-  return !off && !h->pinst && h->opt.adapt_interval > 0 && h->rho_updates < h->opt.adapt_max;
+  // (only inside a solve: a caller sweeping admm_set_rho on an adaptive handle outside one must not accumulate a full Factor
+  //  copy per call -- ADVICE r02)
+  return !off && h->solve_active && !h->pinst && h->opt.adapt_interval > 0 && h->rho_updates < h->opt.adapt_max;
 }
 
 static void spec_reap(admm_handle* h, bool all) {          // drop stale entries whose thread has finished (all: join them)
@@ -1398,11 +1557,26 @@ static int set_rho_internal(admm_handle* h, double rho_new) {
   if (!(rho_new > 0.0) || !std::isfinite(rho_new)) return fail(ADMM_ERR_INVALID, "rho must be positive and finite");
   if (rho_new == h->opt.rho && !h->pinst) return ADMM_OK;     // (per-instance: the QPs' own rho may have moved away from it)
   if (h->pinst) {
-    // every QP's rho := rho_new (the per-QP adaptive rule may have moved them apart): y_b *= rho_b / rho_new
+    // every QP's rho := rho_new (the per-QP adaptive rule may have moved them apart): y_b *= rho_b / rho_new.
+    // TRIAL first: the factor of rho_new goes into the scratch K / S and the conditioning bound is evaluated without storing
+    // anything; only a change that passes is committed (pointer swap), so a refused one leaves the handle untouched.
     int rc;
-    if ((rc = ensure_w(h))) return rc;          // w of the last x-update must be rebuilt with the OLD factor
-    if ((rc = ensure_zy(h))) return rc;
+    if ((rc = pinst_alloc_trial(h, false))) return rc;
     const size_t P = h->pitch;
+    {
+      std::vector<double> cand(P, rho_new);
+      HIP_TRY(hipMemcpyAsync(h->rho2_d, cand.data(), sizeof(double) * P, hipMemcpyHostToDevice, h->stream));
+      HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    int not_pd = 0, grown = 0;
+    if ((rc = pinst_try(h, h->Ad, h->Bd, h->Qd, h->Rd, h->QNd, h->rho2_d, nullptr, &not_pd, &grown))) return rc;
+    if (not_pd) return fail(ADMM_ERR_NUMERIC, "rho change refused: R + rho I + B'PB is not positive definite for " + std::to_string(not_pd) + " QP(s)");
+    if (grown && h->auto_segments)
+      return fail(ADMM_ERR_NUMERIC, "rho change refused: with this rho the segment transfer matrices of " + std::to_string(grown) +
+                                        " QP(s) grow beyond the conditioning bound (max entry > 100) with the handle's " +
+                                        std::to_string(h->S) + " segments; use options.segments = 1");
+    if ((rc = ensure_w(h))) return rc;          // w of the last x-update must be rebuilt with the OLD factor (still in place)
+    if ((rc = ensure_zy(h))) return rc;
     std::vector<double> old(P), c(P);
     HIP_TRY(hipMemcpyAsync(old.data(), h->rho_d, sizeof(double) * P, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
@@ -1414,18 +1588,10 @@ static int set_rho_internal(admm_handle* h, double rho_new) {
     HIP_TRY(hipGetLastError());
     h->zy_valid = true;
     h->v_valid = false;
-    if ((rc = pinst_fill_rho(h, rho_new))) return rc;
-    if ((rc = pinst_factor(h))) {                 // refactor in place failed: restore the old factors and the dual
-      std::string keep = g_err;
-      for (size_t b = 0; b < P; ++b) c[b] = rho_new / old[b];
-      (void)hipMemcpyAsync(h->cscale_d, c.data(), sizeof(double) * P, hipMemcpyHostToDevice, h->stream);
-      admm::launch_padapt_scale(h->stream, h->y, h->cscale_d, h->todo_d, h->L, h->pitch);
-      (void)hipMemcpyAsync(h->rho_d, old.data(), sizeof(double) * P, hipMemcpyHostToDevice, h->stream);
-      (void)hipStreamSynchronize(h->stream);
-      (void)pinst_factor(h);
-      g_err = keep;
-      return rc;
-    }
+    if ((rc = pinst_fill_rho(h, rho_new))) return rc;       // (synchronises: the kernels of the old factor are done)
+    std::swap(h->Kd, h->Kd2);                               // commit
+    std::swap(h->Sd, h->Sd2);
+    if ((rc = pinst_segments(h))) return rc;
     h->opt.rho = rho_new;
     return ADMM_OK;
   }
@@ -1473,10 +1639,14 @@ static int set_rho_internal(admm_handle* h, double rho_new) {
   HIP_TRY(hipStreamSynchronize(h->stream));                // kernels of the old rho are done before the records change
   lap("state to (z, y), sync");
   if (spec_enabled(h)) {                                   // the rule may come back to the rho it leaves: keep that factor
-    std::unique_ptr<SpecFactor> old(new SpecFactor);
-    old->rho = h->opt.rho;
-    old->f = std::move(h->fac);
-    h->spec.push_back(std::move(old));
+    bool have = false;                                     // (once: spec_take returns the first entry of a rho)
+    for (auto& sp2 : h->spec) have = have || sp2->rho == h->opt.rho;
+    if (!have) {
+      std::unique_ptr<SpecFactor> old(new SpecFactor);
+      old->rho = h->opt.rho;
+      old->f = std::move(h->fac);
+      h->spec.push_back(std::move(old));
+    }
   }
   h->fac = std::move(f);
   lap("keep / move factor");
@@ -1509,16 +1679,30 @@ int admm_update_problem(admm_handle* h, const admm_problem* p) {
   if ((p->time_varying == 2) != h->pinst || (h->pinst && (p->stage_bounds == 2) != h->pbounds))
     return fail(ADMM_ERR_INVALID, "admm_update_problem: per-instance dynamics / bounds cannot be added to or removed from a handle");
   if (h->pinst) {
-    if ((rc = ensure_w(h))) return rc;           // w of the last x-update belongs to the old problem data
+    // TRIAL first: the new dynamics and weights go into the scratch buffers and are factorised there, every QP
+    // with the rho it has; only if every factor exists and meets the conditioning bound is anything of the handle replaced
+    // (pointer swaps) -- "on failure the handle is unchanged" holds for this mode as for shared dynamics.
+    if ((rc = pinst_alloc_trial(h, true))) return rc;
+    if ((rc = pinst_upload_dynamics(h, p, h->Ad2, h->Bd2, h->Qd2, h->Rd2, h->QNd2))) return rc;
+    int not_pd = 0, grown = 0;
+    if ((rc = pinst_try(h, h->Ad2, h->Bd2, h->Qd2, h->Rd2, h->QNd2, h->rho_d, nullptr, &not_pd, &grown))) return rc;
+    if (not_pd) return fail(ADMM_ERR_NUMERIC, "problem update refused: R + rho I + B'PB is not positive definite for " + std::to_string(not_pd) + " QP(s)");
+    if (grown && h->auto_segments)
+      return fail(ADMM_ERR_NUMERIC, "problem update refused: the new dynamics make the segment transfer matrices of " + std::to_string(grown) +
+                                        " QP(s) grow beyond the conditioning bound (max entry > 100) with the handle's " +
+                                        std::to_string(h->S) + " segments; set up a new handle or use options.segments = 1");
+    if ((rc = ensure_w(h))) return rc;           // w of the last x-update belongs to the old problem data (still in place)
     if ((rc = ensure_zy(h))) return rc;
     h->zy_valid = true;
     h->v_valid = false;
     HIP_TRY(hipStreamSynchronize(h->stream));
+    std::swap(h->Ad, h->Ad2); std::swap(h->Bd, h->Bd2); std::swap(h->Kd, h->Kd2); std::swap(h->Sd, h->Sd2);      // commit
+    std::swap(h->Qd, h->Qd2); std::swap(h->Rd, h->Rd2); std::swap(h->QNd, h->QNd2);
     h->stage_bounds = p->stage_bounds;
-    if ((rc = pinst_upload(h, p))) return rc;
+    if ((rc = pinst_upload_bounds(h, p))) return rc;
     if ((rc = upload_transposed(h, p->x0, h->x0, h->n))) return rc;
     if (h->has_q && (rc = upload_transposed(h, p->q, h->q, h->L))) return rc;
-    return pinst_factor(h);                      // every QP with the rho it has
+    return pinst_segments(h);                    // transfer matrices of the new factor
   }
   admm::Factor f;
   std::string err;
@@ -1699,6 +1883,7 @@ int admm_solve_begin(admm_handle* h, const double* z0, const double* y0) {
   h->history.clear();
   if (h->pinst) HIP_TRY(hipMemsetAsync(h->nupd_d, 0, sizeof(int) * P, h->stream));
   h->spec_hits = h->spec_misses = 0;
+  h->solve_active = true;
   spec_start(h);                               // adaptive rule: factorise rho tau and rho / tau while the GPU iterates
   h->solve_it = 0;
   h->solve_nconv = 0;
@@ -1792,13 +1977,34 @@ int admm_solve_adapt(admm_handle* h, double R, double S, int32_t* changed) {
     // batch sums of the shared-factor rule -- are not used, so a sharded solve needs no exchange for it.
     int rc;
     HIP_TRY(hipMemsetAsync(h->nchanged_d, 0, sizeof(int), h->stream));
+    if ((rc = pinst_alloc_trial(h, false))) return rc;
     admm::launch_padapt(h->stream, h->resid, h->status, h->rho_d, h->nupd_d, h->todo_d, h->cscale_d, h->nchanged_d, mu2,
-                        h->opt.adapt_tau, h->opt.adapt_max, h->pitch, h->batch);
+                        h->opt.adapt_tau, h->opt.adapt_max, h->pitch, h->batch, h->rho2_d);
     HIP_TRY(hipGetLastError());
     int nchanged = 0;
     HIP_TRY(hipMemcpyAsync(&nchanged, h->nchanged_d, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     if (!nchanged) return ADMM_OK;
+    if (h->S > 1 && h->auto_segments) {
+      // the candidates are factorised on trial (scratch K / S, transfer matrices not stored); a QP whose new rho
+      // breaks the conditioning bound of its segments -- or has no factor -- keeps its rho and stops adapting, before its dual
+      // is rescaled or its factor touched: what the batch-level rule does for shared dynamics.
+      int not_pd = 0, grown = 0;
+      if ((rc = pinst_try(h, h->Ad, h->Bd, h->Qd, h->Rd, h->QNd, h->rho_d, h->todo_d, &not_pd, &grown))) return rc;
+      if (not_pd || grown) {
+        int nveto = 0;
+        HIP_TRY(hipMemsetAsync(h->nveto_d, 0, sizeof(int), h->stream));
+        admm::launch_padapt_veto(h->stream, h->qflag_d, h->rho2_d, h->rho_d, h->nupd_d, h->todo_d, h->cscale_d, h->nchanged_d,
+                                 h->nveto_d, h->opt.adapt_max, h->pitch);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(&nveto, h->nveto_d, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipMemcpyAsync(&nchanged, h->nchanged_d, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        g_warn = "adaptive rho: the change of " + std::to_string(nveto) + " QP(s) was refused (segment transfer matrices beyond the "
+                 "conditioning bound, or no factor, with the new rho); those QPs keep their rho and stop adapting for this solve";
+        if (!nchanged) return ADMM_OK;
+      }
+    }
     if ((rc = ensure_w(h))) return rc;            // w of the last x-update is rebuilt with the OLD factors (rho is not used)
     if ((rc = ensure_zy(h))) return rc;
     admm::launch_padapt_scale(h->stream, h->y, h->cscale_d, h->todo_d, h->L, h->pitch);
@@ -1838,6 +2044,10 @@ int admm_solve_end(admm_handle* h, admm_info* info) {
     std::fprintf(stderr, "[admm] rho changes served by a background / kept factor: %d, factorised on demand: %d\n", h->spec_hits, h->spec_misses);
   HIP_TRY(hipStreamSynchronize(h->stream));
   h->iters_run = h->solve_it;
+  h->solve_active = false;                      // candidates of the adaptive rule are not kept between solves (their threads
+  for (auto& sp2 : h->spec) h->spec_stale.push_back(std::move(sp2));      // are joined lazily, or by admm_free / admm_update_problem)
+  h->spec.clear();
+  spec_reap(h, false);
   if (h->opt.precision_mode == ADMM_PRECISION_MIXED) {
     if (h->mixed_phase1) h->mixed_iters = h->solve_it;
     h->mixed_phase1 = false;

@@ -55,6 +55,7 @@ struct PLaunch {
   const double *Ad, *Bd, *Q, *R, *QN;  // Q, R, QN: shared, row-major, on the device
   double *Kd, *Sd;
   int* fail;
+  int* qflag;                          // FACTOR / SEGMENTS trial runs: per-QP verdict [pitch] (bit 0: S_k not PD, bit 1: conditioning bound), or NULL
   const double *lo, *hi;
   const double *z, *y, *q, *x0;
   double *v, *w, *dbuf, *part;
@@ -71,7 +72,9 @@ struct PLaunch {
 enum class PKernel { FACTOR, XB, XF, XFZ, SEGMENTS, SCAN };
 bool launch_pinst(const PLaunch& l, PKernel k, bool query_only);
 void launch_padapt(hipStream_t stream, const double* resid, const int* status, double* rhov, int* nupd, int* todo,
-                   double* cscale, int* nchanged, double mu2, double tau, int adapt_max, int pitch, int batch);
+                   double* cscale, int* nchanged, double mu2, double tau, int adapt_max, int pitch, int batch, double* rho_prev);
+void launch_padapt_veto(hipStream_t stream, const int* qflag, const double* rho_prev, double* rhov, int* nupd, int* todo,
+                        double* cscale, int* nchanged, int* nveto, int adapt_max, int pitch);
 void launch_padapt_scale(hipStream_t stream, double* y, const double* cscale, const int* todo, int rows, int pitch);
 void launch_pv_to_zy(hipStream_t stream, const double* v, double* z, double* y, const double* lo, const double* hi, size_t count);
 void launch_pv_to_zy_soc(hipStream_t stream, const double* v, double* z, double* y, const double* lo, const double* hi,

@@ -8,6 +8,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <exception>
+#include <mutex>
 #include <thread>
 
 namespace admm {
@@ -53,17 +55,31 @@ void parallel_for(int count, F&& fn) {          // fn(begin, end) over a partiti
   if (nt <= 1) { fn(0, count); return; }
   std::vector<std::thread> th;
   th.reserve(nt - 1);
+  // An exception in a worker (std::bad_alloc from a Mat: large N, n = 12, 16 threads x two background factorisations) must
+  // not reach std::terminate: the first one is kept, every worker is joined, then it is rethrown on the calling thread --
+  // factorise() and the background threads of admm_api.hip turn it into ADMM_ERR_ALLOC.
+  std::exception_ptr first;
+  std::mutex first_mu;
+  auto guarded = [&fn, &first, &first_mu](int b, int e) {
+    try {
+      fn(b, e);
+    } catch (...) {
+      std::lock_guard<std::mutex> g(first_mu);
+      if (!first) first = std::current_exception();
+    }
+  };
   int started = 1;                               // slices [0, started) have an owner (slice 0 = this thread)
   try {
     for (int t = 1; t < nt; ++t) {
-      th.emplace_back([&fn, t, nt, count] { fn((int)((int64_t)count * t / nt), (int)((int64_t)count * (t + 1) / nt)); });
+      th.emplace_back([&guarded, t, nt, count] { guarded((int)((int64_t)count * t / nt), (int)((int64_t)count * (t + 1) / nt)); });
       started = t + 1;
     }
   } catch (...) {                                // no more threads to be had: the remaining slices run here
   }
-  fn(0, count / nt);
-  for (int t = started; t < nt; ++t) fn((int)((int64_t)count * t / nt), (int)((int64_t)count * (t + 1) / nt));
+  guarded(0, count / nt);
+  for (int t = started; t < nt; ++t) guarded((int)((int64_t)count * t / nt), (int)((int64_t)count * (t + 1) / nt));
   for (auto& x : th) x.join();
+  if (first) std::rethrow_exception(first);
 }
 
 // c (p x r) = a (p x q) b (q x r).  Every output element is summed over k in ascending order from 0.0, whatever the
@@ -772,7 +788,7 @@ void build_mfma(Factor& f, int mode) {
 
 void set_factor_thread_cap(int cap) { g_thread_cap = cap; }
 
-int factorise(const admm_problem& p, double rho, int segments, Factor& f, std::string& err, int mfma_mode, bool pack_scan_mfma) {
+static int factorise_impl(const admm_problem& p, double rho, int segments, Factor& f, std::string& err, int mfma_mode, bool pack_scan_mfma) {
   if (mfma_mode < 0 || mfma_mode > 2) { err = "mfma_mode must be 0, 1 or 2"; return ADMM_ERR_INVALID; }
   if (mfma_mode != 0 && !mfma_dims(p.n, p.m)) { err = "the MFMA form needs n <= 12 and m <= 8"; return ADMM_ERR_UNSUPPORTED; }
   const int N = p.N, n = p.n, m = p.m;
@@ -951,6 +967,19 @@ int factorise(const admm_problem& p, double rho, int segments, Factor& f, std::s
   if (mfma_mode) build_mfma(f, mfma_mode);
   timer.lap("mfma records");
   return ADMM_OK;
+}
+
+// No exception leaves the factorisation (C ABI above it; worker threads below it -- parallel_for rethrows theirs here).
+int factorise(const admm_problem& p, double rho, int segments, Factor& f, std::string& err, int mfma_mode, bool pack_scan_mfma) {
+  try {
+    return factorise_impl(p, rho, segments, f, err, mfma_mode, pack_scan_mfma);
+  } catch (const std::bad_alloc&) {
+    err = "out of host memory in the KKT factorisation";
+    return ADMM_ERR_ALLOC;
+  } catch (const std::exception& e) {
+    err = std::string("KKT factorisation: ") + e.what();
+    return ADMM_ERR_ALLOC;
+  }
 }
 
 }  // namespace admm

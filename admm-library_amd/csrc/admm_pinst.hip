@@ -22,9 +22,15 @@ const char* dims_pinst() {
 }
 
 void launch_padapt(hipStream_t stream, const double* resid, const int* status, double* rhov, int* nupd, int* todo,
-                   double* cscale, int* nchanged, double mu2, double tau, int adapt_max, int pitch, int batch) {
+                   double* cscale, int* nchanged, double mu2, double tau, int adapt_max, int pitch, int batch, double* rho_prev) {
   hipLaunchKernelGGL(padapt_kernel, dim3((pitch + 255) / 256), dim3(256), 0, stream, resid, status, rhov, nupd, todo, cscale,
-                     nchanged, mu2, tau, adapt_max, pitch, batch);
+                     nchanged, mu2, tau, adapt_max, pitch, batch, rho_prev);
+}
+
+void launch_padapt_veto(hipStream_t stream, const int* qflag, const double* rho_prev, double* rhov, int* nupd, int* todo,
+                        double* cscale, int* nchanged, int* nveto, int adapt_max, int pitch) {
+  hipLaunchKernelGGL(padapt_veto_kernel, dim3((pitch + 255) / 256), dim3(256), 0, stream, qflag, rho_prev, rhov, nupd, todo, cscale,
+                     nchanged, nveto, adapt_max, pitch);
 }
 
 void launch_padapt_scale(hipStream_t stream, double* y, const double* cscale, const int* todo, int rows, int pitch) {

@@ -39,7 +39,9 @@ __global__ __launch_bounds__(PI_THREADS) void pfactor_kernel(
     const double* __restrict__ Ad, const double* __restrict__ Bd, const double* __restrict__ Qm,
     const double* __restrict__ Rm, const double* __restrict__ QNm, const double* __restrict__ rhov,
     const int* __restrict__ todo, double* __restrict__ Kd, double* __restrict__ Sd, int* __restrict__ fail, int N, int pitch,
-    int batch) {
+    int batch, int* __restrict__ qflag) {
+  // qflag (may be NULL): per-QP verdict of a TRIAL factorisation into scratch K / S (admm_api.hip, pinst_try): bit 0 = some
+  // S_k of this QP is not positive definite
   const int col = blockIdx.x * PI_THREADS + threadIdx.x;
   if (col >= pitch) return;
   if (todo && !todo[col]) return;           // per-QP adaptive rho: only the QPs whose rho has just changed are refactored
@@ -188,7 +190,10 @@ __global__ __launch_bounds__(PI_THREADS) void pfactor_kernel(
       for (int t = 0; t < NU; ++t) Sd[((size_t)k * NU * NU + j * NU + t) * P_ + col] = Si[j][t];
     }
   }
-  if (bad && real) atomicOr(fail, 1);
+  if (bad && real) {
+    atomicOr(fail, 1);
+    if (qflag) atomicOr(&qflag[col], 1);
+  }
 }
 
 // Thrust-magnitude bound ||u_k||_2 <= ub_k on the control rows of a block: the factor c with z_u = c v_u.
@@ -494,7 +499,9 @@ template <int NX, int NU>
 __global__ __launch_bounds__(PI_THREADS) void pseg_kernel(
     const double* __restrict__ Ad, const double* __restrict__ Bd, const double* __restrict__ Kd, const double* __restrict__ Sd,
     const int* __restrict__ seg_start, const int* __restrict__ todo, double* __restrict__ Omd, double* __restrict__ Psd,
-    double* __restrict__ Segd, int* __restrict__ grow, int pitch, int batch) {
+    double* __restrict__ Segd, int* __restrict__ grow, int pitch, int batch, int* __restrict__ qflag) {
+  // Omd == NULL: TRIAL run -- nothing is stored, only the conditioning verdict is formed (*grow, and per QP bit 1 of qflag)
+  const bool store = Omd != nullptr;
   const int col = blockIdx.x * PI_THREADS + threadIdx.x;
   if (col >= pitch) return;
   if (todo && !todo[col]) return;
@@ -549,13 +556,15 @@ __global__ __launch_bounds__(PI_THREADS) void pseg_kernel(
         for (int j = 0; j < NU; ++j) a = fma(Om[i][j], Ps[j][l], a);
         Xi[i][l] = a;
       }
+    if (store) {
 #pragma unroll
-    for (int i = 0; i < NX; ++i)
+      for (int i = 0; i < NX; ++i)
 #pragma unroll
-      for (int j = 0; j < NU; ++j) {
-        Omd[((size_t)k * NX * NU + i * NU + j) * P_ + col] = Om[i][j];
-        Psd[((size_t)k * NU * NX + j * NX + i) * P_ + col] = Ps[j][i];
-      }
+        for (int j = 0; j < NU; ++j) {
+          Omd[((size_t)k * NX * NU + i * NU + j) * P_ + col] = Om[i][j];
+          Psd[((size_t)k * NU * NX + j * NX + i) * P_ + col] = Ps[j][i];
+        }
+    }
     // Lam <- Lam (A - B K)
     double Acl[NX][NX];
 #pragma unroll
@@ -588,12 +597,17 @@ __global__ __launch_bounds__(PI_THREADS) void pseg_kernel(
   for (int i = 0; i < NX; ++i)
 #pragma unroll
     for (int l = 0; l < NX; ++l) {
-      sd[((size_t)0 * NX * NX + i * NX + l) * P_ + col] = Lam[l][i];     // Phi = Lam'
-      sd[((size_t)1 * NX * NX + i * NX + l) * P_ + col] = Xi[i][l];
-      sd[((size_t)2 * NX * NX + i * NX + l) * P_ + col] = Lam[i][l];     // Th
+      if (store) {
+        sd[((size_t)0 * NX * NX + i * NX + l) * P_ + col] = Lam[l][i];     // Phi = Lam'
+        sd[((size_t)1 * NX * NX + i * NX + l) * P_ + col] = Xi[i][l];
+        sd[((size_t)2 * NX * NX + i * NX + l) * P_ + col] = Lam[i][l];     // Th
+      }
       big = fmax(big, fmax(fabs(Lam[i][l]), fabs(Xi[i][l])));
     }
-  if (col < batch && !(big <= 100.0)) atomicOr(grow, 1);
+  if (col < batch && !(big <= 100.0)) {
+    atomicOr(grow, 1);
+    if (qflag) atomicOr(&qflag[col], 2);
+  }
 }
 
 // Segment scan, per QP (both chains are S sequential n x n mat-vecs with the QP's own matrices):
@@ -722,11 +736,12 @@ __global__ __launch_bounds__(PI_THREADS) void pscan_kernel(
 static __global__ __launch_bounds__(256) void padapt_kernel(
     const double* __restrict__ resid, const int* __restrict__ status, double* __restrict__ rhov, int* __restrict__ nupd,
     int* __restrict__ todo, double* __restrict__ cscale, int* __restrict__ nchanged, double mu2, double tau, int adapt_max,
-    int pitch, int batch) {
+    int pitch, int batch, double* __restrict__ rho_prev) {
   const int col = blockIdx.x * 256 + threadIdx.x;
   if (col >= pitch) return;
   int change = 0;
   double c = 1.0;
+  rho_prev[col] = rhov[col];                 // (padapt_veto_kernel puts it back if the new rho is refused)
   if (col < batch && !status[col] && nupd[col] < adapt_max) {
     const double r = resid[col], s_ = resid[(size_t)pitch + col];
     const double R = r * r, S = s_ * s_;
@@ -744,6 +759,24 @@ static __global__ __launch_bounds__(256) void padapt_kernel(
   todo[col] = change;
   cscale[col] = c;
   if (change) atomicAdd(nchanged, 1);
+}
+
+// The rule's change of a QP is REFUSED when the trial factorisation with its new rho fails or its segment transfer matrices
+// break the conditioning bound (qflag != 0; admm_api.hip, admm_solve_adapt): that QP keeps its rho and factor and stops
+// adapting -- what the batch-level rule does for shared dynamics.  Runs before anything of the change
+// (dual rescale, refactor) has been applied.
+static __global__ __launch_bounds__(256) void padapt_veto_kernel(const int* __restrict__ qflag, const double* __restrict__ rho_prev,
+                                                                 double* __restrict__ rhov, int* __restrict__ nupd, int* __restrict__ todo,
+                                                                 double* __restrict__ cscale, int* __restrict__ nchanged,
+                                                                 int* __restrict__ nveto, int adapt_max, int pitch) {
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= pitch || !todo[col] || !qflag[col]) return;
+  rhov[col] = rho_prev[col];
+  nupd[col] = adapt_max;
+  todo[col] = 0;
+  cscale[col] = 1.0;
+  atomicSub(nchanged, 1);
+  atomicAdd(nveto, 1);
 }
 
 // y[row][col] *= cscale[col] for the columns marked in todo (cscale = 1 elsewhere: those columns are not touched, so

@@ -19,7 +19,7 @@ void launch_dim(const PLaunch& l, PKernel k) {
   switch (k) {
     case PKernel::SEGMENTS:
       hipLaunchKernelGGL((pseg_kernel<NX, NU>), sgrid, block, 0, l.stream, l.Ad, l.Bd, l.Kd, l.Sd, l.seg_start, l.todo, l.Omd,
-                         l.Psd, l.Segd, l.grow, l.pitch, l.batch);
+                         l.Psd, l.Segd, l.grow, l.pitch, l.batch, l.qflag);
       break;
     case PKernel::SCAN:
       hipLaunchKernelGGL((pscan_kernel<NX>), dim3(l.pitch / PscanShape<NX>::QPW), block, 0, l.stream, l.Segd, l.tseg, l.eseg, l.x0,
@@ -27,7 +27,7 @@ void launch_dim(const PLaunch& l, PKernel k) {
       break;
     case PKernel::FACTOR:
       hipLaunchKernelGGL((pfactor_kernel<NX, NU>), grid, block, 0, l.stream, l.Ad, l.Bd, l.Q, l.R, l.QN, l.rhov, l.todo, l.Kd, l.Sd,
-                         l.fail, l.N, l.pitch, l.batch);
+                         l.fail, l.N, l.pitch, l.batch, l.qflag);
       break;
     case PKernel::XB: {
 #define XB(HQ, VF, PB_)                                                                                                          \

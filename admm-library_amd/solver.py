@@ -218,7 +218,10 @@ class Solver:
         """New shared data (dynamics, weights, box, x0, q) on this handle; same N, n, m, batch."""
         problem.validate()
         cp, keep = _abi.marshal_problem(problem)
+        import time
+        t0 = time.perf_counter()
         _check(self._lib, self._lib.admm_update_problem(self._h, C.byref(cp)))
+        self.last_update_ms = (time.perf_counter() - t0) * 1e3      # the C call alone (validation, upload, refactor)
         del keep
         self.problem = problem
         self._warn()

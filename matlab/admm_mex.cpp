@@ -16,6 +16,7 @@
 //   info = admm_mex('solve', h, z0, y0)          % z0, y0 optional / []
 //   [w, z, y] = admm_mex('get', h)
 //   admm_mex('iterate', h, iters)
+//   p    = admm_mex('path', h)                   % kernels in use, margin of the default path (admm_get_path)
 //   admm_mex('free', h)
 //
 // MATLAB arrays are column-major doubles, exactly the ABI's layout: A (n x n or
@@ -35,6 +36,9 @@ void fail(const char* id, const char* msg) { mexErrMsgIdAndTxt(id, "%s", msg); }
 
 void check(int rc) {
   if (rc != ADMM_OK) mexErrMsgIdAndTxt("admm:library", "libadmm_hip error %d: %s", rc, admm_last_error());
+  // a call that succeeded but changed the kernels the handle runs says so (ABI v6): pass it on as a MATLAB warning
+  const char* w = admm_last_warning();
+  if (w && w[0]) mexWarnMsgIdAndTxt("admm:path", "%s", w);
 }
 
 const mxArray* field(const mxArray* s, const char* name, bool required) {
@@ -224,6 +228,16 @@ void mexFunction(int nlhs, mxArray* plhs[], int nrhs, const mxArray* prhs[]) {
     mxSetField(plhs[0], 0, "max_r", r);
     mxSetField(plhs[0], 0, "max_s", s);
     mxSetField(plhs[0], 0, "rho", rho);
+  } else if (!std::strcmp(cmd, "path")) {         // admm_mex('path', h): which kernels the handle runs + the default path's margin
+    admm_path_info pi;
+    check(admm_get_path(h, &pi));
+    const char* names[] = {"alternating", "alt_requested", "mfma", "xfree", "segments", "auto_segments", "scan_form",
+                           "per_instance", "alt_check", "alt_gate", "scan_growth"};
+    plhs[0] = mxCreateStructMatrix(1, 1, 11, names);
+    const double vals[] = {(double)pi.alternating, (double)pi.alt_requested, (double)pi.mfma, (double)pi.xfree, (double)pi.segments,
+                           (double)pi.auto_segments, (double)pi.scan_form, (double)pi.per_instance, pi.alt_check, pi.alt_gate,
+                           pi.scan_growth};
+    for (int i = 0; i < 11; ++i) mxSetField(plhs[0], 0, names[i], mxCreateDoubleScalar(vals[i]));
   } else if (!std::strcmp(cmd, "iterate")) {
     if (nrhs < 3) fail("admm:input", "iterate needs an iteration count");
     check(admm_iterate(h, static_cast<int32_t>(mxGetScalar(prhs[2]))));

@@ -13,6 +13,7 @@ typedef size_t mwSize;
 typedef enum { mxREAL = 0, mxCOMPLEX = 1 } mxComplexity;
 typedef enum { mxDOUBLE_CLASS = 6, mxINT32_CLASS = 12, mxUINT64_CLASS = 15 } mxClassID;
 void mexErrMsgIdAndTxt(const char* id, const char* fmt, ...);
+void mexWarnMsgIdAndTxt(const char* id, const char* fmt, ...);
 int mexAtExit(void (*fn)(void));
 mxArray* mxGetField(const mxArray*, mwSize, const char*);
 bool mxIsEmpty(const mxArray*);

@@ -169,3 +169,71 @@ def test_flags_that_exclude_alternation_are_not_warnings(gpu):
     with pkg.Solver(p, pkg.Options(rho=0.05, flags=_abi.FLAG_NO_ALTERNATE)) as s:
         path = s.path()
         assert not path["alt_requested"] and not path["alternating"] and s.last_warning == ""
+
+
+# ---- per-instance dynamics: a refused change leaves the handle untouched; the per-QP adaptive rule keeps the conditioning bound
+# (admm_update_problem overwrote the device data before it knew the factor was acceptable; the masked refactor of the
+# per-QP rule ignored the bound)
+
+def _sensitive_instances(batch=5):
+    import dataclasses
+    base = _rho_sensitive_plant(batch=batch)
+    A = np.broadcast_to(base.A, (batch, base.N, 2, 2)).copy()
+    A[:, :, 0, 1] += 0.01 * np.arange(batch)[:, None]
+    B = np.broadcast_to(base.B, (batch, base.N, 2, 1)).copy()
+    return dataclasses.replace(base, A=A, B=B)
+
+
+def test_per_instance_update_problem_refused_leaves_the_handle_unchanged(gpu):
+    """admm_update_problem with dynamics whose segment transfer matrices break the conditioning bound (a faster-growing plant
+    with hardly any control authority, at the handle's rho and 8 segments): ADMM_ERR_NUMERIC, and the handle still holds the OLD dynamics, box, x0 and
+    factors -- its iterates continue exactly as if the call had not happened (vs the oracle on the old problem)."""
+    import dataclasses
+    p = _sensitive_instances()
+    # a faster-growing plant with hardly any authority: the uncontrolled segment transfer matrix A^8 has entries of 135-210
+    # (NumPy emulation of pseg_kernel), beyond the bound of 100
+    worse = dataclasses.replace(p, A=p.A + 0.3 * np.eye(2), B=p.B * 1e-3, x0=p.x0 + 1.0, lo=p.lo * 0.5, hi=p.hi * 0.5)
+    with pkg.Solver(p, pkg.Options(rho=0.1)) as s:
+        assert s.geometry()["segments"] == 8
+        s.iterate(4)
+        with pytest.raises(pkg.AdmmError) as e:
+            s.update_problem(worse)
+        assert e.value.code == _code("ADMM_ERR_NUMERIC") and "refused" in str(e.value)
+        s.iterate(6)
+        w, z, y = s.get()
+        # an acceptable update still goes through afterwards (the trial buffers are reused)
+        ok = dataclasses.replace(p, x0=p.x0 * 0.5)
+        s.update_problem(ok)
+        s.iterate(3)
+        w2, z2, y2 = s.get()
+    ref = oc.solve(p, rho=0.1, max_iter=10, stop=False)
+    for a, k in ((w, "w"), (z, "z"), (y, "y")):
+        assert np.abs(a - ref[k]).max() <= 1e-10, k
+    ref2 = oc.solve(ok, rho=0.1, max_iter=3, stop=False, z0=ref["z"], y0=ref["y"])
+    assert np.abs(z2 - ref2["z"]).max() <= 1e-10 and np.abs(w2 - ref2["w"]).max() <= 1e-10
+
+
+def test_per_qp_adaptive_rule_keeps_the_conditioning_bound(gpu):
+    """The per-QP adaptive rule on the rho-sensitive plants (adapt_mu ~ 1: every test wants a change; tau = 10): a QP's change
+    to a rho whose transfer matrices exceed the bound is refused -- it keeps the last admissible rho and stops adapting, the
+    call reports it -- instead of iterating on ill-conditioned segments.  With one segment there is no bound and the rule
+    runs on (same options), and the two solves' QPs end on different rho."""
+    p = _sensitive_instances()
+    kw = dict(rho=0.1, max_iter=300, check_interval=10, adapt_interval=10, adapt_mu=1.0001, adapt_tau=10.0, eps_abs=1e-12, eps_rel=1e-12)
+    with pytest.warns(RuntimeWarning, match="adaptive rho: the change of"):
+        s = pkg.Solver(p, pkg.Options(**kw))
+        with s:
+            assert s.geometry()["segments"] == 8
+            info = s.solve()
+            rho = s.rho_per_qp()
+            w, z, y = s.get()
+    assert np.isfinite(w).all() and (rho >= 5e-3).all()            # 0.1 -> 0.01 admissible, 1e-3 refused (as with shared dynamics)
+    with pkg.Solver(p, pkg.Options(segments=1, **kw)) as s1:
+        s1.solve()
+        rho1 = s1.rho_per_qp()
+    assert (rho1 < 5e-3).any()                                      # unguarded, the rule does go lower
+    # the guarded solve's iterates are those of an exact x-update: dynamics feasibility of w to rounding
+    wb = w.reshape(p.batch, p.N, p.nb)
+    x = np.concatenate([p.x0[:, None, :], wb[:, :, p.m:]], axis=1)
+    defect = x[:, 1:] - np.einsum("bkij,bkj->bki", p.A, x[:, :-1]) - np.einsum("bkij,bkj->bki", p.B, wb[:, :, :p.m])
+    assert np.abs(defect).max() <= 1e-9 * max(1.0, np.abs(x).max())

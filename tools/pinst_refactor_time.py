@@ -26,4 +26,4 @@ for batch in [int(b) for b in (sys.argv[2].split() if len(sys.argv) > 2 else "64
         s.sync()
         tu = (time.perf_counter() - t) * 1e3
         print(f"batch {batch} N {N} segments {s.geometry()['segments']}: set_rho {min(ts):.2f} ms (of {' '.join('%.2f' % x for x in ts)}), "
-              f"update_problem {tu:.1f} ms", flush=True)
+              f"update_problem {tu:.1f} ms (admm_update_problem itself: {s.last_update_ms:.1f} ms; the rest is NumPy marshalling)", flush=True)

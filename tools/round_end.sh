@@ -6,8 +6,8 @@
 set -o pipefail
 cd "$(dirname "$0")/.."
 R=$PWD; O=$R/gpurun_out; tag=${1:-rXX}; mkdir -p "$O/profiles_out"
-timeout -k 10 900 python -m pytest tests -m gpu -x -q > "$O/${tag}_pytest_gpu.log" 2>&1; tail -1 "$O/${tag}_pytest_gpu.log"
-grep -q " passed" "$O/${tag}_pytest_gpu.log" && ! grep -q "failed\|error" "$O/${tag}_pytest_gpu.log" || exit 1
+timeout -k 10 1100 python -m pytest tests -m gpu -x -q -p no:warnings > "$O/${tag}_pytest_gpu.log" 2>&1; prc=$?; tail -1 "$O/${tag}_pytest_gpu.log"
+[ $prc -eq 0 ] || exit 1
 timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 || exit 1
 t0=$(date +%s)
 timeout -k 10 600 python bench.py > "$O/${tag}_bench.log" 2>&1 || { tail -5 "$O/${tag}_bench.log"; exit 1; }
@@ -30,7 +30,7 @@ PY
 bash tools/gpu_profile.sh "$tag" || exit 1
 timeout -k 10 600 python bench.py --workload cw_formation --precision mixed --no-cpu-baseline > "$O/${tag}_formation_mixed_bench.log" 2>&1 || { tail -5 "$O/${tag}_formation_mixed_bench.log"; exit 1; }
 tail -n1 "$O/${tag}_formation_mixed_bench.log" > "$O/profiles_out/${tag}_formation_mixed_bench.json"
-bash tools/gpu_profile.sh "${tag}_formation_mixed" --workload cw_formation --precision mixed || exit 1
+MFMA=1 bash tools/gpu_profile.sh "${tag}_formation_mixed" --workload cw_formation --precision mixed || exit 1
 for cfg in "4096 1000" "64 200"; do set -- $cfg
   timeout -k 10 300 python bench.py --workload cw_perinstance --batch $1 --horizon $2 --no-cpu-baseline 2>/dev/null | tail -n1 > "$O/profiles_out/${tag}_perinstance_${1}x${2}_bench.json" || exit 1
 done
