@@ -12,7 +12,7 @@ import numpy as np
 
 from .problems import Problem
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 ADMM_OK = 0
 STATUS_NAMES = {0: "ADMM_OK", 1: "ADMM_ERR_INVALID", 2: "ADMM_ERR_UNSUPPORTED",
@@ -64,6 +64,10 @@ class CPathInfo(C.Structure):
                 ("segments", C.c_int32), ("auto_segments", C.c_int32), ("scan_form", C.c_int32), ("per_instance", C.c_int32),
                 ("alt_check", C.c_double), ("alt_gate", C.c_double), ("scan_growth", C.c_double)]
 
+
+EXCHANGE_ALLGATHER = 0
+# int (*admm_exchange_fn)(void* ctx, void* hip_stream, int32_t op, double* buf, int64_t count)
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64)
 
 SCAN_FORMS = {0: "mfma_gemm", 1: "matrix_vector", 2: "sequential_chain", 3: "per_qp"}
 KERNEL_FAMILIES = {0: "one_lane_fp64", 1: "mfma_mixed", 2: "mfma_fp64"}

@@ -72,6 +72,10 @@ struct admm_handle {
   std::vector<std::unique_ptr<SpecFactor>> spec;        // candidates of the adaptive rule (rho tau, rho / tau)
   std::vector<std::unique_ptr<SpecFactor>> spec_stale;  // no longer candidates; their threads are joined lazily
   int spec_hits = 0, spec_misses = 0;
+  // time-sharded handle (admm_setup_timeshard): this rank runs segments [ts_s0, ts_s0 + ts_sl) of the S the horizon is cut into
+  int ts_n = 0, ts_rank = 0, ts_s0 = 0, ts_sl = 0;      // ts_n = 0: an ordinary handle
+  admm_exchange_fn ts_fn = nullptr;
+  void* ts_ctx = nullptr;
   bool solve_active = false;     // between admm_solve_begin and admm_solve_end: only then are candidate factors kept / started
   // ADMM_FLAG_HISTORY: one record per stopping test of the last admm_solve
   struct HistoryEntry { int32_t it, nconv; double max_r, max_s, rho; };
@@ -174,6 +178,13 @@ admm::XLaunch xlaunch_of(const admm_handle* h) {
   l.recFE = h->recFE; l.recBE = h->recBE; l.mvec = h->mvec;
   l.dbuf = h->dbuf; l.tseg = h->tseg; l.eseg = h->eseg; l.tin = h->tin; l.xin = h->xin; l.part = h->part;
   l.x0 = h->x0;
+  if (h->ts_n) {        // time shard: the kernels see this rank's segments only (per-segment arrays start at its first one)
+    const size_t o = (size_t)h->ts_s0 * h->n * h->pitch;
+    l.S = h->ts_sl;
+    l.seg_start = h->seg_start + h->ts_s0;
+    l.tseg = h->tseg + o; l.eseg = h->eseg + o; l.tin = h->tin + o; l.xin = h->xin + o;
+    l.part = h->part + (size_t)h->ts_s0 * 5 * h->pitch;
+  }
   const bool chain = (h->opt.flags & ADMM_FLAG_SCAN_CHAIN) != 0;     // the chain scan writes slab 0 only
   l.nsplit = chain ? 1 : h->scan_split;
   l.split_stride = (size_t)h->fac.scanM * h->pitch;
@@ -263,10 +274,33 @@ admm::FinArgs fin_args(const admm_handle* h, int it, int nchunks) {
   return fa;
 }
 
+// Time-sharded handles: complete the per-segment arrays the next launch reads -- every rank has written the rows of its own
+// segments -- with an all-gather through the caller's transport (include/admm_hip.h).
+int ts_allgather(admm_handle* h, double* base, size_t count_per_rank) {
+  if (!h->ts_n || h->ts_n == 1) return ADMM_OK;
+  const int rc = h->ts_fn(h->ts_ctx, (void*)h->stream, ADMM_EXCHANGE_ALLGATHER, base, (int64_t)count_per_rank);
+  if (rc) return fail(ADMM_ERR_HIP, "time-sharded handle: the exchange callback failed (" + std::to_string(rc) + ")");
+  return ADMM_OK;
+}
+int ts_exchange_summaries(admm_handle* h) {       // before a segment scan: tseg | eseg (or mseg | ebseg: same slots) of every segment
+  int rc;
+  const size_t cnt = (size_t)h->ts_sl * h->n * h->pitch;
+  if ((rc = ts_allgather(h, h->tseg, cnt))) return rc;
+  return ts_allgather(h, h->eseg, cnt);
+}
+int ts_exchange_partials(admm_handle* h) {        // before a finalise: the residual partial sums of every segment
+  return ts_allgather(h, h->part, (size_t)h->ts_sl * 5 * h->pitch);
+}
+
 // forward_form: the scan of the forward-elimination form (matrix WB).
 // with_finalize: one extra row of workgroups finalises the previous iteration's residual partials
 // (S chunks, it = 0: no stopping rule -- checked iterations of admm_solve finalise standalone).
 int launch_xscan_mfma(admm_handle* h, bool forward_form = false, bool with_finalize = false) {
+  if (h->ts_n) {
+    int rc;
+    if ((rc = ts_exchange_summaries(h))) return rc;
+    if (with_finalize && (rc = ts_exchange_partials(h))) return rc;
+  }
   if (h->scan_gemv) {                           // a handful of QPs: matrix-vector form (admm_kernels.hpp)
     const int M = h->fac.scanM;
     dim3 grid((M + 3) / 4, with_finalize ? 2 : 1), block(256);
@@ -349,6 +383,10 @@ int launch_z(admm_handle* h, bool resid) {
 
 // nchunks = zchunks after the standalone z kernel, S after the fused xfz kernel
 int launch_finalize(admm_handle* h, int it, int nchunks) {
+  if (h->ts_n) {
+    int rc;
+    if ((rc = ts_exchange_partials(h))) return rc;
+  }
   dim3 grid(h->pitch / admm::FIN_COLS), block(admm::FIN_COLS * admm::FIN_GROUPS);
   hipLaunchKernelGGL(admm::resid_finalize_kernel, grid, block, 0, h->stream, fin_args(h, it, nchunks), h->pitch);
   return ADMM_OK;
@@ -1168,7 +1206,8 @@ int admm_host_factor_mfma(const admm_problem* p, double rho, int32_t segments, i
   return ADMM_OK;
 }
 
-int admm_setup(admm_handle** out, const admm_problem* p, const admm_options* o_in) {
+static int setup_common(admm_handle** out, const admm_problem* p, const admm_options* o_in, int ts_rank, int ts_n,
+                        admm_exchange_fn ts_fn, void* ts_ctx) {
   if (!out || !p) return fail(ADMM_ERR_INVALID, "NULL argument");
   *out = nullptr;
   g_warn.clear();
@@ -1177,6 +1216,15 @@ int admm_setup(admm_handle** out, const admm_problem* p, const admm_options* o_i
   int rc;
   if ((rc = validate_options(&o))) return rc;
   if ((rc = validate_problem(p))) return rc;
+  if (ts_n) {
+    if (ts_n < 1 || ts_rank < 0 || ts_rank >= ts_n) return fail(ADMM_ERR_INVALID, "admm_setup_timeshard: need 0 <= rank < nranks");
+    if (ts_n > 1 && !ts_fn) return fail(ADMM_ERR_INVALID, "admm_setup_timeshard: an exchange function is needed with more than one rank");
+    if (p->time_varying == 2) return fail(ADMM_ERR_UNSUPPORTED, "time-sharded handles need batch-shared dynamics");
+    if (o.flags & (ADMM_FLAG_UNFUSED | ADMM_FLAG_GRAPH | ADMM_FLAG_SCAN_CHAIN))
+      return fail(ADMM_ERR_UNSUPPORTED, "time-sharded handles run the fused paths with direct launches (no ADMM_FLAG_UNFUSED / _GRAPH / _SCAN_CHAIN)");
+    if (o.segments % ts_n != 0) return fail(ADMM_ERR_INVALID, "admm_setup_timeshard: options.segments (the total) must be a multiple of nranks");
+    if (p->N < ts_n) return fail(ADMM_ERR_INVALID, "admm_setup_timeshard: fewer stages than ranks");
+  }
   if (!dims_supported(p->n, p->m))
     return fail(ADMM_ERR_UNSUPPORTED, "(n, m) = (" + std::to_string(p->n) + ", " + std::to_string(p->m) +
                                           ") has no compiled kernel; supported: " + supported_list());
@@ -1195,6 +1243,7 @@ int admm_setup(admm_handle** out, const admm_problem* p, const admm_options* o_i
     if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) h->num_cus = prop.multiProcessorCount;
   }
   h->opt = o;
+  h->ts_n = ts_n; h->ts_rank = ts_rank; h->ts_fn = ts_fn; h->ts_ctx = ts_ctx;
   h->N = p->N; h->n = p->n; h->m = p->m; h->nb = p->n + p->m; h->batch = p->batch;
   h->L = p->N * h->nb;
   h->pitch = ((p->batch + 63) / 64) * 64;
@@ -1228,6 +1277,13 @@ int admm_setup(admm_handle** out, const admm_problem* p, const admm_options* o_i
       const double total = (double)h->N * h->nb * h->pitch * 8.0;
       const int min_by_span = (int)(total / 1.9e9) + 1;
       if (S < min_by_span) S = min_by_span;
+    }
+    if (ts_n) {               // time shards: the rule above gives the segments of ONE rank's grid; the horizon gets nranks times as many
+      if (o.segments == 0) {
+        const int max_total = h->N >= 16 ? h->N / 8 : h->N;
+        S = std::max(1, std::min(S, max_total / ts_n)) * ts_n;
+      }
+      if (S > h->N) S = (h->N / ts_n) * ts_n;
     }
     if (S > h->N) S = h->N;
     if (S < 1) S = 1;
@@ -1290,7 +1346,12 @@ int admm_setup(admm_handle** out, const admm_problem* p, const admm_options* o_i
   // 1e-14 for the workloads of DESIGN.md §3 where max|W| is O(1)).  With an automatic segment
   // count, fall back to fewer, longer segments until the growth is benign.
   h->auto_segments = o.segments == 0;
-  if (o.segments == 0) {
+  if (o.segments == 0 && ts_n && h->fac.S > ts_n && scan_growth(h->fac) > SCAN_GROWTH_MAX) {
+    release(h);            // (every rank must arrive at the same count: no silent back-off here)
+    return fail(ADMM_ERR_NUMERIC, "admm_setup_timeshard: the segment transfer matrices grow beyond the conditioning bound with the "
+                                  "automatic segment count; give options.segments (a multiple of nranks)");
+  }
+  if (o.segments == 0 && !ts_n) {
     while (h->fac.S > 1 && scan_growth(h->fac) > SCAN_GROWTH_MAX) {
       const int S2 = std::max(1, h->fac.S / 2);
       rc = admm::factorise(*p, o.rho, S2, h->fac, err, h->mfma_mode, !h->scan_gemv);
@@ -1298,6 +1359,11 @@ int admm_setup(admm_handle** out, const admm_problem* p, const admm_options* o_i
     }
   }
   h->S = h->fac.S;
+  if (ts_n) {
+    if (h->S % ts_n != 0) { release(h); return fail(ADMM_ERR_INVALID, "admm_setup_timeshard: the segment count " + std::to_string(h->S) + " is not a multiple of nranks"); }
+    h->ts_sl = h->S / ts_n;
+    h->ts_s0 = ts_rank * h->ts_sl;
+  }
   keep_shared(h, p);     // host copy of the shared problem data, for admm_set_rho / the adaptive rule
   {  // the x kernels address one segment of an array through a 32-bit buffer descriptor
     int longest = 0;
@@ -1437,6 +1503,28 @@ int admm_setup(admm_handle** out, const admm_problem* p, const admm_options* o_i
 #undef TRY_RELEASE
 #undef HIP_TRY_RELEASE
   *out = h;
+  return ADMM_OK;
+}
+
+int admm_setup(admm_handle** out, const admm_problem* p, const admm_options* o) {
+  return setup_common(out, p, o, 0, 0, nullptr, nullptr);
+}
+
+int admm_setup_timeshard(admm_handle** out, const admm_problem* p, const admm_options* o, int32_t rank, int32_t nranks,
+                         admm_exchange_fn exchange, void* ctx) {
+  if (nranks < 1) return fail(ADMM_ERR_INVALID, "admm_setup_timeshard: nranks must be >= 1");
+  return setup_common(out, p, o, rank, nranks, exchange, ctx);
+}
+
+int admm_get_window(admm_handle* h, int32_t* stage_lo, int32_t* stage_hi, int32_t* seg_lo, int32_t* segs_local, int32_t* segs_total) {
+  if (!h) return fail(ADMM_ERR_INVALID, "NULL handle");
+  const bool ts = h->ts_n > 0 && !h->pinst;
+  const int s0 = ts ? h->ts_s0 : 0, sl = ts ? h->ts_sl : h->S;
+  if (stage_lo) *stage_lo = h->pinst ? 0 : h->fac.seg_start[s0];
+  if (stage_hi) *stage_hi = h->pinst ? h->N : h->fac.seg_start[s0 + sl];
+  if (seg_lo) *seg_lo = s0;
+  if (segs_local) *segs_local = sl;
+  if (segs_total) *segs_total = h->S;
   return ADMM_OK;
 }
 
@@ -1767,6 +1855,7 @@ int admm_step_x(admm_handle* h) {
 int admm_step_z(admm_handle* h, int32_t residuals) {
   if (!h) return fail(ADMM_ERR_INVALID, "NULL handle");
   if (h->pbounds) return fail(ADMM_ERR_UNSUPPORTED, "admm_step_z: the standalone z kernel has no per-instance bounds form");
+  if (h->ts_n) return fail(ADMM_ERR_UNSUPPORTED, "admm_step_z is not available on a time-sharded handle (the standalone z kernel's partial sums are not per segment)");
   HIP_TRY(hipSetDevice(h->device));
   int rc = ensure_w(h);
   if (!rc) rc = ensure_zy(h);
@@ -2131,6 +2220,7 @@ int admm_profile(admm_handle* h, int32_t iters, int32_t residuals, int32_t fused
   if (!h || !ms) return fail(ADMM_ERR_INVALID, "NULL argument");
   if (iters < 1 || iters > 4096) return fail(ADMM_ERR_INVALID, "iters must lie in [1, 4096]");
   if (h->pinst && fused_path != 1) return fail(ADMM_ERR_UNSUPPORTED, "admm_profile: per-instance dynamics run the plain fused path only (fused_path = 1)");
+  if (h->ts_n) return fail(ADMM_ERR_UNSUPPORTED, "admm_profile is not available on a time-sharded handle");
   h->xfree_mode = 1;
   HIP_TRY(hipSetDevice(h->device));
   constexpr int NE = 6;     // events per iteration

@@ -83,3 +83,112 @@ def solve_sharded(solver, global_batch: int, group=None, device="cpu"):
         if adaptive:
             solver.solve_adapt(Rg, Sg)
     return solver.solve_end()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Time sharding (include/admm_hip.h ABI v7): ONE batch whose horizon is cut into segments that live on
+# different ranks -- the "shooting segments" of BASELINE.json's north_star.  The segment algebra couples them exactly
+# through 2 n numbers per segment and QP, completed by an all-gather before every segment scan: the one place where RCCL
+# carries data in this library.
+# ---------------------------------------------------------------------------------------------------------------------
+
+class _DevView:
+    """A device pointer as something torch can wrap without copying (__cuda_array_interface__)."""
+
+    def __init__(self, ptr: int, count: int):
+        self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+
+
+def device_tensor(ptr: int, count: int, device):
+    """fp64 torch tensor over `count` doubles of device memory at `ptr` (no copy; the memory belongs to the handle)."""
+    import torch
+    return torch.as_tensor(_DevView(ptr, count), device=device)
+
+
+def make_exchange(group=None, device="cuda:0"):
+    """The admm_exchange_fn of a time-sharded handle over torch.distributed: RCCL (backend "nccl") enqueues the all-gather
+    behind the library's own HIP stream, so nothing waits on the host; any other backend (gloo: several ranks on one GPU, CPU
+    transport) synchronises the stream and moves the slices through host memory.  Returns (ctypes callback, stats dict)."""
+    import torch
+    import torch.distributed as dist
+    from . import _abi
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    nccl = dist.get_backend(group) == "nccl"
+    stats = {"calls": 0, "doubles": 0}
+
+    def exchange(ctx, stream, op, buf, count):
+        try:
+            if op != _abi.EXCHANGE_ALLGATHER:
+                return 2
+            full = device_tensor(buf, count * world, device)
+            mine = full[rank * count:(rank + 1) * count]
+            ext = torch.cuda.ExternalStream(stream, device=device)
+            stats["calls"] += 1
+            stats["doubles"] += int(count) * world
+            with torch.cuda.stream(ext):
+                if nccl:
+                    dist.all_gather_into_tensor(full, mine, group=group)        # in place: `mine` is its own slice of `full`
+                else:
+                    ext.synchronize()
+                    host = mine.cpu()
+                    outs = [torch.empty_like(host) for _ in range(world)]
+                    dist.all_gather(outs, host, group=group)
+                    for r, t in enumerate(outs):
+                        if r != rank:
+                            full[r * count:(r + 1) * count].copy_(t)
+                    ext.synchronize()
+            return 0
+        except Exception:           # never let an exception cross the C boundary
+            import traceback
+            traceback.print_exc()
+            return 1
+
+    return _abi.EXCHANGE_FN(exchange), stats
+
+
+class TimeShardedSolver:
+    """One batch of QPs, the horizon's segments spread over the ranks of a torch.distributed group (one process per GPU).
+    Every rank passes the GLOBAL problem; iterate / run / solve are collective calls (same arguments on every rank) and
+    return the same residuals, iteration counts and stop decisions everywhere; get() assembles the full vectors from the
+    ranks' windows."""
+
+    def __init__(self, problem: Problem, options=None, group=None, device="cuda:0"):
+        import torch.distributed as dist
+        from .solver import Solver
+        self.group, self.device = group, device
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self._fn, self.exchange_stats = make_exchange(group, device)
+        self.solver = Solver(problem, options, timeshard=(self.rank, self.world, self._fn))
+        self.window = self.solver.window()
+
+    def close(self):
+        self.solver.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def iterate(self, iters: int):
+        self.solver.iterate(iters)
+
+    def run(self, iters: int, residual_every: int = 0):
+        self.solver.run(iters, residual_every)
+
+    def solve(self):
+        return self.solver.solve()
+
+    def residuals(self):
+        return self.solver.residuals()
+
+    def get(self):
+        """(w, z, y) of the whole horizon on every rank: each rank contributes the rows of its own stages."""
+        import numpy as np
+        import torch.distributed as dist
+        nb = self.solver.problem.nb
+        lo, hi = self.window["stage_lo"] * nb, self.window["stage_hi"] * nb
+        local = [a[:, lo:hi].copy() for a in self.solver.get()]
+        parts = [None] * self.world
+        dist.all_gather_object(parts, local, group=self.group)
+        return tuple(np.concatenate([p[i] for p in parts], axis=1) for i in range(3))

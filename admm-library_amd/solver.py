@@ -63,6 +63,9 @@ _SIGNATURES = {
     "admm_get_rho": (C.c_int, [C.c_void_p, c_double_p]),
     "admm_get_history": (C.c_int, [C.c_void_p, C.c_int32, c_int32_p, c_int32_p, c_int32_p, c_double_p, c_double_p, c_double_p]),
     "admm_get_path": (C.c_int, [C.c_void_p, C.POINTER(_abi.CPathInfo)]),
+    "admm_setup_timeshard": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(CProblem), C.POINTER(COptions), C.c_int32, C.c_int32,
+                                      _abi.EXCHANGE_FN, C.c_void_p]),
+    "admm_get_window": (C.c_int, [C.c_void_p] + [c_int32_p] * 5),
     "admm_free": (None, [C.c_void_p]),
     "admm_last_error": (C.c_char_p, []),
     "admm_last_warning": (C.c_char_p, []),
@@ -161,14 +164,22 @@ class SolveInfo:
 class Solver:
     """One handle = one batch of QPs on one GPU."""
 
-    def __init__(self, problem: Problem, options: Optional[Options] = None):
+    def __init__(self, problem: Problem, options: Optional[Options] = None, timeshard=None):
+        """timeshard = (rank, nranks, exchange): a TIME-SHARDED handle (admm_setup_timeshard; sharding.TimeShardedSolver builds
+        the exchange function over torch.distributed) -- `exchange` is an _abi.EXCHANGE_FN the caller keeps alive."""
         self._lib = load_library()
         self._h = C.c_void_p()
         self.problem = problem
         self.options = options or Options()
         cp, keep = _abi.marshal_problem(problem)
         co = self.options.to_c()
-        _check(self._lib, self._lib.admm_setup(C.byref(self._h), C.byref(cp), C.byref(co)))
+        if timeshard is None:
+            _check(self._lib, self._lib.admm_setup(C.byref(self._h), C.byref(cp), C.byref(co)))
+        else:
+            rank, nranks, fn = timeshard
+            self._exchange = fn                     # the C side calls it for as long as the handle lives
+            _check(self._lib, self._lib.admm_setup_timeshard(C.byref(self._h), C.byref(cp), C.byref(co), int(rank), int(nranks),
+                                                            fn if fn is not None else _abi.EXCHANGE_FN(0), None))
         del keep
         self.batch, self.L = problem.batch, problem.L
         self._warn()
@@ -342,6 +353,12 @@ class Solver:
         v = [C.c_int32() for _ in range(4)]
         _check(self._lib, self._lib.admm_get_geometry(self._h, *[C.byref(x) for x in v]))
         return {"pitch": v[0].value, "segments": v[1].value, "zrows": v[2].value, "zchunks": v[3].value}
+
+    def window(self) -> dict:
+        """admm_get_window: the stages / segments this handle iterates (the whole horizon unless it is a time shard)."""
+        v = [C.c_int32() for _ in range(5)]
+        _check(self._lib, self._lib.admm_get_window(self._h, *[C.byref(x) for x in v]))
+        return {"stage_lo": v[0].value, "stage_hi": v[1].value, "seg_lo": v[2].value, "segs_local": v[3].value, "segs_total": v[4].value}
 
     def path(self) -> dict:
         """admm_get_path: which kernels this handle runs and the measured margin of the default path."""

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ADMM_HIP_ABI_VERSION 6
+#define ADMM_HIP_ABI_VERSION 7
 
 typedef enum admm_status {
   ADMM_OK = 0,
@@ -307,6 +307,34 @@ int admm_get_path(admm_handle* h, admm_path_info* info);
  * SUCCEEDED but changed the kernels a handle runs (the forward-elimination gate above; the adaptive rule refused a rho); ""
  * if there was nothing to report.  Cleared at the start of each of those calls. */
 const char* admm_last_warning(void);
+
+/* TIME-SHARDED handles: one batch of QPs whose horizon is cut into segments that live on DIFFERENT ranks (ABI v7).
+ * The parallel-in-time x-update couples its segments EXACTLY through 2 n numbers per segment and QP (the segment summaries the
+ * elimination sweeps leave, and the boundary values the scan returns) -- so the "shooting segments" of one horizon can sit on
+ * different GPUs and exchange just those: every rank factorises the whole horizon on the host, runs the fused kernels of its own
+ * S / nranks consecutive segments, and before each segment scan the summaries are completed by an ALL-GATHER over the ranks (the
+ * only data-path collective of this library; the residual partial sums of the segments travel the same way before each stopping
+ * test, so every rank takes the same decisions).  The iterates are those of one handle holding every segment (up to the rounding
+ * of the scan product).
+ *
+ * The transport is the caller's: `exchange` is called from inside admm_run / admm_iterate / admm_solve* at those points, with
+ *   op = ADMM_EXCHANGE_ALLGATHER: `buf` holds nranks slices of `count` doubles in rank order, this rank's slice (at
+ *        buf + rank * count) is complete; when the function's work on `hip_stream` is done every slice must be.
+ * buf is DEVICE memory.  The function either enqueues the collective on hip_stream (RCCL: nothing waits on the host) or
+ * synchronises the stream and moves the data itself (any other transport); it returns 0 on success (anything else fails the
+ * calling entry point with ADMM_ERR_HIP).
+ *
+ * admm_setup_timeshard takes the GLOBAL problem on every rank.  options.segments = total segment count (0 = automatic), a
+ * multiple of nranks.  Shared dynamics only, fused paths only (no ADMM_FLAG_UNFUSED / _GRAPH / _SCAN_CHAIN).  State arrays
+ * keep the full horizon on every rank in this version (only the rank's own stages are current: admm_get returns whole vectors
+ * whose rows outside [stage_lo, stage_hi) * (n + m) are stale; the host side gathers the windows -- admm_get_window). */
+#define ADMM_EXCHANGE_ALLGATHER 0
+typedef int (*admm_exchange_fn)(void* ctx, void* hip_stream, int32_t op, double* buf, int64_t count);
+int admm_setup_timeshard(admm_handle** out, const admm_problem* p, const admm_options* o, int32_t rank, int32_t nranks,
+                         admm_exchange_fn exchange, void* ctx);
+/* The rank's window: stages [stage_lo, stage_hi), segments [seg_lo, seg_lo + segs_local) of segs_total.  An ordinary handle
+ * reports the whole horizon and rank 0 of 1. */
+int admm_get_window(admm_handle* h, int32_t* stage_lo, int32_t* stage_hi, int32_t* seg_lo, int32_t* segs_local, int32_t* segs_total);
 
 void admm_free(admm_handle* h);
 
