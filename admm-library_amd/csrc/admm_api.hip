@@ -182,7 +182,8 @@ admm::XLaunch xlaunch_of(const admm_handle* h) {
     const size_t o = (size_t)h->ts_s0 * h->n * h->pitch;
     l.S = h->ts_sl;
     l.seg_start = h->seg_start + h->ts_s0;
-    l.tseg = h->tseg + o; l.eseg = h->eseg + o; l.tin = h->tin + o; l.xin = h->xin + o;
+    if (h->ts_n == 1) { l.tseg = h->tseg + o; l.eseg = h->eseg + o; }     // (several ranks: h->tseg / h->eseg are this rank's block already)
+    l.tin = h->tin + o; l.xin = h->xin + o;
     l.part = h->part + (size_t)h->ts_s0 * 5 * h->pitch;
   }
   const bool chain = (h->opt.flags & ADMM_FLAG_SCAN_CHAIN) != 0;     // the chain scan writes slab 0 only
@@ -283,10 +284,8 @@ int ts_allgather(admm_handle* h, double* base, size_t count_per_rank) {
   return ADMM_OK;
 }
 int ts_exchange_summaries(admm_handle* h) {       // before a segment scan: tseg | eseg (or mseg | ebseg: same slots) of every segment
-  int rc;
-  const size_t cnt = (size_t)h->ts_sl * h->n * h->pitch;
-  if ((rc = ts_allgather(h, h->tseg, cnt))) return rc;
-  return ts_allgather(h, h->eseg, cnt);
+  // ONE all-gather: the scan's input rows are laid out rank by rank (admm_factor.hpp), each rank's block = 2 n rows per segment
+  return ts_allgather(h, h->scan_in, (size_t)2 * h->ts_sl * h->n * h->pitch);
 }
 int ts_exchange_partials(admm_handle* h) {        // before a finalise: the residual partial sums of every segment
   return ts_allgather(h, h->part, (size_t)h->ts_sl * 5 * h->pitch);
@@ -1337,7 +1336,7 @@ static int setup_common(admm_handle** out, const admm_problem* p, const admm_opt
   h->scan_gemv = h->batch <= admm::SCAN_GEMV_MAXCOLS && !(o.flags & ADMM_FLAG_SCAN_CHAIN) &&
                  std::getenv("ADMM_NO_GEMV_SCAN") == nullptr;
   std::string err;
-  rc = admm::factorise(*p, o.rho, h->S, h->fac, err, h->mfma_mode, !h->scan_gemv);
+  rc = admm::factorise(*p, o.rho, h->S, h->fac, err, h->mfma_mode, !h->scan_gemv, ts_n);
   if (rc) { release(h); return fail(rc, err); }
   // Conditioning guard of the parallel-in-time form: the segment coupling is exact in exact
   // arithmetic, but its transfer matrices are products of closed-loop matrices, and for a barely
@@ -1407,6 +1406,12 @@ static int setup_common(admm_handle** out, const admm_problem* p, const admm_opt
     h->tseg = h->scan_in;
     h->x0 = h->scan_in + Sn * P;
     h->eseg = h->scan_in + (Sn + h->n) * P;
+    if (h->fac.ts_ranks > 1) {     // time shards: rank-by-rank input rows (admm_factor.hpp); tseg / eseg = THIS rank's block
+      const size_t blk = (size_t)2 * h->ts_sl * h->n;
+      h->tseg = h->scan_in + (size_t)h->ts_rank * blk * P;
+      h->eseg = h->tseg + (size_t)h->ts_sl * h->n * P;
+      h->x0 = h->scan_in + 2 * Sn * P;
+    }
     h->tin = h->scan_out;
     h->xin = h->scan_out + (size_t)h->fac.scanMt * P;
     TRY_RELEASE(dalloc(&h->scanWp, h->fac.scanWp.size()));
@@ -1622,7 +1627,7 @@ static void spec_start(admm_handle* h) {
       try {
         admm::Factor f;
         std::string err;
-        rc = admm::factorise(p, s->rho, hc->S, f, err, hc->mfma_mode, !hc->scan_gemv);
+        rc = admm::factorise(p, s->rho, hc->S, f, err, hc->mfma_mode, !hc->scan_gemv, hc->ts_n);
         s->f = std::move(f);
         s->err = std::move(err);
       } catch (...) {
@@ -1702,7 +1707,7 @@ static int set_rho_internal(admm_handle* h, double rho_new) {
     f = std::move(sp->f);
     ++h->spec_hits;
   } else {
-    rc = admm::factorise(p, rho_new, h->S, f, err, h->mfma_mode, !h->scan_gemv);
+    rc = admm::factorise(p, rho_new, h->S, f, err, h->mfma_mode, !h->scan_gemv, h->ts_n);
     ++h->spec_misses;
   }
   lap("factor (take / compute)");
@@ -1794,7 +1799,7 @@ int admm_update_problem(admm_handle* h, const admm_problem* p) {
   }
   admm::Factor f;
   std::string err;
-  if ((rc = admm::factorise(*p, h->opt.rho, h->S, f, err, h->mfma_mode, !h->scan_gemv))) return fail(rc, err);
+  if ((rc = admm::factorise(*p, h->opt.rho, h->S, f, err, h->mfma_mode, !h->scan_gemv, h->ts_n))) return fail(rc, err);
   if (f.recB.size() != h->fac.recB.size() || f.scanWp.size() != h->fac.scanWp.size())
     return fail(ADMM_ERR_NUMERIC, "internal: record sizes changed on refactor");
   if (h->auto_segments && h->S > 1 && scan_growth(f) > SCAN_GROWTH_MAX)

@@ -183,6 +183,28 @@ bool all_finite(const double* a, size_t cnt) {
 
 
 // W (row-major M x K) -> MFMA A-fragment order, plus each M-group's non-zero k-step range.
+// Columns of a dense scan matrix (M x K, row-major) from the ordinary input layout  tseg(0..S-1) | x0 | eseg(0..S-1) | pad
+// to the rank-by-rank layout of time-sharded handles (admm_factor.hpp).
+void timeshard_columns(std::vector<double>& W, int M, int K, int S, int n, int ranks) {
+  if (ranks <= 1) return;
+  const int sl = S / ranks, Sn = S * n;
+  std::vector<int> newcol(K);
+  for (int c = 0; c < K; ++c) newcol[c] = c;
+  for (int s = 0; s < S; ++s)
+    for (int i = 0; i < n; ++i) {
+      const int base = (s / sl) * 2 * sl * n + (s % sl) * n + i;
+      newcol[s * n + i] = base;                          // tseg(s)
+      newcol[Sn + n + s * n + i] = base + sl * n;        // eseg(s)
+    }
+  for (int i = 0; i < n; ++i) newcol[Sn + i] = 2 * Sn + i;  // x0
+  std::vector<double> row(K);
+  for (int r = 0; r < M; ++r) {
+    double* w = &W[(size_t)r * K];
+    for (int c = 0; c < K; ++c) row[newcol[c]] = w[c];
+    for (int c = 0; c < K; ++c) w[c] = row[c];
+  }
+}
+
 void pack_scan(const std::vector<double>& Wm, int M, int K, std::vector<double>& Wp, std::vector<int32_t>& range) {
   auto round_up = [](int v, int q) { return ((v + q - 1) / q) * q; };
   auto W = [&](int r, int c) -> double { return Wm[(size_t)r * K + c]; };
@@ -594,6 +616,7 @@ void build_alternating(Factor& f, const std::vector<Mat>& A, const std::vector<M
   timer.lap("  alt: verification");
   f.scanWpB.clear();
   f.scanRangeB.clear();
+  timeshard_columns(f.scanWB, M, K, S, n, f.ts_ranks);      // (after the verification above, which uses the ordinary layout)
   if (pack_scan_mfma) pack_scan(f.scanWB, M, K, f.scanWpB, f.scanRangeB);
   f.alt_ok = true;
   timer.lap("  alt: pack scan");
@@ -788,7 +811,7 @@ void build_mfma(Factor& f, int mode) {
 
 void set_factor_thread_cap(int cap) { g_thread_cap = cap; }
 
-static int factorise_impl(const admm_problem& p, double rho, int segments, Factor& f, std::string& err, int mfma_mode, bool pack_scan_mfma) {
+static int factorise_impl(const admm_problem& p, double rho, int segments, Factor& f, std::string& err, int mfma_mode, bool pack_scan_mfma, int ts_ranks) {
   if (mfma_mode < 0 || mfma_mode > 2) { err = "mfma_mode must be 0, 1 or 2"; return ADMM_ERR_INVALID; }
   if (mfma_mode != 0 && !mfma_dims(p.n, p.m)) { err = "the MFMA form needs n <= 12 and m <= 8"; return ADMM_ERR_UNSUPPORTED; }
   const int N = p.N, n = p.n, m = p.m;
@@ -806,6 +829,7 @@ static int factorise_impl(const admm_problem& p, double rho, int segments, Facto
   if (S > N) S = N;
 
   f.N = N; f.n = n; f.m = m; f.S = S; f.rho = rho;
+  f.ts_ranks = (ts_ranks > 1 && S % ts_ranks == 0) ? ts_ranks : 0;
   f.RB = rec_b_size(n, m); f.RF = rec_f_size(n, m); f.RS = rec_s_size(n);
   f.seg_start.resize(S + 1);
   for (int s = 0; s <= S; ++s) f.seg_start[s] = (int32_t)(((int64_t)s * N) / S);
@@ -953,6 +977,7 @@ static int factorise_impl(const admm_problem& p, double rho, int segments, Facto
       if (!std::isfinite(v)) { err = "scan matrix overflowed; use more segments"; return ADMM_ERR_NUMERIC; }
     f.scanWp.clear();
     f.scanRange.clear();
+    timeshard_columns(f.scanW, M, K, S, n, f.ts_ranks);
     if (pack_scan_mfma) pack_scan(f.scanW, M, K, f.scanWp, f.scanRange);
   }
 
@@ -970,9 +995,9 @@ static int factorise_impl(const admm_problem& p, double rho, int segments, Facto
 }
 
 // No exception leaves the factorisation (C ABI above it; worker threads below it -- parallel_for rethrows theirs here).
-int factorise(const admm_problem& p, double rho, int segments, Factor& f, std::string& err, int mfma_mode, bool pack_scan_mfma) {
+int factorise(const admm_problem& p, double rho, int segments, Factor& f, std::string& err, int mfma_mode, bool pack_scan_mfma, int ts_ranks) {
   try {
-    return factorise_impl(p, rho, segments, f, err, mfma_mode, pack_scan_mfma);
+    return factorise_impl(p, rho, segments, f, err, mfma_mode, pack_scan_mfma, ts_ranks);
   } catch (const std::bad_alloc&) {
     err = "out of host memory in the KKT factorisation";
     return ADMM_ERR_ALLOC;

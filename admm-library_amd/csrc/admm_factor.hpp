@@ -40,6 +40,7 @@ namespace admm {
 struct Factor {
   int N = 0, n = 0, m = 0, S = 0;
   double rho = 0.0;                 // the rho this factor was computed for
+  int ts_ranks = 0;                 // > 1: scan inputs in the rank-by-rank layout of time-sharded handles (see factorise)
   int RB = 0, RF = 0, RS = 0;
   std::vector<int32_t> seg_start;   // S + 1 entries, seg_start[S] = N
   std::vector<double> recB;         // N * RB
@@ -107,8 +108,12 @@ inline int rec_be_size(int n, int m) { return rec_be_layout(n, m).SIZE; }
 // mfma_mode: 0 = no MFMA records; 1 / 2 = also pack the MFMA form, mixed / fp64 (needs mfma_dims(n, m)).
 // pack_scan_mfma = false leaves scanWp / scanRange (and the B pair) empty: handles whose scan runs as a matrix-vector
 // product (batches of <= 4 QPs) only need the dense matrices.
+// ts_ranks > 1 (time-sharded handles, include/admm_hip.h): the INPUT rows of both scan products are laid out rank by rank --
+//   [ rank 0: tseg of its S / ts_ranks segments | eseg of them ] [ rank 1: ... ] ... | x0 | pad
+// instead of tseg(0..S-1) | x0 | eseg(0..S-1), so that the segment summaries of all ranks are completed by ONE all-gather of
+// contiguous, equal slices (the columns of scanW / scanWB are permuted accordingly before they are packed).
 int factorise(const admm_problem& p, double rho, int segments, Factor& out, std::string& err, int mfma_mode = 0,
-              bool pack_scan_mfma = true);
+              bool pack_scan_mfma = true, int ts_ranks = 0);
 
 // The per-stage / per-segment loops of factorise run on host threads (ADMM_FACTOR_THREADS, default min(cores, 16)); this
 // caps the count for factorisations started from the calling thread (0 = no cap).  Used by the background refactors of

@@ -177,5 +177,5 @@ def test_two_process_time_sharded_solve_equals_the_oracle(gpu, tmp_path):
         assert (np.abs(g[r]["iters"] - ref["iters"]) <= 10).all()
         for k in "wzy":
             assert np.abs(g[r][k] - ref[k]).max() <= TOL * max(1.0, np.abs(ref[k]).max()), (r, k)
-        assert int(g[r]["calls"]) >= 2 * ref["iters_run"]            # two all-gathers (tseg | eseg) per iteration at least
+        assert int(g[r]["calls"]) >= ref["iters_run"]                # one all-gather of the segment summaries per iteration at least
     np.testing.assert_array_equal(g[0]["z"], g[1]["z"])
