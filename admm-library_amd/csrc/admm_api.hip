@@ -1161,6 +1161,19 @@ int admm_host_scan_matrix(const admm_problem* p, double rho, int32_t segments, d
   return ADMM_OK;
 }
 
+int admm_host_scan_matrices_timeshard(const admm_problem* p, double rho, int32_t segments, int32_t nranks, double* W, double* WB,
+                                      int32_t* ok) {
+  if (!p || nranks < 1 || segments < 1 || segments % nranks != 0) return fail(ADMM_ERR_INVALID, "need segments >= 1, a multiple of nranks >= 1");
+  admm::Factor f;
+  std::string err;
+  int rc = admm::factorise(*p, rho, segments, f, err, 0, true, nranks);
+  if (rc) return fail(rc, err);
+  if (W) std::memcpy(W, f.scanW.data(), sizeof(double) * f.scanW.size());
+  if (ok) *ok = f.alt_ok ? 1 : 0;
+  if (WB && f.alt_ok) std::memcpy(WB, f.scanWB.data(), sizeof(double) * f.scanWB.size());
+  return ADMM_OK;
+}
+
 int admm_record_sizes_alt(int32_t n, int32_t m, int32_t* rfe, int32_t* rbe) {
   if (n < 1 || m < 1) return fail(ADMM_ERR_INVALID, "n, m must be positive");
   if (rfe) *rfe = admm::rec_fe_size(n, m);

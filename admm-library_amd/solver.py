@@ -76,6 +76,8 @@ _SIGNATURES = {
                                         c_int32_p, c_int32_p]),
     "admm_host_factor": (C.c_int, [C.POINTER(CProblem), C.c_double, C.c_int32, c_double_p, c_double_p,
                                    c_double_p, c_double_p, c_double_p, c_int32_p]),
+    "admm_host_scan_matrices_timeshard": (C.c_int, [C.POINTER(CProblem), C.c_double, C.c_int32, C.c_int32, c_double_p, c_double_p,
+                                                   c_int32_p]),
     "admm_update_problem": (C.c_int, [C.c_void_p, C.POINTER(CProblem)]),
     "admm_record_sizes_alt": (C.c_int, [C.c_int32, C.c_int32, c_int32_p, c_int32_p]),
     "admm_host_factor_alt": (C.c_int, [C.POINTER(CProblem), C.c_double, C.c_int32, c_double_p, c_double_p,

@@ -354,6 +354,11 @@ int admm_host_factor(const admm_problem* p, double rho, int32_t segments, double
 int admm_host_scan_matrix(const admm_problem* p, double rho, int32_t segments, double* W, int32_t* M,
                           int32_t* Mt, int32_t* K);
 
+/* The same two dense scan matrices (W, and WB if *ok) with their INPUT columns in the rank-by-rank layout of time-sharded handles
+ * (admm_setup_timeshard): [rank 0: tseg of its segments | eseg of them][rank 1: ...] ... | x0 | pad.  Shapes as above. */
+int admm_host_scan_matrices_timeshard(const admm_problem* p, double rho, int32_t segments, int32_t nranks, double* W, double* WB,
+                                      int32_t* ok);
+
 /* Alternating-direction iteration: per-stage records of the two fused kernels
  * (rfe / rbe doubles per stage; layouts in csrc/admm_layout.hpp) and the dense scan matrix WB of
  * the forward-elimination form (same M x K shape and row / column layout as W above:

@@ -316,3 +316,37 @@ def test_host_factor_does_not_depend_on_the_thread_count(built):
         assert out.returncode == 0, out.stderr[-2000:]
         digests.add(out.stdout.strip().splitlines()[-1])
     assert len(digests) == 1, digests
+
+
+def test_timeshard_scan_layout_is_a_column_permutation(lib):
+    """Time-sharded handles (ABI v7): the scan matrices with their input rows laid out rank by rank are the ordinary ones with
+    permuted columns -- W_ts in_ts == W in for the same segment summaries, for both scan forms and 1, 2, 4 ranks."""
+    import ctypes as C
+    p = pkg.cw_rendezvous(N=96, batch=2)
+    S, n, rho = 8, p.n, 0.05
+    hf = host_factor(p, rho, S)
+    W, WB = hf["scanW"], hf["scanWB"]
+    M, K = W.shape
+    rng = np.random.default_rng(3)
+    tseg, eseg, x0 = rng.standard_normal((S, n)), rng.standard_normal((S, n)), rng.standard_normal(n)
+    vin = np.zeros(K)
+    vin[:S * n], vin[S * n:S * n + n], vin[S * n + n:2 * S * n + n] = tseg.ravel(), x0, eseg.ravel()
+    cp, keep = _abi.marshal_problem(p)
+    for ranks in (1, 2, 4):
+        Wt, WBt, ok = np.empty((M, K)), np.empty((M, K)), C.c_int32()
+        assert lib.admm_host_scan_matrices_timeshard(C.byref(cp), rho, S, ranks, _abi.dptr(Wt), _abi.dptr(WBt), C.byref(ok)) == 0 and ok.value
+        sl = S // ranks
+        vts = np.zeros(K)
+        if ranks == 1:
+            vts = vin.copy()
+        else:
+            for r in range(ranks):
+                base = r * 2 * sl * n
+                vts[base:base + sl * n] = tseg[r * sl:(r + 1) * sl].ravel()
+                vts[base + sl * n:base + 2 * sl * n] = eseg[r * sl:(r + 1) * sl].ravel()
+            vts[2 * S * n:2 * S * n + n] = x0
+        np.testing.assert_array_equal(Wt @ vts, W @ vin) if ranks == 1 else np.testing.assert_allclose(Wt @ vts, W @ vin, rtol=0, atol=1e-13)
+        np.testing.assert_allclose(WBt @ vts, WB @ vin, rtol=0, atol=1e-11 * max(1.0, np.abs(WB @ vin).max()))
+        assert sorted(np.abs(Wt).sum(axis=0).round(9)) == sorted(np.abs(W).sum(axis=0).round(9))      # the same columns, reordered
+    del keep
+    assert lib.admm_host_scan_matrices_timeshard(C.byref(cp), rho, 6, 4, None, None, None) != 0           # 6 segments on 4 ranks
