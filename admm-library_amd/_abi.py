@@ -89,8 +89,17 @@ def iptr(a):
 
 
 def _colmajor(mat: np.ndarray) -> np.ndarray:
-    """(..., r, c) row-major matrices -> buffer holding each one column-major."""
-    return np.ascontiguousarray(np.swapaxes(np.asarray(mat, np.float64), -1, -2))
+    """(..., r, c) row-major matrices -> buffer holding each one column-major.  Large stacks (per-instance dynamics: 1.2 GB of
+    A at 4096 x 1000 stages) are transposed by torch's threaded copy where torch is importable -- NumPy's strided copy is one
+    thread and was most of what an admm_update_problem call cost from Python once the C side took 60 ms."""
+    a = np.asarray(mat, np.float64)
+    if a.nbytes >= (16 << 20) and a.ndim >= 3:
+        try:
+            import torch
+            return torch.from_numpy(np.ascontiguousarray(a)).transpose(-1, -2).contiguous().numpy()
+        except ImportError:
+            pass
+    return np.ascontiguousarray(np.swapaxes(a, -1, -2))
 
 
 def marshal_problem(p: Problem):

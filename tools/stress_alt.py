@@ -32,10 +32,7 @@ for trial in range(trials):
                            thrust_norm=soc)
     ref = oc.solve(p, rho=rho, alpha=alpha, max_iter=iters, check_interval=1, eps_abs=0, eps_rel=0, stop=False)
     with pkg.Solver(p, pkg.Options(rho=rho, alpha=alpha, segments=segs, flags=flags)) as s:
-        try:
-            s.profile(1, alternating=True); on = True
-        except pkg.AdmmError:
-            on = False
+        on = s.path()["alternating"]
         s.set_state(z=np.zeros((p.batch, p.L)), y=np.zeros((p.batch, p.L)))
         s.run(iters, residual_every=int(rng.choice([0, 1, 4])))
         w, z, y = s.get()
