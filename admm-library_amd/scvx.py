@@ -93,6 +93,43 @@ def linearise(xprev: np.ndarray, u: np.ndarray, dt: float, step=rk4_step, eps: f
     return A, B
 
 
+def linearise_device(xprev: np.ndarray, u: np.ndarray, dt: float, device: str = "cuda:0", eps: float = 1e-6,
+                     substeps: int = 4, rc: float = RC_KM) -> Tuple[np.ndarray, np.ndarray]:
+    """linearise() of the shipped model (rk4_step of relative_motion_rhs) with the n + m central differences evaluated as ONE
+    batch of torch tensors on `device`: the same formulas in the same order, fp64.  The NumPy version makes 2 (n + m) x 16
+    passes over (B, N, 6) arrays -- 10 s per outer iteration of a 4096-trajectory batch, most of the wall time of
+    examples/scvx_batch_rendezvous.py; this is host plumbing, not the solver."""
+    import torch
+    xp = torch.as_tensor(np.ascontiguousarray(xprev), dtype=torch.float64, device=device)
+    up = torch.as_tensor(np.ascontiguousarray(u), dtype=torch.float64, device=device)
+    n, m = xp.shape[-1], up.shape[-1]
+
+    def rhs(s, uu):
+        x, y, z, vx, vy, vz = (s[..., i] for i in range(6))
+        rd3 = ((rc + x) ** 2 + y ** 2 + z ** 2) ** 1.5
+        k = rc ** 3 / rd3
+        ax = 2.0 * vy + x + rc - k * (rc + x) + uu[..., 0]
+        ay = -2.0 * vx + y - k * y + uu[..., 1]
+        az = -k * z + uu[..., 2]
+        return torch.stack([vx, vy, vz, ax, ay, az], dim=-1)
+
+    def step(s, uu):
+        h = dt / substeps
+        for _ in range(substeps):
+            k1 = rhs(s, uu)
+            k2 = rhs(s + 0.5 * h * k1, uu)
+            k3 = rhs(s + 0.5 * h * k2, uu)
+            k4 = rhs(s + h * k3, uu)
+            s = s + (h / 6.0) * (k1 + 2.0 * k2 + 2.0 * k3 + k4)
+        return s
+
+    ex = eps * torch.eye(n, dtype=torch.float64, device=device).reshape((n,) + (1,) * (xp.dim() - 1) + (n,))
+    eu = eps * torch.eye(m, dtype=torch.float64, device=device).reshape((m,) + (1,) * (up.dim() - 1) + (m,))
+    A = (step(xp[None] + ex, up[None]) - step(xp[None] - ex, up[None])) / (2.0 * eps)        # (n, ..., n): [j, ..., i] = dF_i / dx_j
+    B = (step(xp[None].expand((m,) + xp.shape), up[None] + eu) - step(xp[None].expand((m,) + xp.shape), up[None] - eu)) / (2.0 * eps)
+    return torch.movedim(A, 0, -1).contiguous().cpu().numpy(), torch.movedim(B, 0, -1).contiguous().cpu().numpy()
+
+
 @dataclasses.dataclass
 class ScvxResult:
     u: np.ndarray                 # (N, m) controls
@@ -218,13 +255,13 @@ def scvx(x0: np.ndarray, N: int, dt: float, Q, R, QN, u_lo, u_hi,
 
 
 def correction_qp_batch(xb: np.ndarray, ub: np.ndarray, x0: np.ndarray, dt: float, Q, R, QN, u_lo, u_hi,
-                        tr_u: np.ndarray, tr_x: np.ndarray, step=rk4_step) -> Problem:
+                        tr_u: np.ndarray, tr_x: np.ndarray, step=rk4_step, device: Optional[str] = None) -> Problem:
     """The correction QPs of B trajectories as ONE batch with per-instance dynamics, box and linear term
     (xb (B, N, n), ub (B, N, m), x0 (B, n), trust radii (B,))."""
     Bn, N, n = xb.shape
     m = ub.shape[-1]
     xprev = np.concatenate([x0[:, None, :], xb[:, :-1, :]], axis=1)
-    A, B = linearise(xprev, ub, dt, step)
+    A, B = linearise_device(xprev, ub, dt, device) if (device is not None and step is rk4_step) else linearise(xprev, ub, dt, step)
     q = np.empty((Bn, N, m + n))
     q[..., :m] = ub @ R.T
     q[:, :-1, m:] = xb[:, :-1, :] @ Q.T
@@ -244,11 +281,12 @@ def scvx_batch(x0: np.ndarray, N: int, dt: float, Q, R, QN, u_lo, u_hi,
                qp_solver: Optional[Callable[[Problem], Tuple[np.ndarray, int]]] = None,
                tr_u: float = 0.1, tr_x: float = 20.0, max_outer: int = 20, tol: float = 1e-6,
                rho_reject: float = 0.1, rho_expand: float = 0.7, step=rk4_step,
-               qp_options: Optional[dict] = None) -> List[ScvxResult]:
+               qp_options: Optional[dict] = None, linearise_on: Optional[str] = None) -> List[ScvxResult]:
     """scvx() for B initial conditions x0 (B, n) at once: the same trust-region loop per trajectory (own trust radii,
     own accept / reject decisions, own stop), but ONE batched QP solve per outer iteration -- per-instance dynamics,
     bounds and linear term (correction_qp_batch).  A trajectory that has stopped keeps its place in the batch with a
-    zero-width box (its correction is then exactly zero) until the last one stops."""
+    zero-width box (its correction is then exactly zero) until the last one stops.
+    linearise_on = "cuda:0": the central differences of the shipped model run as torch tensors on that device (linearise_device)."""
     x0 = np.atleast_2d(np.asarray(x0, np.float64))
     Bn = x0.shape[0]
     Q, R, QN = (np.asarray(a, np.float64) for a in (Q, R, QN))
@@ -270,7 +308,8 @@ def scvx_batch(x0: np.ndarray, N: int, dt: float, Q, R, QN, u_lo, u_hi,
     for it in range(1, max_outer + 1):
         if not active.any():
             break
-        p = correction_qp_batch(xb, ub, x0, dt, Q, R, QN, u_lo, u_hi, np.where(active, tru, 0.0), np.where(active, trx, 0.0), step)
+        p = correction_qp_batch(xb, ub, x0, dt, Q, R, QN, u_lo, u_hi, np.where(active, tru, 0.0), np.where(active, trx, 0.0), step,
+                                device=linearise_on)
         z, admm_iters = qp_solver(p)
         d = np.asarray(z, np.float64).reshape(Bn, N, m + n)
         du, dx = d[..., :m], d[..., m:]

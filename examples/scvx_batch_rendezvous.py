@@ -43,7 +43,8 @@ def timed_solver():
 
 
 t0 = time.perf_counter()
-res = sc.scvx_batch(x0, N, dt, Q, R, QN, -3.0, 3.0, qp_solver=timed_solver(), tr_u=1.0, tr_x=100.0, max_outer=25, tol=1e-7)
+res = sc.scvx_batch(x0, N, dt, Q, R, QN, -3.0, 3.0, qp_solver=timed_solver(), tr_u=1.0, tr_x=100.0, max_outer=25, tol=1e-7,
+                    linearise_on=None if os.environ.get("SCVX_HOST_LINEARISE") else "cuda:0")
 wall = time.perf_counter() - t0
 outer = max(r.outer_iterations for r in res)
 print(f"{B} trajectories, N = {N}: {sum(r.converged for r in res)} converged in at most {outer} outer iterations, {wall:.2f} s wall")

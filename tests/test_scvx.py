@@ -86,3 +86,18 @@ def test_batched_loop_equals_the_single_trajectory_loops():
         assert abs(got.cost - one.cost) <= 1e-6 * abs(one.cost)
         assert np.abs(got.u - one.u).max() <= 1e-2
         np.testing.assert_allclose(got.x, sc.rollout(x0s[b], got.u, case.DT), atol=1e-12)
+
+
+def test_batched_torch_linearisation_matches_the_numpy_one():
+    """linearise_device (the n + m central differences as one torch batch; the 4096-trajectory example runs it on the GPU) vs
+    linearise: same formulas, so the two agree to the noise floor of a central difference with eps = 1e-6 (~1e-8 on O(1) entries)."""
+    rng = np.random.default_rng(0)
+    xp = rng.standard_normal((5, 7, 6)) * np.array([10.0, 100.0, 30.0, 1.0, 1.0, 1.0])
+    u = rng.standard_normal((5, 7, 3))
+    A, B = sc.linearise(xp, u, 0.03)
+    A2, B2 = sc.linearise_device(xp, u, 0.03, device="cpu")
+    assert A2.shape == A.shape == (5, 7, 6, 6) and B2.shape == B.shape == (5, 7, 6, 3)
+    assert np.abs(A - A2).max() < 1e-6 and np.abs(B - B2).max() < 1e-6
+    A1, B1 = sc.linearise(xp[0], u[0], 0.03)                       # the single-trajectory shape
+    A3, B3 = sc.linearise_device(xp[0], u[0], 0.03, device="cpu")
+    assert np.abs(A1 - A3).max() < 1e-6 and np.abs(B1 - B3).max() < 1e-6
