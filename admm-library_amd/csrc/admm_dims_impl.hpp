@@ -82,6 +82,8 @@ void launch_dim(const XLaunch& l, XKernel k, bool a, bool b) {
   do {                                                                                                       \
     if constexpr (!(RS) && !(RX)) {                                                                          \
       if (l.xfree == 2) ALT4(RS, RX, HQ, SC, 2); else if (l.xfree == 1) ALT4(RS, RX, HQ, SC, 1); else ALT4(RS, RX, HQ, SC, 0); \
+    } else if constexpr ((RS) && !(RX) && NX + NU >= 12) {   /* residual form with the state rows' shortcut: fp64-issue-bound blocks only */ \
+      if (l.xfree) ALT4(RS, RX, HQ, SC, 1); else ALT4(RS, RX, HQ, SC, 0);                                     \
     } else ALT4(RS, RX, HQ, SC, 0);                                                                          \
   } while (0)
 #define ALT2(RS, RX, HQ) do { if (l.has_soc) ALT3(RS, RX, HQ, true); else ALT3(RS, RX, HQ, false); } while (0)

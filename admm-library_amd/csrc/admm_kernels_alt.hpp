@@ -164,7 +164,11 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY(NX + NU, HASQ, SOC) 
   // c0 = 0 stands in, and the unchanged arithmetic gives y_old = 0 - clip(0) = 0: bit-identical iterates for
   // 8 n / (n + m) fewer bytes per element (21.33 -> 16 B at n = 6, m = 3) on every iteration without residuals, and n
   // fewer registers per ring slot.
-  static_assert(!XFREE || (!RESID && !RELAX), "XFREE needs z_old of no row");
+  // (round 3) XFREE = 1 together with RESID: the unbounded state rows are READ (the dual residual needs z_old = v_old) and
+  // written, but skip the clip / dual arithmetic and the two sums that are identically zero -- for the blocks whose kernels are
+  // bound by fp64 issue rather than HBM (n + m >= 12).
+  static_assert(!XFREE || !RELAX, "XFREE needs no over-relaxation");
+  static_assert(!(XFREE == 2 && RESID), "the residuals need v of every row");
   const RowView vv(v, (size_t)k0 * NB * P, (size_t)(k1 - k0) * NB * P * 8);
   const RowView vd(dbuf, (size_t)k0 * NU * P, (size_t)(k1 - k0) * NU * P * 8);
   const RowView vm(dbb, (size_t)k0 * NU * P, (size_t)(k1 - k0) * NU * P * 8);
@@ -190,7 +194,7 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY(NX + NU, HASQ, SOC) 
     const unsigned r0 = (unsigned)(kj - k0) * NB * PB;
 #pragma unroll
     for (int r = 0; r < NB; ++r) {
-      l0[j][r] = (XFREE && r >= NU) ? 0.0 : vv.load<ADMM_ALT_LOAD_AUX>(lb, r0 + r * PB);
+      l0[j][r] = (XFREE && !RESID && r >= NU) ? 0.0 : vv.load<ADMM_ALT_LOAD_AUX>(lb, r0 + r * PB);
       if (HASQ) lq[j][r] = vq.load<ADMM_ALT_LOAD_AUX>(lb, r0 + r * PB);
     }
   }
@@ -226,7 +230,7 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY(NX + NU, HASQ, SOC) 
           const unsigned r0 = (unsigned)(kn - k0) * NB * PB;
 #pragma unroll
           for (int r = 0; r < NB; ++r) {
-            l0[j][r] = (XFREE && r >= NU) ? 0.0 : vv.load<ADMM_ALT_LOAD_AUX>(lb, r0 + r * PB);
+            l0[j][r] = (XFREE && !RESID && r >= NU) ? 0.0 : vv.load<ADMM_ALT_LOAD_AUX>(lb, r0 + r * PB);
             if (HASQ) lq[j][r] = vq.load<ADMM_ALT_LOAD_AUX>(lb, r0 + r * PB);
           }
         }
@@ -297,6 +301,12 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY(NX + NU, HASQ, SOC) 
             if (XFREE != 2) vv.store<ADMM_ALT_STORE_AUX>(wv[r], lb_st, r0 + r * PB);
             g[r] = -rho * wv[r];
             if (HASQ) g[r] += cq[r];
+            if (RESID) {          // w - z+ = 0 and y+ = 0 on this row; z+ = w, z_old = v_old
+              const double ds = wv[r] - c0[r];
+              a_s = fma(ds, ds, a_s);
+              a_w = fma(wv[r], wv[r], a_w);
+              a_z = fma(wv[r], wv[r], a_z);
+            }
             continue;
           }
           const bool ball = SOC && r < NU;
@@ -436,7 +446,11 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY(NX + NU, HASQ, SOC) 
   // c0 = 0 stands in, and the unchanged arithmetic gives y_old = 0 - clip(0) = 0: bit-identical iterates for
   // 8 n / (n + m) fewer bytes per element (21.33 -> 16 B at n = 6, m = 3) on every iteration without residuals, and n
   // fewer registers per ring slot.
-  static_assert(!XFREE || (!RESID && !RELAX), "XFREE needs z_old of no row");
+  // (round 3) XFREE = 1 together with RESID: the unbounded state rows are READ (the dual residual needs z_old = v_old) and
+  // written, but skip the clip / dual arithmetic and the two sums that are identically zero -- for the blocks whose kernels are
+  // bound by fp64 issue rather than HBM (n + m >= 12).
+  static_assert(!XFREE || !RELAX, "XFREE needs no over-relaxation");
+  static_assert(!(XFREE == 2 && RESID), "the residuals need v of every row");
   const RowView vv(v, (size_t)k0 * NB * P, (size_t)(k1 - k0) * NB * P * 8);
   const RowView vd(dbuf, (size_t)k0 * NU * P, (size_t)(k1 - k0) * NU * P * 8);
   const RowView vm(dbb, (size_t)k0 * NU * P, (size_t)(k1 - k0) * NU * P * 8);
@@ -467,7 +481,7 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY(NX + NU, HASQ, SOC) 
     const unsigned r0 = (unsigned)SIDX(kj) * NB * PB;
 #pragma unroll
     for (int r = 0; r < NB; ++r) {
-      l0[j][r] = (XFREE && r >= NU) ? 0.0 : vv.load<ADMM_ALT_LOAD_AUX>(lb, r0 + r * PB);
+      l0[j][r] = (XFREE && !RESID && r >= NU) ? 0.0 : vv.load<ADMM_ALT_LOAD_AUX>(lb, r0 + r * PB);
       if (HASQ) lq[j][r] = vq.load<ADMM_ALT_LOAD_AUX>(lb, r0 + r * PB);
     }
   }
@@ -504,7 +518,7 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY(NX + NU, HASQ, SOC) 
           const unsigned r0 = (unsigned)SIDX(kn) * NB * PB;
 #pragma unroll
           for (int r = 0; r < NB; ++r) {
-            l0[j][r] = (XFREE && r >= NU) ? 0.0 : vv.load<ADMM_ALT_LOAD_AUX>(lb, r0 + r * PB);
+            l0[j][r] = (XFREE && !RESID && r >= NU) ? 0.0 : vv.load<ADMM_ALT_LOAD_AUX>(lb, r0 + r * PB);
             if (HASQ) lq[j][r] = vq.load<ADMM_ALT_LOAD_AUX>(lb, r0 + r * PB);
           }
         }
@@ -560,6 +574,12 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY(NX + NU, HASQ, SOC) 
               if (XFREE != 2) vv.store<ADMM_ALT_STORE_AUX>(wv[r], lb_st, r0 + r * PB);
               g[r] = -rho * wv[r];
               if (HASQ) g[r] += cq[r];
+              if (RESID) {
+                const double ds = wv[r] - c0[r];
+                a_s = fma(ds, ds, a_s);
+                a_w = fma(wv[r], wv[r], a_w);
+                a_z = fma(wv[r], wv[r], a_z);
+              }
               continue;
             }
             const bool ball = SOC && r < NU;
