@@ -173,6 +173,7 @@ static int setup_common(admm_handle** out, const admm_problem* p, const admm_opt
   h->ts_n = ts_n; h->ts_rank = ts_rank; h->ts_fn = ts_fn; h->ts_ctx = ts_ctx;
   h->N = p->N; h->n = p->n; h->m = p->m; h->nb = p->n + p->m; h->batch = p->batch;
   h->L = p->N * h->nb;
+  h->wk0 = 0; h->wk1 = p->N;           // stage window of the big arrays: the whole horizon unless this becomes a time shard (below)
   h->pitch = ((p->batch + 63) / 64) * 64;
   h->has_q = p->q != nullptr;
   h->has_soc = problem_has_soc(p);
@@ -306,12 +307,18 @@ static int setup_common(admm_handle** out, const admm_problem* p, const admm_opt
 
   HIP_TRY_RELEASE(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   const size_t P = h->pitch, L = h->L;
-  TRY_RELEASE(dalloc(&h->w, L * P));
-  TRY_RELEASE(dalloc(&h->z, L * P));
-  TRY_RELEASE(dalloc(&h->y, L * P));
-  TRY_RELEASE(dalloc(&h->v, L * P));
-  if (h->has_q) TRY_RELEASE(dalloc(&h->q, L * P));
-  TRY_RELEASE(dalloc(&h->dbuf, (size_t)h->N * h->m * P));
+  // the stage window of the big arrays: a time shard of several ranks holds its own stages only (admm_runtime.hpp)
+  h->wk0 = 0; h->wk1 = h->N;
+  if (ts_n > 1 && std::getenv("ADMM_TS_FULL_ARRAYS") == nullptr) { h->wk0 = h->fac.seg_start[h->ts_s0]; h->wk1 = h->fac.seg_start[h->ts_s0 + h->ts_sl]; }
+  const size_t Lw = win_rows(h), Nmw = (size_t)(h->wk1 - h->wk0) * h->m;
+  // (dalloc into the field, then bias it: release() undoes the bias before hipFree)
+#define DALLOC_WIN(field, count, bias) do { TRY_RELEASE(dalloc(&(field), (count))); (field) -= (bias); } while (0)
+  DALLOC_WIN(h->w, Lw * P, win_bias(h));
+  DALLOC_WIN(h->z, Lw * P, win_bias(h));
+  DALLOC_WIN(h->y, Lw * P, win_bias(h));
+  DALLOC_WIN(h->v, Lw * P, win_bias(h));
+  if (h->has_q) DALLOC_WIN(h->q, Lw * P, win_bias(h));
+  DALLOC_WIN(h->dbuf, Nmw * P, win_bias_m(h));
   {  // scan operands: in = tseg | x0 | eseg | pad,  out = t_in | pad | x_in | pad  (admm_factor.hpp)
     const size_t Sn = (size_t)h->S * h->n;
     TRY_RELEASE(dalloc(&h->scan_in, (size_t)h->fac.scanK * P));
@@ -385,8 +392,8 @@ static int setup_common(admm_handle** out, const admm_problem* p, const admm_opt
     TRY_RELEASE(dalloc(&h->recBE, h->fac.recBE.size()));
     TRY_RELEASE(dalloc(&h->scanWpB, h->fac.scanWpB.size()));
     TRY_RELEASE(dalloc(&h->scan_rangeB, h->fac.scanRangeB.size()));
-    TRY_RELEASE(dalloc(&h->mvec, (size_t)h->N * h->m * P));     // db rows of the forward elimination
-    HIP_TRY_RELEASE(hipMemsetAsync(h->mvec, 0, sizeof(double) * (size_t)h->N * h->m * P, h->stream));
+    DALLOC_WIN(h->mvec, Nmw * P, win_bias_m(h));               // db rows of the forward elimination
+    HIP_TRY_RELEASE(hipMemsetAsync(h->mvec + win_bias_m(h), 0, sizeof(double) * Nmw * P, h->stream));
     HIP_TRY_RELEASE(hipMemcpy(h->recFE, h->fac.recFE.data(), sizeof(double) * h->fac.recFE.size(), hipMemcpyHostToDevice));
     HIP_TRY_RELEASE(hipMemcpy(h->recBE, h->fac.recBE.data(), sizeof(double) * h->fac.recBE.size(), hipMemcpyHostToDevice));
     if (!h->scan_gemv) HIP_TRY_RELEASE(hipMemcpy(h->scanWpB, h->fac.scanWpB.data(), sizeof(double) * h->fac.scanWpB.size(), hipMemcpyHostToDevice));
@@ -405,15 +412,15 @@ static int setup_common(admm_handle** out, const admm_problem* p, const admm_opt
   TRY_RELEASE(dalloc(&h->status, P));
   TRY_RELEASE(dalloc(&h->iters, P));
   TRY_RELEASE(dalloc(&h->nconv, 1));
-  h->stage_rows = L;
-  TRY_RELEASE(dalloc(&h->stage, L * (size_t)h->batch));
+  h->stage_rows = Lw;
+  TRY_RELEASE(dalloc(&h->stage, Lw * (size_t)h->batch));
   HIP_TRY_RELEASE(hipHostMalloc((void**)&h->h_nconv, sizeof(int), hipHostMallocDefault));
 
-  HIP_TRY_RELEASE(hipMemsetAsync(h->w, 0, sizeof(double) * L * P, h->stream));
-  HIP_TRY_RELEASE(hipMemsetAsync(h->z, 0, sizeof(double) * L * P, h->stream));
-  HIP_TRY_RELEASE(hipMemsetAsync(h->y, 0, sizeof(double) * L * P, h->stream));
-  HIP_TRY_RELEASE(hipMemsetAsync(h->v, 0, sizeof(double) * L * P, h->stream));
-  HIP_TRY_RELEASE(hipMemsetAsync(h->dbuf, 0, sizeof(double) * (size_t)h->N * h->m * P, h->stream));
+  HIP_TRY_RELEASE(hipMemsetAsync(h->w + win_bias(h), 0, sizeof(double) * Lw * P, h->stream));
+  HIP_TRY_RELEASE(hipMemsetAsync(h->z + win_bias(h), 0, sizeof(double) * Lw * P, h->stream));
+  HIP_TRY_RELEASE(hipMemsetAsync(h->y + win_bias(h), 0, sizeof(double) * Lw * P, h->stream));
+  HIP_TRY_RELEASE(hipMemsetAsync(h->v + win_bias(h), 0, sizeof(double) * Lw * P, h->stream));
+  HIP_TRY_RELEASE(hipMemsetAsync(h->dbuf + win_bias_m(h), 0, sizeof(double) * Nmw * P, h->stream));
   HIP_TRY_RELEASE(hipMemsetAsync(h->part, 0, sizeof(double) * part_chunks * 5 * P, h->stream));
   HIP_TRY_RELEASE(hipMemsetAsync(h->resid, 0, sizeof(double) * 5 * P, h->stream));
   HIP_TRY_RELEASE(hipMemsetAsync(h->status, 0, sizeof(int) * P, h->stream));
@@ -433,6 +440,7 @@ static int setup_common(admm_handle** out, const admm_problem* p, const admm_opt
   TRY_RELEASE(upload_transposed(h, p->x0, h->x0, h->n));
   if (h->has_q) TRY_RELEASE(upload_transposed(h, p->q, h->q, h->L));
   HIP_TRY_RELEASE(hipStreamSynchronize(h->stream));
+#undef DALLOC_WIN
 #undef TRY_RELEASE
 #undef HIP_TRY_RELEASE
   *out = h;

@@ -33,6 +33,18 @@ int upload_h2d(admm_handle* h, void* dst, const void* src, size_t bytes) {
 
 // QP-major host array (batch x rows) -> batch-minor device array (rows x pitch)
 int upload_transposed(admm_handle* h, const double* src, double* dst, int rows) {
+  if (rows == h->L && windowed(h)) {
+    // a state-sized array of a handle that holds a stage window only: rows [r0, r0 + Lw) of every QP's vector (a strided 2-D
+    // copy out of the caller's L x batch array), transposed into the window (dst is the biased pointer)
+    const size_t r0 = win_row0(h), Lw = win_rows(h);
+    HIP_TRY(hipMemcpy2DAsync(h->stage, Lw * sizeof(double), src + r0, (size_t)h->L * sizeof(double), Lw * sizeof(double), h->batch,
+                             hipMemcpyHostToDevice, h->stream));
+    dim3 gridw(((int)Lw + admm::T_TILE - 1) / admm::T_TILE, (h->pitch + admm::T_TILE - 1) / admm::T_TILE), blockw(admm::T_TILE * 8);
+    hipLaunchKernelGGL(admm::to_batch_minor_kernel, gridw, blockw, 0, h->stream, h->stage, dst + win_bias(h), h->batch, (int)Lw, h->pitch);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return ADMM_OK;
+  }
   if ((size_t)rows > h->stage_rows) return fail(ADMM_ERR_INVALID, "internal: staging buffer too small");
   int rc_up;
   if ((rc_up = upload_h2d(h, h->stage, src, sizeof(double) * (size_t)rows * h->batch))) return rc_up;
@@ -44,6 +56,16 @@ int upload_transposed(admm_handle* h, const double* src, double* dst, int rows) 
 }
 
 int download_transposed(admm_handle* h, const double* src, double* dst, int rows) {
+  if (rows == h->L && windowed(h)) {          // the window's rows only; the caller's other rows are left alone
+    const size_t r0 = win_row0(h), Lw = win_rows(h);
+    dim3 gridw(((int)Lw + admm::T_TILE - 1) / admm::T_TILE, (h->pitch + admm::T_TILE - 1) / admm::T_TILE), blockw(admm::T_TILE * 8);
+    hipLaunchKernelGGL(admm::from_batch_minor_kernel, gridw, blockw, 0, h->stream, src + win_bias(h), h->stage, h->batch, (int)Lw, h->pitch);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy2DAsync(dst + r0, (size_t)h->L * sizeof(double), h->stage, Lw * sizeof(double), Lw * sizeof(double), h->batch,
+                             hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return ADMM_OK;
+  }
   dim3 grid((rows + admm::T_TILE - 1) / admm::T_TILE, (h->pitch + admm::T_TILE - 1) / admm::T_TILE), block(admm::T_TILE * 8);
   hipLaunchKernelGGL(admm::from_batch_minor_kernel, grid, block, 0, h->stream, src, h->stage, h->batch, rows, h->pitch);
   HIP_TRY(hipGetLastError());
@@ -188,6 +210,11 @@ void release(admm_handle* h) {
   h->spec_stale.clear();
   (void)hipSetDevice(h->device);
   destroy_graph(h);
+  // the big per-stage arrays are held as pointers biased by the stage window (admm_runtime.hpp): undo that before freeing
+  for (double** b : {&h->w, &h->z, &h->y, &h->v, &h->q})
+    if (*b) *b += win_bias(h);
+  for (double** b : {&h->dbuf, &h->mvec})
+    if (*b) *b += win_bias_m(h);
   double** bufs[] = {&h->w, &h->z, &h->y, &h->v, &h->q, &h->dbuf, &h->scan_in, &h->scan_out, &h->scanWp,
                      &h->part, &h->resid, &h->lo, &h->hi, &h->ub, &h->recB, &h->recF, &h->recS, &h->stage,
                      &h->recFE, &h->recBE, &h->mvec, &h->scanWpB};

@@ -187,13 +187,16 @@ int ensure_zy(admm_handle* h) {
     h->zy_valid = true;
     return ADMM_OK;
   }
-  dim3 grid((h->pitch / 2 + Z_THREADS - 1) / Z_THREADS, h->zchunks), block(Z_THREADS);
+  // (over the handle's stage window: the whole horizon unless it is a time shard; rows are relative to the window's first)
+  const size_t b = win_bias(h), r0 = win_row0(h);
+  const int Lw = (int)win_rows(h);
+  dim3 grid((h->pitch / 2 + Z_THREADS - 1) / Z_THREADS, (Lw + h->zrows - 1) / h->zrows), block(Z_THREADS);
   if (h->has_soc)
-    hipLaunchKernelGGL(admm::v_to_zy_soc_kernel, grid, block, 0, h->stream, (const double*)h->v, h->z, h->y,
-                       h->lo, h->hi, h->ub, h->L, h->zrows, h->pitch, h->nb, h->m);
+    hipLaunchKernelGGL(admm::v_to_zy_soc_kernel, grid, block, 0, h->stream, (const double*)(h->v + b), h->z + b, h->y + b,
+                       h->lo + r0, h->hi + r0, h->ub + h->wk0, Lw, h->zrows, h->pitch, h->nb, h->m);
   else
-    hipLaunchKernelGGL(admm::v_to_zy_kernel, grid, block, 0, h->stream, (const double*)h->v, h->z, h->y,
-                       h->lo, h->hi, h->L, h->zrows, h->pitch);
+    hipLaunchKernelGGL(admm::v_to_zy_kernel, grid, block, 0, h->stream, (const double*)(h->v + b), h->z + b, h->y + b,
+                       h->lo + r0, h->hi + r0, Lw, h->zrows, h->pitch);
   h->zy_valid = true;
   return ADMM_OK;
 }

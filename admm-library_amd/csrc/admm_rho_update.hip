@@ -176,8 +176,8 @@ int set_rho_internal(admm_handle* h, double rho_new) {
   if ((rc = ensure_zy(h))) return rc;
   {
     const double c = h->opt.rho / rho_new;
-    const size_t count2 = (size_t)h->L * h->pitch / 2;      // pitch is even
-    hipLaunchKernelGGL(admm::scale_kernel, dim3(2048), dim3(256), 0, h->stream, h->y, c, count2);
+    const size_t count2 = win_rows(h) * h->pitch / 2;       // pitch is even; the handle's stage window
+    hipLaunchKernelGGL(admm::scale_kernel, dim3(2048), dim3(256), 0, h->stream, h->y + win_bias(h), c, count2);
     HIP_TRY(hipGetLastError());
   }
   h->zy_valid = true;

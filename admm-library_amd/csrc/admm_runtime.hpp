@@ -62,6 +62,11 @@ struct admm_handle {
   // time-sharded handle (admm_setup_timeshard): this rank runs segments [ts_s0, ts_s0 + ts_sl) of the S the horizon is cut into
   int ts_n = 0, ts_rank = 0, ts_s0 = 0, ts_sl = 0;      // ts_n = 0: an ordinary handle
   admm_exchange_fn ts_fn = nullptr;
+  // Stage window [wk0, wk1) of the big per-stage arrays (w, z, y, v, q: (n + m) rows per stage; dbuf, mvec: m rows per stage):
+  // the whole horizon for an ordinary handle; a time shard of several ranks ALLOCATES only its own stages.  The pointers
+  // h->w ... are biased by the window's first row (allocation - wk0 * rows_per_stage * pitch), so the kernels, which address
+  // rows by their global stage index, run unchanged; only the window's rows are ever touched (admm::rt::win_* below).
+  int wk0 = 0, wk1 = 0;
   void* ts_ctx = nullptr;
   bool solve_active = false;     // between admm_solve_begin and admm_solve_end: only then are candidate factors kept / started
   // ADMM_FLAG_HISTORY: one record per stopping test of the last admm_solve
@@ -275,6 +280,13 @@ void spec_reap(admm_handle* h, bool all);
 std::unique_ptr<SpecFactor> spec_take(admm_handle* h, double rho);
 void spec_start(admm_handle* h);
 int set_rho_internal(admm_handle* h, double rho_new);
+
+// ---- the stage window of the big per-stage arrays (see admm_handle::wk0)
+inline size_t win_row0(const admm_handle* h) { return (size_t)h->wk0 * h->nb; }                       // first stacked row held
+inline size_t win_rows(const admm_handle* h) { return (size_t)(h->wk1 - h->wk0) * h->nb; }            // stacked rows held
+inline size_t win_bias(const admm_handle* h) { return win_row0(h) * (size_t)h->pitch; }               // elements the state pointers are biased by
+inline size_t win_bias_m(const admm_handle* h) { return (size_t)h->wk0 * h->m * (size_t)h->pitch; }   // ... dbuf / mvec
+inline bool windowed(const admm_handle* h) { return h->wk0 != 0 || h->wk1 != h->N; }
 
 // ---- one-line helpers
 // vform: read the state from h->v (z = clip(v), y = v - z rebuilt in registers)

@@ -325,9 +325,11 @@ const char* admm_last_warning(void);
  * calling entry point with ADMM_ERR_HIP).
  *
  * admm_setup_timeshard takes the GLOBAL problem on every rank.  options.segments = total segment count (0 = automatic), a
- * multiple of nranks.  Shared dynamics only, fused paths only (no ADMM_FLAG_UNFUSED / _GRAPH / _SCAN_CHAIN).  State arrays
- * keep the full horizon on every rank in this version (only the rank's own stages are current: admm_get returns whole vectors
- * whose rows outside [stage_lo, stage_hi) * (n + m) are stale; the host side gathers the windows -- admm_get_window). */
+ * multiple of nranks.  Shared dynamics only, fused paths only (no ADMM_FLAG_UNFUSED / _GRAPH / _SCAN_CHAIN).  A rank ALLOCATES
+ * the state (w, z, y, v, q and the feed-forward rows) of its own stages only: admm_set_state / admm_solve(z0, y0) /
+ * admm_update_instances(q) take the usual L x batch arrays and use the rows [stage_lo, stage_hi) * (n + m) of every QP,
+ * admm_get writes those rows of the caller's arrays and leaves the others alone; the host side assembles the windows
+ * (admm_get_window). */
 #define ADMM_EXCHANGE_ALLGATHER 0
 typedef int (*admm_exchange_fn)(void* ctx, void* hip_stream, int32_t op, double* buf, int64_t count);
 int admm_setup_timeshard(admm_handle** out, const admm_problem* p, const admm_options* o, int32_t rank, int32_t nranks,
