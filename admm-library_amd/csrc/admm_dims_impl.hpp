@@ -21,7 +21,7 @@ namespace {
 
 template <int NX, int NU>
 void launch_dim(const XLaunch& l, XKernel k, bool a, bool b) {
-  const dim3 grid((l.pitch + XB_THREADS - 1) / XB_THREADS, l.S), block(XB_THREADS);
+  const dim3 grid = sweep_grid((l.pitch + XB_THREADS - 1) / XB_THREADS, l.S), block(XB_THREADS);
   switch (k) {
     case XKernel::XB: {
       const double* zin = a ? l.v : l.z;

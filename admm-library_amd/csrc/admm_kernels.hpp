@@ -47,6 +47,23 @@ constexpr int prefetch_depth(int nb) {
 #endif
 #define ADMM_X_OCCUPANCY __attribute__((amdgpu_waves_per_eu(1, ADMM_X_MAX_WAVES)))
 
+// Grid of the sweep kernels: (column block, segment).  Workgroups are dealt to the 8 XCDs round-robin in linear order, and the 16
+// column blocks of a segment all read that segment's stage records; with the column block as the fast index (the default) a
+// segment's workgroups are spread over all XCDs and every XCD's L2 fetches every segment's records (~14 MB of the 28-32 MB
+// read-side excess of a launch at configs[2]).  ADMM_SEGMENT_MAJOR_GRID=1 makes the SEGMENT the fast index -- linear id % 8 =
+// segment % 8: two segments per XCD at S = 16, their records fetched once -- the XCD-aware mapping.  Measured round 3, same box,
+// two runs each (tools/ab_variants.sh colmaj segmaj): 6766 / 6608 vs 6700 / 6695 batch-iterations/s with residuals, 9930 / 9834 vs
+// 9717 / 9644 every 10th, n = 12: 3283 vs 3333 -- inside the run-to-run spread either way (the records are < 2 % of the traffic and
+// sit in the infinity cache), so the default stays.
+#ifndef ADMM_SEGMENT_MAJOR_GRID
+#define ADMM_SEGMENT_MAJOR_GRID 0
+#endif
+__device__ __forceinline__ int grid_col_block() { return ADMM_SEGMENT_MAJOR_GRID ? blockIdx.y : blockIdx.x; }
+__device__ __forceinline__ int grid_segment() { return ADMM_SEGMENT_MAJOR_GRID ? blockIdx.x : blockIdx.y; }
+inline dim3 sweep_grid(int col_blocks, int segments) {
+  return ADMM_SEGMENT_MAJOR_GRID ? dim3(segments, col_blocks) : dim3(col_blocks, segments);
+}
+
 // Stage records (per-stage matrices + box, shared by the batch) are staged into LDS in
 // chunks of this many stages: <= 64 KiB per workgroup (two workgroups per CU still fit), a
 // multiple of the prefetch depth so that ring slots stay aligned across refills.
@@ -319,7 +336,7 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_X_OCCUPANCY void xb_kernel(
   // No early return (every wave must reach the barriers) and no store branches: lanes past the
   // pitch are clamped onto the last column for their LOADS (so they compute finite values) and
   // their STORES are dropped (out-of-range buffer offset) -- the stage loop stays branch-free.
-  const int col_raw = blockIdx.x * XB_THREADS + threadIdx.x;
+  const int col_raw = grid_col_block() * XB_THREADS + threadIdx.x;
   const int col = col_raw < pitch ? col_raw : pitch - 1;
 #ifdef ADMM_STORE_PRED      // A/B diagnostic: the older predicated-store form
   const bool st = col_raw < pitch;
@@ -329,7 +346,7 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_X_OCCUPANCY void xb_kernel(
   // Stores of clamped lanes go to an out-of-range buffer offset and are dropped by the hardware
   // (see RowView): still branch-free, and no lane ever writes a column it does not own.
   const unsigned lb_st = col_raw < pitch ? (unsigned)col * 8u : ROWVIEW_OOB;
-  const int s = blockIdx.y;
+  const int s = grid_segment();
   cint_p seg_start = as_const(seg_start_);
   const int k0 = seg_start[s], k1 = seg_start[s + 1];
   const size_t P = (size_t)pitch;
@@ -869,10 +886,10 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_X_OCCUPANCY void xf_kernel(
 #define ADMM_LD(R_, C_, BLK_, PTR_) (void)(PTR_)
   (void)rec16; (void)ops;
 #endif
-  const int col_raw = blockIdx.x * XB_THREADS + threadIdx.x;
+  const int col_raw = grid_col_block() * XB_THREADS + threadIdx.x;
   const int col = col_raw < pitch ? col_raw : pitch - 1;      // clamped lanes: loads only (see xb_kernel)
   const unsigned lb_st = col_raw < pitch ? (unsigned)col * 8u : ROWVIEW_OOB;
-  const int s = blockIdx.y;
+  const int s = grid_segment();
   cint_p seg_start = as_const(seg_start_);
   const int k0 = seg_start[s], k1 = seg_start[s + 1];
   const size_t P = (size_t)pitch;
@@ -1007,7 +1024,7 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_X_OCCUPANCY void xfz_kernel(
   (void)rec16; (void)ops;
 #endif
 
-  const int col_raw = blockIdx.x * XB_THREADS + threadIdx.x;
+  const int col_raw = grid_col_block() * XB_THREADS + threadIdx.x;
   const int col = col_raw < pitch ? col_raw : pitch - 1;      // clamped lanes: loads only (see xb_kernel)
 #ifdef ADMM_STORE_PRED
   const bool st = col_raw < pitch;
@@ -1017,7 +1034,7 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_X_OCCUPANCY void xfz_kernel(
   // v is updated IN PLACE, so a clamped lane must never store: a duplicate of the last column
   // running ahead would overwrite v rows its owner has not read yet.  Out-of-range offset = dropped.
   const unsigned lb_st = col_raw < pitch ? (unsigned)col * 8u : ROWVIEW_OOB;
-  const int s = blockIdx.y;
+  const int s = grid_segment();
   cint_p seg_start = as_const(seg_start_);
   const int k0 = seg_start[s], k1 = seg_start[s + 1];
   const size_t P = (size_t)pitch;

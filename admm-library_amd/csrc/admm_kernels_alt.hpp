@@ -149,10 +149,10 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY(NX + NU, HASQ, SOC) 
   (void)rec16; (void)ops;
 #endif
 
-  const int col_raw = blockIdx.x * XB_THREADS + threadIdx.x;
+  const int col_raw = grid_col_block() * XB_THREADS + threadIdx.x;
   const int col = col_raw < pitch ? col_raw : pitch - 1;      // clamped lanes: loads only (see xb_kernel)
   const unsigned lb_st = col_raw < pitch ? (unsigned)col * 8u : ROWVIEW_OOB;
-  const int s = blockIdx.y;
+  const int s = grid_segment();
   cint_p seg_start = as_const(seg_start_);
   const int k0 = seg_start[s], k1 = seg_start[s + 1];
   const size_t P = (size_t)pitch;
@@ -431,10 +431,10 @@ __global__ __launch_bounds__(XB_THREADS) ADMM_ALT_OCCUPANCY(NX + NU, HASQ, SOC) 
   (void)rec16; (void)ops;
 #endif
 
-  const int col_raw = blockIdx.x * XB_THREADS + threadIdx.x;
+  const int col_raw = grid_col_block() * XB_THREADS + threadIdx.x;
   const int col = col_raw < pitch ? col_raw : pitch - 1;
   const unsigned lb_st = col_raw < pitch ? (unsigned)col * 8u : ROWVIEW_OOB;
-  const int s = blockIdx.y;
+  const int s = grid_segment();
   cint_p seg_start = as_const(seg_start_);
   const int k0 = seg_start[s], k1 = seg_start[s + 1];
   const size_t P = (size_t)pitch;

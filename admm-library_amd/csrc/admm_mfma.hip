@@ -26,7 +26,7 @@ bool launch_dim(const XLaunch& l, XKernel k, bool resid, bool query_only) {
   if (query_only) return true;
   // one 16-QP tile per wave for small batches (waves beyond the batch idle), two otherwise
   const bool nt1 = l.pitch <= 128;
-  const dim3 grid((l.pitch + mf_cols(nt1 ? 1 : 2) - 1) / mf_cols(nt1 ? 1 : 2), l.S), block(MF_THREADS);
+  const dim3 grid = sweep_grid((l.pitch + mf_cols(nt1 ? 1 : 2) - 1) / mf_cols(nt1 ? 1 : 2), l.S), block(MF_THREADS);
   const bool relax = l.alpha != 1.0;
   if (l.has_q) {
     // A linear term q: HASQ forms of the fp64 alternating pair with one tile per wave (small batches), for the shape of the

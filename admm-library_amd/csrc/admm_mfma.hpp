@@ -183,7 +183,7 @@ __global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, c = lane & 15;
-  const int s = blockIdx.y;
+  const int s = grid_segment();
   cint_p seg_start = as_const(seg_start_);
   const int k0 = seg_start[s], k1 = seg_start[s + 1];
   const size_t P = (size_t)pitch;
@@ -203,14 +203,14 @@ __global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
   unsigned lbl[NT], lbs[NT];             // lane byte offsets for loads (clamped column) / stores (dropped if clamped)
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
-    const int col_raw = blockIdx.x * mf_cols(NT) + (wave * NT + nt) * 16 + c;
+    const int col_raw = grid_col_block() * mf_cols(NT) + (wave * NT + nt) * 16 + c;
     col[nt] = col_raw < pitch ? col_raw : pitch - 1;
     lbl[nt] = ((unsigned)g * (unsigned)pitch + (unsigned)col[nt]) * 8u;
     lbs[nt] = col_raw < pitch ? lbl[nt] : ROWVIEW_OOB;
   }
   // a wave all of whose columns lie beyond the batch (pad columns of the last 64, or the unused waves of a small
   // batch) takes part in the record staging and the barriers only
-  const bool wave_active = blockIdx.x * mf_cols(NT) + wave * NT * 16 < batch;
+  const bool wave_active = grid_col_block() * mf_cols(NT) + wave * NT * 16 < batch;
   // XFREE: the state rows are unbounded at every stage and neither residuals nor over-relaxation need z_old: their v is
   // not read (xfze_kernel explains why that is exact)
   static_assert(!XFREE || (!RESID && !RELAX), "XFREE needs z_old of no row");
@@ -445,7 +445,7 @@ __global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, c = lane & 15;
-  const int s = blockIdx.y;
+  const int s = grid_segment();
   cint_p seg_start = as_const(seg_start_);
   const int k0 = seg_start[s], k1 = seg_start[s + 1];
   const size_t P = (size_t)pitch;
@@ -464,14 +464,14 @@ __global__ __launch_bounds__(MF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
   unsigned lbl[NT], lbs[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
-    const int col_raw = blockIdx.x * mf_cols(NT) + (wave * NT + nt) * 16 + c;
+    const int col_raw = grid_col_block() * mf_cols(NT) + (wave * NT + nt) * 16 + c;
     col[nt] = col_raw < pitch ? col_raw : pitch - 1;
     lbl[nt] = ((unsigned)g * (unsigned)pitch + (unsigned)col[nt]) * 8u;
     lbs[nt] = col_raw < pitch ? lbl[nt] : ROWVIEW_OOB;
   }
   // a wave all of whose columns lie beyond the batch (pad columns of the last 64, or the unused waves of a small
   // batch) takes part in the record staging and the barriers only
-  const bool wave_active = blockIdx.x * mf_cols(NT) + wave * NT * 16 < batch;
+  const bool wave_active = grid_col_block() * mf_cols(NT) + wave * NT * 16 < batch;
   // XFREE: the state rows are unbounded at every stage and neither residuals nor over-relaxation need z_old: their v is
   // not read (xfze_kernel explains why that is exact)
   static_assert(!XFREE || (!RESID && !RELAX), "XFREE needs z_old of no row");
