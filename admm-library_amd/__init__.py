@@ -9,13 +9,13 @@ and the multi-GPU sharding helpers.  There is no CPU fallback: without the
 built library or without a GPU the solver raises.
 """
 from .problems import (Problem, double_integrator, cw_rendezvous, cw_formation, cw_matrices,
-                       random_ltv, random_instances, cw_rendezvous_instances, mean_motion, SEED0)
+                       random_ltv, random_instances, cw_rendezvous_instances, cw_formation_instances, mean_motion, SEED0)
 from .solver import (AdmmError, Options, Solver, admm_setup, admm_solve,
                      library_path, load_library, device_count, last_warning)
 from .sharding import (shard_bounds, shard_problem, gather_batch, global_residual_max, solve_sharded, TimeShardedSolver,
                        make_exchange, device_tensor)
 
-__all__ = ["TimeShardedSolver", "make_exchange", "device_tensor", "last_warning", "Problem", "double_integrator", "cw_rendezvous", "cw_formation", "cw_matrices", "random_ltv", "random_instances", "cw_rendezvous_instances",
+__all__ = ["TimeShardedSolver", "make_exchange", "device_tensor", "last_warning", "Problem", "double_integrator", "cw_rendezvous", "cw_formation", "cw_matrices", "random_ltv", "random_instances", "cw_rendezvous_instances", "cw_formation_instances",
            "mean_motion", "SEED0", "AdmmError", "Options", "Solver", "admm_setup",
            "admm_solve", "library_path", "load_library", "device_count",
            "shard_bounds", "shard_problem", "gather_batch", "global_residual_max", "solve_sharded"]

@@ -66,11 +66,13 @@ struct PLaunch {
   double *tseg, *eseg, *tin, *xin;     // [S][n][pitch]
   int* grow;                           // SEGMENTS: set if a transfer matrix exceeds the conditioning bound
   bool rows;                           // small batches: the sweeps with a QP's rows spread over lanes (admm_pinst_rows.hpp)
+  bool rows_factor;                    // (6, 3) only: FACTOR / SEGMENTS through the wide shapes' kernels (admm_pinst_wide.hpp)
   bool has_soc;                        // thrust-magnitude bound ub [N] on the control rows (one-lane kernels only)
   const double* ub;
 };
 enum class PKernel { FACTOR, XB, XF, XFZ, SEGMENTS, SCAN };
 bool launch_pinst(const PLaunch& l, PKernel k, bool query_only);
+bool pinst_rows_only(int n, int m);   // a wide shape: rows-over-lanes kernels whatever the batch, no thrust-magnitude forms
 void launch_padapt(hipStream_t stream, const double* resid, const int* status, double* rhov, int* nupd, int* todo,
                    double* cscale, int* nchanged, double mu2, double tau, int adapt_max, int pitch, int batch, double* rho_prev);
 void launch_padapt_veto(hipStream_t stream, const int* qflag, const double* rho_prev, double* rhov, int* nupd, int* todo,
@@ -79,6 +81,8 @@ void launch_padapt_scale(hipStream_t stream, double* y, const double* cscale, co
 void launch_pv_to_zy(hipStream_t stream, const double* v, double* z, double* y, const double* lo, const double* hi, size_t count);
 void launch_pv_to_zy_soc(hipStream_t stream, const double* v, double* z, double* y, const double* lo, const double* hi,
                          const double* ub, int N, int nb, int m, int pitch);
+// QP-major staged operand (batch x N x E) -> the wide shapes' tiled layout (admm_pinst.hpp, Operand / to_tiled_kernel)
+void launch_to_tiled(hipStream_t stream, const double* src, double* dst, int batch, int N, int E, int n, int pitch);
 const char* dims_pinst();
 // " (n,m) (n,m) ..." of a group, for error messages
 const char* dims_group0();

@@ -55,6 +55,18 @@ int upload_transposed(admm_handle* h, const double* src, double* dst, int rows) 
   return ADMM_OK;
 }
 
+// QP-major host operand (batch x N x E) -> the wide shapes' tiled device layout
+int upload_tiled(admm_handle* h, const double* src, double* dst, int E) {
+  const size_t rows = (size_t)h->N * E;
+  if (rows > h->stage_rows) return fail(ADMM_ERR_INVALID, "internal: staging buffer too small");
+  int rc_up;
+  if ((rc_up = upload_h2d(h, h->stage, src, sizeof(double) * rows * h->batch))) return rc_up;
+  admm::launch_to_tiled(h->stream, h->stage, dst, h->batch, h->N, E, h->n, h->pitch);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return ADMM_OK;
+}
+
 int download_transposed(admm_handle* h, const double* src, double* dst, int rows) {
   if (rows == h->L && windowed(h)) {          // the window's rows only; the caller's other rows are left alone
     const size_t r0 = win_row0(h), Lw = win_rows(h);

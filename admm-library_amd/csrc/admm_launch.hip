@@ -50,6 +50,7 @@ admm::PLaunch plaunch_of(const admm_handle* h) {
   l.S = h->S; l.seg_start = h->seg_start; l.Omd = h->Omd; l.Psd = h->Psd; l.Segd = h->Segd;
   l.tseg = h->tseg; l.eseg = h->eseg; l.tin = h->tin; l.xin = h->xin; l.grow = h->pgrow;
   l.rows = h->pi_rows;
+  l.rows_factor = h->pi_rows_factor;
   l.has_soc = h->has_soc; l.ub = h->ub;
   l.Ad = h->Ad; l.Bd = h->Bd; l.Q = h->Qd; l.R = h->Rd; l.QN = h->QNd; l.Kd = h->Kd; l.Sd = h->Sd; l.fail = h->pfail;
   l.qflag = nullptr;

@@ -621,6 +621,47 @@ __global__ __launch_bounds__(PI_THREADS) void pseg_kernel(
 constexpr int PSCAN_D = 8;        // steps whose operands are prefetched as one group
 template <int NX> struct PscanShape { static constexpr int QPW = NX <= 2 ? 32 : (NX <= 4 ? 16 : (NX <= 8 ? 8 : 4)); };
 
+// ---- operand layout of the rows-over-lanes kernels ----
+// Batch-minor (every other array of the library): element e of stage k of QP col at [(k * E + e) * pitch + col].  A wave of the
+// rows-over-lanes kernels serves QPW QPs, so each of its accesses takes 8 * QPW bytes out of every 128-byte line, and the line is
+// complete only if the waves of the neighbouring QPs read it while it is cached: measured at (12, 6), 4096 x 1000, 1.7-1.8 x the
+// algorithmic HBM bytes.  TILED (the operand arrays A, B, K, S^-1, Omega, Psi of the wide shapes; nothing else reads them):
+//     [stage k][QP group g = col / QPW][element e][c = col % QPW]
+// -- the E x QPW doubles a wave needs of a stage are ONE contiguous chunk (4.6 KB for A at n = 12), whole lines, its own.
+template <int NX, bool TILED>
+struct Operand {
+  static constexpr int QPW = PscanShape<NX>::QPW;
+  const double* p;       // element 0 of stage 0, this lane's QP
+  size_t kstride;        // doubles per stage: E * pitch in both layouts
+  size_t pitch_;
+  __device__ __forceinline__ Operand(const double* arr, int E, size_t P_, int col) {
+    p = TILED ? arr + (size_t)(col / QPW) * E * QPW + col % QPW : arr + col;
+    kstride = P_ * E;
+    pitch_ = P_;
+  }
+  __device__ __forceinline__ const double* stage(int k) const { return p + (size_t)k * kstride; }
+  __device__ __forceinline__ size_t el(int e) const { return TILED ? (size_t)e * QPW : (size_t)e * pitch_; }
+};
+
+// ---- lane geometry shared by the rows-over-lanes kernels (admm_pinst_rows.hpp, admm_pinst_wide.hpp) ----
+constexpr int PROWS_BLOCK = 256;      // up to 4 waves per workgroup: the 16 / QPW waves that share a 128-byte line of every array
+
+// lane geometry of the rows-over-lanes kernels: wave w of block b serves the QPW QPs from (b * waves + w) * QPW
+template <int NX>
+struct RowsLane {
+  static constexpr int QPW = PscanShape<NX>::QPW;
+  int c, ir, col;
+  __device__ __forceinline__ RowsLane() {
+    const int lane = threadIdx.x % PI_THREADS, wave = threadIdx.x / PI_THREADS, wpb = blockDim.x / PI_THREADS;
+    c = lane % QPW;
+    ir = lane / QPW;
+    col = (blockIdx.x * wpb + wave) * QPW + c;
+  }
+  // the value `v` holds on the lane that owns row l of this lane's QP
+  __device__ __forceinline__ double across(double v, int l) const { return __shfl(v, l * QPW + c, PI_THREADS); }
+};
+
+
 template <int NX>
 __global__ __launch_bounds__(PI_THREADS) void pscan_kernel(
     const double* __restrict__ Segd, const double* __restrict__ tseg, double* __restrict__ eseg,
@@ -722,6 +763,22 @@ __global__ __launch_bounds__(PI_THREADS) void pscan_kernel(
       if (g + 1 >= ngroups) break;
       if (g + 2 < ngroups) load(A, (g + 2) * D);
       steps(B, (g + 1) * D);
+    }
+  }
+}
+
+// QP-major staged array src[b][rows] (rows = N * E) -> TILED operand array dst[k][g][e][c] (Operand<., true>); columns beyond the
+// batch are zero.  Thread t of block (k, g-chunk) moves element (e, c) = (t / QPW, t % QPW): contiguous stores, QPW interleaved
+// contiguous loads.
+static __global__ __launch_bounds__(256) void to_tiled_kernel(const double* __restrict__ src, double* __restrict__ dst, int batch,
+                                                               int N, int E, int qpw, int pitch) {
+  const int G = pitch / qpw;
+  const size_t tile = (size_t)E * qpw;
+  for (size_t kg = blockIdx.x; kg < (size_t)N * G; kg += gridDim.x) {
+    const int k = (int)(kg / G), g = (int)(kg % G);
+    for (int t = threadIdx.x; t < (int)tile; t += 256) {
+      const int e = t / qpw, c = t % qpw, b = g * qpw + c;
+      dst[kg * tile + t] = b < batch ? src[((size_t)b * N + k) * E + e] : 0.0;
     }
   }
 }

@@ -19,45 +19,50 @@ namespace admm {
 #ifndef ADMM_PROWS_D
 #define ADMM_PROWS_D 2
 #endif
-constexpr int PROWS_D = ADMM_PROWS_D;      // stages per prefetch group (two groups alternate: up to 2 * PROWS_D - 1 stages in flight)
+// stages per prefetch group (two groups alternate: up to 2 * D - 1 stages in flight); one from n = 8: a stage is ~50 operands there
+template <int NX> struct ProwsDepth { static constexpr int D = NX >= 8 ? 1 : ADMM_PROWS_D; };
 
 // ---------------------------------------------------------------------------
 // Backward sweep, rows over lanes (the arithmetic of pxb_kernel):
 //     g = q - rho (z - y);  p = g^x + t;  h = B'p + g^u;  d_k = Si h -> dbuf;  t = A'p - K'h;   SEG: e += Omega_k d_k
 // ---------------------------------------------------------------------------
-template <int NX, int NU, bool HASQ, bool VFORM, bool PB, bool SEG>
-__global__ __launch_bounds__(PI_THREADS) void pxb_rows_kernel(
+template <int NX, int NU, bool HASQ, bool VFORM, bool PB, bool SEG, bool TILED = false>
+__global__ __launch_bounds__(PROWS_BLOCK) void pxb_rows_kernel(
     const double* __restrict__ z, const double* __restrict__ y, const double* __restrict__ q,
     const double* __restrict__ Ad, const double* __restrict__ Bd, const double* __restrict__ Kd,
     const double* __restrict__ Sd, const double* __restrict__ lo, const double* __restrict__ hi,
     double* __restrict__ dbuf, const double* __restrict__ rhov, int N, int pitch,
     const double* __restrict__ Omd, const int* __restrict__ seg_start, double* __restrict__ tseg, double* __restrict__ eseg) {
-  constexpr int NB = NX + NU, D = PROWS_D, QPW = PscanShape<NX>::QPW;
+  constexpr int NB = NX + NU, D = ProwsDepth<NX>::D, QPW = PscanShape<NX>::QPW;
   static_assert(NU <= NX && QPW * NX <= PI_THREADS, "rows over lanes: m <= n, n x QPW lanes");
-  const int lane = threadIdx.x, c = lane % QPW, ir = lane / QPW;
+  const RowsLane<NX> ln;
+  const int ir = ln.ir, col = ln.col;
+  if (col >= pitch) return;                                 // (a whole wave: pitch is a multiple of 64, hence of QPW)
   const bool live_x = ir < NX, live_u = ir < NU;
   const int i = live_x ? ir : 0, j = live_u ? ir : 0;       // (other lanes shadow row 0: loads and arithmetic only)
-  const int col = blockIdx.x * QPW + c;                     // pitch is a multiple of 64, hence of QPW
   const size_t P_ = (size_t)pitch;
   const double rho = rhov[col];
   const int sg = SEG ? (int)blockIdx.y : 0;
   const int ka = SEG ? seg_start[sg] : 0, kb = SEG ? seg_start[sg + 1] : N;
-  auto across = [&](double v, int l) { return __shfl(v, l * QPW + c, PI_THREADS); };   // row l's value of this QP
+  auto across = [&](double v, int l) { return ln.across(v, l); };   // row l's value of this QP
   struct Ops {
     double Acol[NX], Kcol[NU], Om[SEG ? NU : 1], Bcol[NX], Si[NU];
     double x0, x1, u0, u1, qx, qu, lox, hix, lou, hiu;
   };
+  const Operand<NX, TILED> opA(Ad, NX * NX, P_, col), opB(Bd, NX * NU, P_, col), opK(Kd, NU * NX, P_, col), opS(Sd, NU * NU, P_, col),
+      opO(SEG ? Omd : Ad, NX * NU, P_, col);
   auto load = [&](Ops& o, int k) {
+    const double *Ak = opA.stage(k), *Bk = opB.stage(k), *Kk = opK.stage(k), *Sk = opS.stage(k), *Ok = opO.stage(k);
 #pragma unroll
     for (int l = 0; l < NX; ++l) {
-      o.Acol[l] = Ad[((size_t)k * NX * NX + i * NX + l) * P_ + col];      // A[l][i]
-      o.Bcol[l] = Bd[((size_t)k * NX * NU + j * NX + l) * P_ + col];      // B[l][j]
+      o.Acol[l] = Ak[opA.el(i * NX + l)];      // A[l][i]
+      o.Bcol[l] = Bk[opB.el(j * NX + l)];      // B[l][j]
     }
 #pragma unroll
     for (int l = 0; l < NU; ++l) {
-      o.Kcol[l] = Kd[((size_t)k * NU * NX + l * NX + i) * P_ + col];      // K[l][i]
-      o.Si[l] = Sd[((size_t)k * NU * NU + j * NU + l) * P_ + col];
-      if (SEG) o.Om[l] = Omd[((size_t)k * NX * NU + i * NU + l) * P_ + col];
+      o.Kcol[l] = Kk[opK.el(l * NX + i)];      // K[l][i]
+      o.Si[l] = Sk[opS.el(j * NU + l)];
+      if (SEG) o.Om[l] = Ok[opO.el(i * NU + l)];
     }
     const size_t ox = ((size_t)k * NB + NU + i) * P_ + col, ou = ((size_t)k * NB + j) * P_ + col;
     o.x0 = z[ox]; o.u0 = z[ou];
@@ -138,25 +143,26 @@ __global__ __launch_bounds__(PI_THREADS) void pxb_rows_kernel(
 // Forward rollout (+ z-update, dual ascent, residual partials when ZUP; + w stored when STOREW), rows over lanes
 // (the arithmetic of pxfz_kernel):   u = -K x - d [- Psi t_in];  x <- A x + B u;   ZUP: v+ = wh + y_old -> v
 // ---------------------------------------------------------------------------
-template <int NX, int NU, bool ZUP, bool RESID, bool RELAX, bool VIN, bool PB, bool STOREW, bool SEG>
-__global__ __launch_bounds__(PI_THREADS) void pxfz_rows_kernel(
+template <int NX, int NU, bool ZUP, bool RESID, bool RELAX, bool VIN, bool PB, bool STOREW, bool SEG, bool TILED = false>
+__global__ __launch_bounds__(PROWS_BLOCK) void pxfz_rows_kernel(
     const double* __restrict__ dbuf, const double* __restrict__ x0, const double* __restrict__ Ad,
     const double* __restrict__ Bd, const double* __restrict__ Kd, const double* __restrict__ lo,
     const double* __restrict__ hi, const double* __restrict__ zin, const double* __restrict__ yin,
     double* __restrict__ v, double* __restrict__ w, double* __restrict__ part, double alpha, int N, int pitch,
     const double* __restrict__ Psd, const int* __restrict__ seg_start, const double* __restrict__ tin,
     const double* __restrict__ xin) {
-  constexpr int NB = NX + NU, D = PROWS_D, QPW = PscanShape<NX>::QPW;
+  constexpr int NB = NX + NU, D = ProwsDepth<NX>::D, QPW = PscanShape<NX>::QPW;
   constexpr bool NEEDZ = RESID || RELAX;
   static_assert(NU <= NX && QPW * NX <= PI_THREADS, "rows over lanes: m <= n, n x QPW lanes");
-  const int lane = threadIdx.x, c = lane % QPW, ir = lane / QPW;
+  const RowsLane<NX> ln;
+  const int ir = ln.ir, col = ln.col;
+  if (col >= pitch) return;
   const bool live_x = ir < NX, live_u = ir < NU;
   const int i = live_x ? ir : 0, j = live_u ? ir : 0;
-  const int col = blockIdx.x * QPW + c;
   const size_t P_ = (size_t)pitch;
   const int sg = SEG ? (int)blockIdx.y : 0;
   const int ka = SEG ? seg_start[sg] : 0, kb = SEG ? seg_start[sg + 1] : N;
-  auto across = [&](double val, int l) { return __shfl(val, l * QPW + c, PI_THREADS); };
+  auto across = [&](double val, int l) { return ln.across(val, l); };
   double x = SEG ? xin[((size_t)sg * NX + i) * P_ + col] : x0[(size_t)i * P_ + col];
   double ti[SEG ? NX : 1];
 #pragma unroll
@@ -167,15 +173,18 @@ __global__ __launch_bounds__(PI_THREADS) void pxfz_rows_kernel(
     double Krow[NX], Ps[SEG ? NX : 1], Arow[NX], Brow[NU], dj;
     double x0, x1, u0, u1, lox, hix, lou, hiu;
   };
+  const Operand<NX, TILED> opA(Ad, NX * NX, P_, col), opB(Bd, NX * NU, P_, col), opK(Kd, NU * NX, P_, col),
+      opP(SEG ? Psd : Kd, NU * NX, P_, col);
   auto load = [&](Ops& o, int k) {
+    const double *Ak = opA.stage(k), *Bk = opB.stage(k), *Kk = opK.stage(k), *Pk = opP.stage(k);
 #pragma unroll
     for (int l = 0; l < NX; ++l) {
-      o.Krow[l] = Kd[((size_t)k * NU * NX + j * NX + l) * P_ + col];      // K[j][l]
-      o.Arow[l] = Ad[((size_t)k * NX * NX + l * NX + i) * P_ + col];      // A[i][l]
-      if (SEG) o.Ps[l] = Psd[((size_t)k * NU * NX + j * NX + l) * P_ + col];
+      o.Krow[l] = Kk[opK.el(j * NX + l)];      // K[j][l]
+      o.Arow[l] = Ak[opA.el(l * NX + i)];      // A[i][l]
+      if (SEG) o.Ps[l] = Pk[opP.el(j * NX + l)];
     }
 #pragma unroll
-    for (int l = 0; l < NU; ++l) o.Brow[l] = Bd[((size_t)k * NX * NU + l * NX + i) * P_ + col];   // B[i][l]
+    for (int l = 0; l < NU; ++l) o.Brow[l] = Bk[opB.el(l * NX + i)];   // B[i][l]
     o.dj = dbuf[((size_t)k * NU + j) * P_ + col];
     const size_t ox = ((size_t)k * NB + NU + i) * P_ + col, ou = ((size_t)k * NB + j) * P_ + col;
     if (ZUP) {

@@ -51,6 +51,11 @@ int pinst_upload_dynamics(admm_handle* h, const admm_problem* p, double* Ad, dou
   HIP_TRY(hipMemcpy(Rd, R.data(), sizeof(double) * R.size(), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(QNd, QN.data(), sizeof(double) * QN.size(), hipMemcpyHostToDevice));
   int rc;
+  if (h->pi_tiled) {
+    if ((rc = upload_tiled(h, p->A, Ad, n * n))) return rc;
+    if ((rc = upload_tiled(h, p->B, Bd, n * m))) return rc;
+    return ADMM_OK;
+  }
   if ((rc = upload_transposed(h, p->A, Ad, h->N * n * n))) return rc;
   if ((rc = upload_transposed(h, p->B, Bd, h->N * n * m))) return rc;
   return ADMM_OK;
@@ -149,6 +154,12 @@ int setup_pinst(admm_handle* h, const admm_problem* p) {
   }
   h->pinst = true;
   h->pbounds = p->stage_bounds == 2;
+  h->pi_tiled = admm::pinst_rows_only(p->n, p->m);
+  // wide shapes ((8, 4), (12, 6), ...; csrc/admm_pinst_wide.hpp): every kernel in its rows-over-lanes form, whatever the batch
+  const bool wide = admm::pinst_rows_only(p->n, p->m);
+  if (wide && h->has_soc)
+    return fail(ADMM_ERR_UNSUPPORTED, "unorm (thrust-magnitude bound) with per-instance dynamics: not available for (n, m) = (" +
+                                          std::to_string(p->n) + ", " + std::to_string(p->m) + ")");
   // Segments in time (csrc/admm_pinst.hpp): one lane sweeps one segment of one QP, so an iteration takes N / S dependent
   // stage round trips instead of N.  Automatic count: enough (64-QP wave, segment) pairs for one wave per SIMD, segments
   // of at least 8 stages, at most 64 (32 from 512 QPs: the scan is S sequential steps per QP); large batches fill the chip
@@ -156,7 +167,15 @@ int setup_pinst(admm_handle* h, const admm_problem* p) {
   h->auto_segments = o.segments == 0;
   {
     int S = o.segments;
-    if (S == 0) {
+    if (S == 0 && wide) {
+      // a wave serves QPW QPs: enough (wave, segment) pairs for one wave per SIMD, segments of at least 8 stages
+      const int qpw = p->n <= 2 ? 32 : (p->n <= 4 ? 16 : (p->n <= 8 ? 8 : 4));
+      const int waves = h->pitch / qpw;
+      S = (4 * h->num_cus + waves - 1) / waves;
+      if (S > h->N / 8) S = h->N / 8;
+      if (S > (waves <= 64 ? 64 : 32)) S = waves <= 64 ? 64 : 32;
+      if (std::getenv("ADMM_PI_NO_SEGMENTS")) S = 1;
+    } else if (S == 0) {
       const int waves = h->pitch / 64;
       // (measured, N = 1000, n = 6: 64 QPs 2.26 -> 0.27 ms per iteration, 4096 QPs 3.04 -> 1.60 ms; from 8192 QPs the batch
       //  alone reaches the HBM roofline and the segments' extra operands -- Omega_k, Psi_k: +16 % bytes -- only cost)
@@ -176,6 +195,8 @@ int setup_pinst(admm_handle* h, const admm_problem* p) {
     if (h->has_soc) h->pi_rows = false;          // the thrust-magnitude forms exist for the one-lane kernels only
     if (std::getenv("ADMM_PI_LANE_PER_QP")) h->pi_rows = false;
     if (std::getenv("ADMM_PI_ROWS") && !h->has_soc) h->pi_rows = true;
+    if (wide) h->pi_rows = true;
+    h->pi_rows_factor = std::getenv("ADMM_PI_ROWS_FACTOR") != nullptr;
   }
   h->alt = h->alt_allowed = false;
   h->time_varying = 2;

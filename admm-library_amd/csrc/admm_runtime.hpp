@@ -117,6 +117,8 @@ struct admm_handle {
   double *Omd = nullptr, *Psd = nullptr, *Segd = nullptr;
   int* pgrow = nullptr;
   bool pi_rows = false;          // small batches: sweeps with a QP's rows spread over lanes (csrc/admm_pinst_rows.hpp)
+  bool pi_tiled = false;         // wide shapes: operand arrays A, B, K, S^-1, Omega, Psi in the tiled layout (csrc/admm_pinst.hpp, Operand)
+  bool pi_rows_factor = false;   // (6, 3), ADMM_PI_ROWS_FACTOR=1: factorisation / transfer matrices through the wide shapes' kernels
   // per-QP rho (every QP of a per-instance problem has its own factor, so the adaptive rule runs QP by QP on the device)
   double *rho_d = nullptr, *cscale_d = nullptr;     // [pitch]
   int *nupd_d = nullptr, *todo_d = nullptr, *nchanged_d = nullptr;
@@ -245,6 +247,7 @@ int enqueue_one(admm_handle* h, bool resid, bool use_graph, int remaining, int i
 
 // ---- host <-> device transfers, validation, uploads of the factor, handle lifetime (admm_hostio.hip)
 int upload_h2d(admm_handle* h, void* dst, const void* src, size_t bytes);
+int upload_tiled(admm_handle* h, const double* src, double* dst, int E);   // per-instance operand (batch x N x E) -> tiled layout
 int upload_transposed(admm_handle* h, const double* src, double* dst, int rows);
 int download_transposed(admm_handle* h, const double* src, double* dst, int rows);
 bool finite_all(const double* a, size_t cnt);

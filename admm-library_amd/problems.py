@@ -321,3 +321,27 @@ def cw_rendezvous_instances(N: int = 200, batch: int = 64, seed0: int = SEED0, u
         lo[i] = np.array([-um] * 3 + [-np.inf] * 6)[None]
         hi[i] = np.array([um] * 3 + [np.inf] * 6)[None]
     return dataclasses.replace(base, A=A, B=B, lo=lo, hi=hi, name=f"cw_rendezvous_instances_N{N}_b{batch}")
+
+
+def cw_formation_instances(N: int = 200, batch: int = 64, seed0: int = SEED0, u_max: float = 0.2,
+                           spread: float = 0.05) -> Problem:
+    """cw_formation (n = 12, m = 6) with PER-INSTANCE dynamics: in QP i each of the two craft flies about its own reference
+    orbit (mean motion scaled by 1 + spread * U(-1, 1)) and has its own input box -- the wide-shape twin of
+    cw_rendezvous_instances."""
+    base = cw_formation(N=N, batch=batch, seed0=seed0, u_max=u_max)
+    dt = 2.0 * np.pi / N
+    A = np.zeros((batch, N, 12, 12))
+    B = np.zeros((batch, N, 12, 6))
+    lo = np.empty((batch, N, 18))
+    hi = np.empty((batch, N, 18))
+    for i in range(batch):
+        rng = np.random.default_rng(seed0 + 100003 * (i + 1))
+        um = np.empty(6)
+        for c in range(2):
+            Ai, Bi = cw_matrices(dt * (1.0 + spread * rng.uniform(-1.0, 1.0)))
+            A[i, :, 6 * c:6 * c + 6, 6 * c:6 * c + 6] = Ai[None]
+            B[i, :, 6 * c:6 * c + 6, 3 * c:3 * c + 3] = Bi[None]
+            um[3 * c:3 * c + 3] = u_max * (1.0 + spread * rng.uniform(-1.0, 1.0))
+        lo[i] = np.concatenate([-um, [-np.inf] * 12])[None]
+        hi[i] = np.concatenate([um, [np.inf] * 12])[None]
+    return dataclasses.replace(base, A=A, B=B, lo=lo, hi=hi, name=f"cw_formation_instances_N{N}_b{batch}")

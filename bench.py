@@ -57,7 +57,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=4096, help="QPs per GPU")
     ap.add_argument("--horizon", type=int, default=1000)
-    ap.add_argument("--workload", choices=["cw_rendezvous", "cw_formation", "cw_rendezvous_soc", "cw_perinstance"], default="cw_rendezvous",
+    ap.add_argument("--workload", choices=["cw_rendezvous", "cw_formation", "cw_rendezvous_soc", "cw_perinstance", "cw_formation_perinstance"], default="cw_rendezvous",
                     help="cw_rendezvous = configs[1..3] (n=6, m=3, the metric's workload); cw_formation = configs[4]'s "
                          "shape (n=12, m=6) in fp64 -- a side measurement, never the reported metric's config")
     ap.add_argument("--precision", choices=["fp64", "fp64_one_lane", "mixed", "fp64_mfma"], default="fp64",
@@ -228,7 +228,8 @@ def launch_ranks(a):
 def bench_perinstance(a, pkg, np, world, rank, dev_index, lo_i, hi_i, gbatch, barrier, max_over_ranks):
     """SIDE MEASUREMENT: per-instance dynamics (admm_problem.time_varying = 2, stage_bounds = 2).  A different
     roofline from the metric's: every QP streams its own factor operands, ~200 B per stacked element and iteration."""
-    full = pkg.cw_rendezvous_instances(N=a.horizon, batch=hi_i - lo_i, seed0=pkg.SEED0 + lo_i)
+    make = pkg.cw_formation_instances if a.workload == "cw_formation_perinstance" else pkg.cw_rendezvous_instances
+    full = make(N=a.horizon, batch=hi_i - lo_i, seed0=pkg.SEED0 + lo_i)
     n_, m_, nb = full.n, full.m, full.nb
     with pkg.Solver(full, pkg.Options(rho=0.05, check_interval=1, device=dev_index)) as sv:
         geo = sv.geometry()
@@ -259,10 +260,11 @@ def bench_perinstance(a, pkg, np, world, rank, dev_index, lo_i, hi_i, gbatch, ba
             "value": gbatch * a.steps / dt, "unit": "QP-iterations/s", "batch_iterations_per_s": a.steps / dt,
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "repeats": a.repeats, "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"SIDE MEASUREMENT (cw_perinstance): batch of {a.batch} N={a.horizon} n={n_} m={m_} QPs per GPU, "
+            "config": {"workload": f"SIDE MEASUREMENT ({a.workload}): batch of {a.batch} N={a.horizon} n={n_} m={m_} QPs per GPU, "
                                    f"every QP with its own dynamics and box (time_varying = 2, stage_bounds = 2), residuals every iteration",
                        "N": a.horizon, "n": n_, "m": m_, "batch_per_gpu": a.batch, "global_batch": gbatch, **geo},
-            "roofline": {"kernel": "pxb_kernel + pxfz_kernel (one lane per QP sweeps the whole horizon; operands per QP from HBM)",
+            "roofline": {"kernel": ("pxb_rows_kernel + pxfz_rows_kernel (a QP's rows over the lanes of a wave; operands per QP from HBM)"
+                                    if n_ >= 8 else "pxb_kernel + pxfz_kernel (one lane per QP; operands per QP from HBM)"),
                          "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "traffic": None, "bytes_per_element": b_xb + b_xfz, "bytes_per_launch_pair": (b_xb + b_xfz) * elems,
                          "avg_launch_ms": {"pxb": prof["xb_ms"], "pxfz": prof["xfz_ms"]},
@@ -333,7 +335,7 @@ def main():
     # global problem = batch * world QPs; this rank's contiguous shard
     gbatch = a.batch * world
     lo_i, hi_i = pkg.shard_bounds(gbatch, world, rank)
-    if a.workload == "cw_perinstance":
+    if a.workload in ("cw_perinstance", "cw_formation_perinstance"):
         return bench_perinstance(a, pkg, np, world, rank, dev_index, lo_i, hi_i, gbatch, barrier, max_over_ranks)
     if a.workload == "cw_rendezvous_soc":      # side measurement: thrust-magnitude bound instead of the input box
         full = pkg.cw_rendezvous(N=a.horizon, batch=hi_i - lo_i, seed0=pkg.SEED0 + lo_i, thrust_norm=True)

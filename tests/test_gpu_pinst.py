@@ -207,3 +207,105 @@ def test_thrust_magnitude_bound_with_per_instance_dynamics(gpu, case, alpha, seg
         assert int(info.iters_run) == ref["iters_run"]
         np.testing.assert_array_equal(s.rho_per_qp(), ref["rho"])
         assert _close(s.get(), ref)
+
+
+# ---- wide shapes ((8, 4), (12, 6), ...): every kernel with a QP's rows spread over the lanes (csrc/admm_pinst_wide.hpp) ----
+WIDE_CASES = [
+    dict(N=25, n=12, m=6, batch=70, seed=41),                                 # configs[4]'s shape, more than 64 QPs: 4-wave workgroups
+    dict(N=24, n=12, m=6, batch=9, seed=42, instance_bounds=False),
+    dict(N=16, n=12, m=6, batch=3, seed=43, with_q=False),
+    dict(N=1, n=12, m=6, batch=2, seed=44),
+    dict(N=30, n=8, m=4, batch=67, seed=45),
+    dict(N=21, n=8, m=4, batch=5, seed=46, instance_bounds=False),
+    dict(N=20, n=12, m=3, batch=65, seed=47),
+    dict(N=33, n=9, m=3, batch=12, seed=48, with_q=False),
+]
+
+
+@pytest.mark.parametrize("segments", [0, 1, 5], ids=["auto_segments", "one_segment", "five_segments"])
+@pytest.mark.parametrize("alpha", [1.0, 1.5])
+@pytest.mark.parametrize("idx", range(len(WIDE_CASES)))
+def test_wide_shapes_match_the_oracle(gpu, idx, alpha, segments, monkeypatch):
+    """Device factorisation (pfactor_rows_kernel), per-QP transfer matrices (pseg_rows_kernel), scan and both sweeps at the
+    shapes one lane cannot hold: iterates against the C oracle applied QP by QP."""
+    monkeypatch.delenv("ADMM_PI_LANE_PER_QP", raising=False)
+    monkeypatch.delenv("ADMM_PI_ROWS", raising=False)
+    p = pkg.random_instances(**WIDE_CASES[idx])
+    with pkg.Solver(p, pkg.Options(rho=0.3, alpha=alpha, segments=segments)) as s:
+        want = {0: max(1, min(64, p.N // 8)), 1: 1, 5: min(5, p.N)}[segments]
+        assert s.geometry()["segments"] == want
+        done = 0
+        for upto in (1, 2, 3, 10, 40):
+            s.run(upto - done, residual_every=2)
+            done = upto
+            ref = oc.solve(p, rho=0.3, alpha=alpha, max_iter=upto, stop=False)
+            assert _close(s.get(), ref), upto
+
+
+@pytest.mark.parametrize("segments", [1, 4])
+@pytest.mark.parametrize("batch", [9, 70])
+def test_rows_factorisation_agrees_with_the_one_lane_factorisation(gpu, batch, segments, monkeypatch):
+    """The wide shapes' factor / transfer-matrix kernels instantiated at (6, 3), where the one-lane kernels exist: the same
+    recursion in the same summation order -- the iterates through either factor agree to rounding (observed <= 1e-15 absolute
+    after 25 iterations; the two compilations differ by an ulp in rare entries), far inside the tolerance against the oracle."""
+    p = pkg.random_instances(N=26, n=6, m=3, batch=batch, seed=51)
+    out = {}
+    for twin in (False, True):
+        monkeypatch.delenv("ADMM_PI_ROWS_FACTOR", raising=False)
+        if twin:
+            monkeypatch.setenv("ADMM_PI_ROWS_FACTOR", "1")
+        with pkg.Solver(p, pkg.Options(rho=0.3, segments=segments)) as s:
+            s.run(25, residual_every=5)
+            out[twin] = s.get() + (s.residuals(),)
+            s.set_rho(0.8)                       # a refactorisation (on trial first), then more iterations
+            s.run(10, residual_every=5)
+            out[twin] += s.get()
+    for a, b in zip(out[False], out[True]):
+        a, b = np.asarray(a), np.asarray(b)
+        assert np.abs(a - b).max() <= 1e-13 * max(1.0, np.abs(a).max())
+
+
+def test_wide_shape_solve_set_rho_update_problem_and_per_qp_rho(gpu):
+    p = pkg.random_instances(N=20, n=12, m=6, batch=66, seed=53)
+    kw = dict(rho=0.3, eps_abs=1e-7, eps_rel=1e-7, max_iter=3000, check_interval=10)
+    ref = oc.solve(p, **kw)
+    with pkg.Solver(p, pkg.Options(**kw)) as s:
+        assert s.path()["per_instance"]
+        info = s.solve()
+        assert int(info.iters_run) == ref["iters_run"]
+        np.testing.assert_array_equal(info.status, ref["status"])
+        assert _close(s.get(), ref)
+        s.set_rho(0.9)
+        s.iterate(7)
+        ref2 = oc.solve(p, rho=0.9, max_iter=7, stop=False, z0=ref["z"], y0=ref["y"] * (0.3 / 0.9))
+        assert _close(s.get(), ref2)
+        p2 = pkg.random_instances(N=20, n=12, m=6, batch=66, seed=54)
+        s.update_problem(p2)
+        s.set_state(z=np.zeros((66, p2.L)), y=np.zeros((66, p2.L)))
+        s.iterate(12)
+        assert _close(s.get(), oc.solve(p2, rho=0.9, max_iter=12, stop=False))
+    # the per-QP adaptive rule (masked trial refactorisation of the QPs whose rho has moved)
+    kw = dict(rho=0.3, eps_abs=1e-7, eps_rel=1e-7, max_iter=2000, check_interval=10, adapt_interval=20, adapt_mu=1.5, adapt_tau=2.0,
+              adapt_max=8)
+    ref = oc.solve(p, **kw)
+    assert ref["rho_updates"].max() >= 1
+    with pkg.Solver(p, pkg.Options(**kw)) as s:
+        info = s.solve()
+        np.testing.assert_array_equal(s.rho_per_qp(), ref["rho"])
+        assert int(info.iters_run) == ref["iters_run"]
+        np.testing.assert_array_equal(info.status, ref["status"])
+        np.testing.assert_array_equal(info.iters, ref["iters"])
+        assert _close(s.get(), ref)
+
+
+def test_wide_shape_failures_are_reported(gpu):
+    inv = {v: k for k, v in _abi.STATUS_NAMES.items()}
+    p = pkg.random_instances(N=10, n=12, m=6, batch=4, seed=55)
+    ind = dataclasses.replace(p, R=-0.5 * np.eye(6))
+    with pytest.raises(pkg.AdmmError) as e:
+        pkg.Solver(ind, pkg.Options(rho=0.01))
+    assert e.value.code == inv["ADMM_ERR_NUMERIC"]
+    soc = pkg.random_instances(N=10, n=12, m=6, batch=4, seed=55, thrust_norm=True)
+    with pytest.raises(pkg.AdmmError) as e:
+        pkg.Solver(soc, pkg.Options(rho=0.3))
+    assert e.value.code == inv["ADMM_ERR_UNSUPPORTED"]

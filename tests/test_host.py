@@ -269,7 +269,7 @@ def test_no_spills_at_headline_shapes(built):
     ge.build_library()          # incremental: recompiles only the units whose sources changed; leaves every unit's report
     files = sorted(glob.glob(os.path.join(ge.ROOT, "build", "obj", "admm_dims_g*.resource_usage.txt")))
     others = sorted(set(glob.glob(os.path.join(ge.ROOT, "build", "obj", "*.resource_usage.txt"))) - set(files))
-    assert len(files) == 4 and len(others) == 3          # admm_mfma.hip, admm_pinst.hip, admm_pinst_g1.hip are gated too
+    assert len(files) == 4 and len(others) == 4          # admm_mfma.hip, admm_pinst.hip, admm_pinst_g1.hip, admm_pinst_g2.hip are gated too
     for f in others:            # MFMA forms at (12, 6) / (6, 3) and the per-instance kernels at (6, 3): no scratch
         ge.check_no_spills(ge.parse_resource_usage(open(f).read()))
     rows = [r for f in files for r in ge.parse_resource_usage(open(f).read())]
