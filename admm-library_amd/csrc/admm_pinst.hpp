@@ -643,6 +643,42 @@ struct Operand {
   __device__ __forceinline__ size_t el(int e) const { return TILED ? (size_t)e * QPW : (size_t)e * pitch_; }
 };
 
+// ---- operand tiles staged through LDS (the sweeps of the wide shapes) ----
+// A wave keeps at most 63 vector loads in flight, and a rows-over-lanes load carries 8 * QPW bytes for each of <= n lane rows (384 B
+// at (12, 6), 192 B for the control-row operands): one stage per wave in flight, ~16 MB over the chip -- measured 0.53 of the HBM
+// roofline at 4096 x 1000 whatever the prefetch depth.  Staged: all 64 lanes copy the (contiguous) tile of stage k + 2 with 16-byte
+// loads -- 1 KB per instruction, every byte used -- into registers, the registers go to LDS one stage later, and the lane rows read
+// THEIR operands from LDS when the stage is computed.  E = elements of the operand, M = length of its minor run (the index the lanes
+// of a read differ in jumps by M elements: one element of padding per run spreads those reads over the LDS banks).
+typedef double pair_t __attribute__((ext_vector_type(2)));      // 16 bytes: one global_load_dwordx4 / ds_write_b128
+
+template <int E, int M, int QPW>
+struct StageTile {
+  static_assert(E % M == 0 && QPW % 2 == 0, "whole runs; a 16-byte pair stays inside one element row");
+  static constexpr int MP = M + 1;
+  static constexpr int LWORDS = (E / M) * MP * QPW;        // doubles of the padded LDS copy
+  static constexpr int GPAIRS = E * QPW / 2;               // 16-byte pairs of the tile in memory
+  static constexpr int NLD = (GPAIRS + 63) / 64;           // pairs per lane
+  __device__ static __forceinline__ int pair_of(int lane, int n) {      // (the last, partial round re-reads the tile's last pair)
+    const int q = lane + 64 * n;
+    return (GPAIRS % 64 == 0 || n + 1 < NLD) ? q : (q < GPAIRS ? q : GPAIRS - 1);
+  }
+  __device__ static __forceinline__ void gload(pair_t (&r)[NLD], const double* tile, int lane) {
+    const pair_t* t2 = reinterpret_cast<const pair_t*>(tile);
+#pragma unroll
+    for (int n = 0; n < NLD; ++n) r[n] = t2[pair_of(lane, n)];
+  }
+  __device__ static __forceinline__ void lstore(const pair_t (&r)[NLD], double* lds, int lane) {
+#pragma unroll
+    for (int n = 0; n < NLD; ++n) {
+      const int w = 2 * pair_of(lane, n), e = w / QPW, c = w % QPW;
+      *reinterpret_cast<pair_t*>(&lds[((e / M) * MP + e % M) * QPW + c]) = r[n];
+    }
+  }
+  // element e (= run * M + minor) of QP c
+  __device__ static __forceinline__ int at(int run, int minor, int c) { return (run * MP + minor) * QPW + c; }
+};
+
 // ---- lane geometry shared by the rows-over-lanes kernels (admm_pinst_rows.hpp, admm_pinst_wide.hpp) ----
 constexpr int PROWS_BLOCK = 256;      // up to 4 waves per workgroup: the 16 / QPW waves that share a 128-byte line of every array
 

@@ -2,6 +2,8 @@
 // instantiate them (admm_pinst.hip, admm_pinst_g1.hip: the shapes are split so that the build compiles them in parallel).
 #pragma once
 
+#include <atomic>
+
 #include "admm_dispatch.hpp"
 #include "admm_pinst.hpp"
 #include "admm_pinst_rows.hpp"
@@ -10,16 +12,33 @@
 namespace admm {
 namespace {
 
+// Launch with dynamic LDS; beyond the 64 KB a kernel may use by default the limit is raised first (once per kernel and device).
+template <auto Kernel, class... Args>
+void launch_with_lds(dim3 grid, dim3 block, size_t lds_bytes, hipStream_t stream, Args... args) {
+  if (lds_bytes > 64 * 1024) {
+    static std::atomic<unsigned> raised{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!((raised.load(std::memory_order_relaxed) >> dev) & 1u)) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(Kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      raised.fetch_or(1u << dev, std::memory_order_relaxed);
+    }
+  }
+  hipLaunchKernelGGL(Kernel, grid, block, lds_bytes, stream, args...);
+}
+
 // Grid of the rows-over-lanes kernels: a wave serves QPW QPs; from 65 QPs on a workgroup takes the 16 / QPW waves whose
 // accesses share the 128-byte lines of every array (their 8 * QPW-byte pieces would otherwise be fetched by different XCDs).
 template <int NX>
 struct RowsGrid {
   dim3 grid, block, grid1;     // grid1: without the segment dimension (factorisation)
+  int waves_per_block;
   explicit RowsGrid(const PLaunch& l) {
     constexpr int QPW = PscanShape<NX>::QPW;
     const int wpb = l.pitch > 64 ? (16 / QPW > 1 ? 16 / QPW : 1) : 1;
     const int waves = l.pitch / QPW;
     block = dim3(PI_THREADS * wpb);
+    waves_per_block = wpb;
     grid1 = dim3((waves + wpb - 1) / wpb);
     grid = dim3(grid1.x, l.S > 0 ? l.S : 1);
   }
@@ -50,10 +69,10 @@ void launch_dim_wide(const PLaunch& l, PKernel k) {
 #define XB(HQ, VF, PB_)                                                                                                          \
   do {                                                                                                                           \
     if (seg)                                                                                                                     \
-      hipLaunchKernelGGL((pxb_rows_kernel<NX, NU, HQ, VF, PB_, true, TILED>), rgrid, rblock, 0, l.stream, l.vform ? l.v : l.z, l.y, l.q, \
+      launch_with_lds<pxb_rows_kernel<NX, NU, HQ, VF, PB_, true, TILED>>(rgrid, rblock, TILED ? rg.waves_per_block * pxb_rows_lds_words<NX, NU, true>() * sizeof(double) : 0, l.stream, l.vform ? l.v : l.z, l.y, l.q, \
                          l.Ad, l.Bd, l.Kd, l.Sd, l.lo, l.hi, l.dbuf, l.rhov, l.N, l.pitch, l.Omd, l.seg_start, l.tseg, l.eseg);   \
     else                                                                                                                         \
-      hipLaunchKernelGGL((pxb_rows_kernel<NX, NU, HQ, VF, PB_, false, TILED>), rgrid, rblock, 0, l.stream, l.vform ? l.v : l.z, l.y,    \
+      launch_with_lds<pxb_rows_kernel<NX, NU, HQ, VF, PB_, false, TILED>>(rgrid, rblock, TILED ? rg.waves_per_block * pxb_rows_lds_words<NX, NU, false>() * sizeof(double) : 0, l.stream, l.vform ? l.v : l.z, l.y,    \
                          l.q, l.Ad, l.Bd, l.Kd, l.Sd, l.lo, l.hi, l.dbuf, l.rhov, l.N, l.pitch, nullptr, nullptr, nullptr,       \
                          nullptr);                                                                                               \
   } while (0)
@@ -66,11 +85,11 @@ void launch_dim_wide(const PLaunch& l, PKernel k) {
     }
     case PKernel::XF:
       if (seg)
-        hipLaunchKernelGGL((pxfz_rows_kernel<NX, NU, false, false, false, false, false, true, true, TILED>), rgrid, rblock, 0, l.stream,
+        launch_with_lds<pxfz_rows_kernel<NX, NU, false, false, false, false, false, true, true, TILED>>(rgrid, rblock, TILED ? rg.waves_per_block * pxfz_rows_lds_words<NX, NU, true>() * sizeof(double) : 0, l.stream,
                            l.dbuf, l.x0, l.Ad, l.Bd, l.Kd, l.lo, l.hi, l.z, l.y, l.v, l.w, l.part, l.alpha, l.N, l.pitch, l.Psd,
                            l.seg_start, l.tin, l.xin);
       else
-        hipLaunchKernelGGL((pxfz_rows_kernel<NX, NU, false, false, false, false, false, true, false, TILED>), rgrid, rblock, 0, l.stream,
+        launch_with_lds<pxfz_rows_kernel<NX, NU, false, false, false, false, false, true, false, TILED>>(rgrid, rblock, TILED ? rg.waves_per_block * pxfz_rows_lds_words<NX, NU, false>() * sizeof(double) : 0, l.stream,
                            l.dbuf, l.x0, l.Ad, l.Bd, l.Kd, l.lo, l.hi, l.z, l.y, l.v, l.w, l.part, l.alpha, l.N, l.pitch, nullptr,
                            nullptr, nullptr, nullptr);
       break;
@@ -78,11 +97,11 @@ void launch_dim_wide(const PLaunch& l, PKernel k) {
 #define XFZ(RS, RX, VI, PB_)                                                                                                       \
   do {                                                                                                                             \
     if (seg)                                                                                                                       \
-      hipLaunchKernelGGL((pxfz_rows_kernel<NX, NU, true, RS, RX, VI, PB_, false, true, TILED>), rgrid, rblock, 0, l.stream, l.dbuf, l.x0, \
+      launch_with_lds<pxfz_rows_kernel<NX, NU, true, RS, RX, VI, PB_, false, true, TILED>>(rgrid, rblock, TILED ? rg.waves_per_block * pxfz_rows_lds_words<NX, NU, true>() * sizeof(double) : 0, l.stream, l.dbuf, l.x0, \
                          l.Ad, l.Bd, l.Kd, l.lo, l.hi, l.z, l.y, l.v, l.w, l.part, l.alpha, l.N, l.pitch, l.Psd, l.seg_start,      \
                          l.tin, l.xin);                                                                                            \
     else                                                                                                                           \
-      hipLaunchKernelGGL((pxfz_rows_kernel<NX, NU, true, RS, RX, VI, PB_, false, false, TILED>), rgrid, rblock, 0, l.stream, l.dbuf,      \
+      launch_with_lds<pxfz_rows_kernel<NX, NU, true, RS, RX, VI, PB_, false, false, TILED>>(rgrid, rblock, TILED ? rg.waves_per_block * pxfz_rows_lds_words<NX, NU, false>() * sizeof(double) : 0, l.stream, l.dbuf,      \
                          l.x0, l.Ad, l.Bd, l.Kd, l.lo, l.hi, l.z, l.y, l.v, l.w, l.part, l.alpha, l.N, l.pitch, nullptr, nullptr,  \
                          nullptr, nullptr);                                                                                        \
   } while (0)

@@ -231,7 +231,7 @@ def bench_perinstance(a, pkg, np, world, rank, dev_index, lo_i, hi_i, gbatch, ba
     make = pkg.cw_formation_instances if a.workload == "cw_formation_perinstance" else pkg.cw_rendezvous_instances
     full = make(N=a.horizon, batch=hi_i - lo_i, seed0=pkg.SEED0 + lo_i)
     n_, m_, nb = full.n, full.m, full.nb
-    with pkg.Solver(full, pkg.Options(rho=0.05, check_interval=1, device=dev_index)) as sv:
+    with pkg.Solver(full, pkg.Options(rho=0.05, check_interval=1, segments=a.segments, device=dev_index)) as sv:
         geo = sv.geometry()
         sv.run(max(a.warmup, 3), residual_every=1)
         t_end = time.perf_counter() + a.warm_seconds
