@@ -10,7 +10,8 @@ written from the QP's definition, not from the Riccati form ei
                        multiplier of the dynamics (banded Cholesky of G G'), complementarity;
   condensed_bvls       configs[0] condensed to a bounded least-squares problem in u for scipy.optimize.lsq_linear.
 
-Batch-shared dynamics only (A: (n, n) or (N, n, n)); box constraints (no thrust-magnitude bound).
+Batch-shared dynamics (A: (n, n) or (N, n, n)); kkt_certificate_instances applies the certificate QP by QP to per-instance
+dynamics (A: (batch, N, n, n), own box per QP).  Box constraints (no thrust-magnitude bound).
 """
 import numpy as np
 import scipy.sparse as sp
@@ -145,6 +146,24 @@ def kkt_certificate_batch(p, z, y, rho):
     viol = np.where(at_lo, np.maximum(lamf, 0.0), np.where(at_hi, np.maximum(-lamf, 0.0), np.abs(lamf)))
     comp = viol.max(axis=1)
     return feas_dyn, feas_box, stat, comp, int((at_lo | at_hi).sum())
+
+
+def kkt_certificate_instances(p, z, y, rho):
+    """kkt_certificate_batch for PER-INSTANCE dynamics / bounds (admm_problem.time_varying = 2): every QP with its own A_k, B_k
+    (and box), one QP at a time.  rho: scalar or one value per QP (the per-QP adaptive rule)."""
+    import dataclasses
+    rho = np.broadcast_to(np.asarray(rho, dtype=float), (p.batch,))
+    per_box = np.ndim(p.lo) == 3
+    out = [[], [], [], []]
+    n_active = 0
+    for b in range(p.batch):
+        one = dataclasses.replace(p, A=p.A[b], B=p.B[b], x0=p.x0[b:b + 1], q=None if p.q is None else p.q[b:b + 1],
+                                  lo=p.lo[b] if per_box else p.lo, hi=p.hi[b] if per_box else p.hi)
+        r = kkt_certificate_batch(one, z[b:b + 1], y[b:b + 1], float(rho[b]))
+        for acc, v in zip(out, r[:4]):
+            acc.append(float(v[0]))
+        n_active += r[4]
+    return tuple(np.asarray(a) for a in out) + (n_active,)
 
 
 def condense(p):

@@ -64,6 +64,29 @@ def test_optimality_of_every_qp_of_a_converged_full_batch(gpu, case):
     assert n_active > 100 * p.batch // 10                                          # the thrust box binds throughout the batch
 
 
+@pytest.mark.parametrize("case", ["rendezvous_n6", "formation_n12"])
+def test_optimality_of_every_qp_with_per_instance_dynamics(gpu, case):
+    """Per-instance dynamics and boxes (time_varying = 2, stage_bounds = 2) -- n = 6 on the one-lane kernels,
+    n = 12 on the rows-over-lanes kernels of the wide shapes (device factorisation, tiled operands staged through LDS): 256 QPs of
+    N = 200 stages solved to eps = 1e-8 with the per-QP adaptive rule; every QP's (z, rho_b y) satisfies ITS OWN QP's optimality
+    conditions (its A_k, B_k, its box) to the bounds of the batch-shared test."""
+    make = pkg.cw_rendezvous_instances if case == "rendezvous_n6" else pkg.cw_formation_instances
+    p = make(N=200, batch=256)
+    opt = pkg.Options(rho=0.05, alpha=1.6, eps_abs=1e-8, eps_rel=1e-8, max_iter=20000, check_interval=10, adapt_interval=50)
+    with pkg.Solver(p, opt) as s:
+        assert s.path()["per_instance"]
+        info = s.solve()
+        _, z, y = s.get()
+        rho = s.rho_per_qp()
+    assert int(info.n_converged) == p.batch and info.status.all()
+    feas_dyn, feas_box, stat, comp, n_active = ind.kkt_certificate_instances(p, z, y, rho)
+    worst = dict(feas_dyn=feas_dyn.max(), feas_box=feas_box.max(), stat=stat.max(), comp=comp.max())
+    print(case, "iterations", info.iters_run, "rho", rho.min(), rho.max(), worst, "active", n_active)
+    assert feas_box.max() == 0.0, worst
+    assert feas_dyn.max() < 1e-6 and stat.max() < 1e-6 and comp.max() < 1e-6, worst
+    assert n_active > 10 * p.batch
+
+
 XCASES = {
     "n6": (lambda: pkg.cw_rendezvous(N=1000, batch=4096), _abi.PRECISION_FP64),
     "n12": (lambda: pkg.cw_formation(N=1000, batch=4096), _abi.PRECISION_FP64),

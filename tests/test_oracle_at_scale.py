@@ -61,3 +61,18 @@ def test_certificate_rejects_a_wrong_answer():
     z2 = res["z"].copy()
     z2.reshape(2, p.N, p.nb)[:, :, :p.m] *= 0.5
     assert ind.kkt_certificate_batch(p, z2, res["y"], res["rho"])[2].max() > 1e-4
+
+
+def test_oracle_with_per_instance_dynamics_is_optimal_qp_by_qp():
+    """Per-instance dynamics (n = 12, m = 6; every QP its own A_k, B_k and box): the C oracle's converged (z, rho y) satisfies each
+    QP's own optimality conditions -- the checker tests/test_gpu_independent.py applies to the HIP path's wide-shape kernels."""
+    p = pkg.cw_formation_instances(N=40, batch=3)
+    r = oc.solve(p, rho=0.05, alpha=1.6, eps_abs=1e-9, eps_rel=1e-9, max_iter=30000, check_interval=10)
+    assert r["status"].all()
+    feas_dyn, feas_box, stat, comp, n_active = ind.kkt_certificate_instances(p, r["z"], r["y"], 0.05)
+    assert feas_box.max() == 0.0 and feas_dyn.max() < 1e-7 and stat.max() < 1e-7 and comp.max() < 1e-7
+    assert n_active > 50
+    bad = r["z"].copy()
+    bad[1, 7] += 1e-3                                  # a perturbed state entry of QP 1 breaks ITS dynamics, nobody else's
+    fd = ind.kkt_certificate_instances(p, bad, r["y"], 0.05)[0]
+    assert fd[1] > 1e-4 and fd[0] < 1e-7 and fd[2] < 1e-7
