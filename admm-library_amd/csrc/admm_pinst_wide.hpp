@@ -19,9 +19,17 @@
 
 namespace admm {
 
-// Phases of a stage are kept apart in the schedule: unfenced, the compiler hoists the cross-lane reads of later phases over the
-// earlier ones and runs out of registers at (12, 6).
+// Scheduling fences between the phases of a stage / the steps of a phase: OFF.  They were put in while the kernel ran out of
+// registers; the causes turned out to be elsewhere (see pfactor_rows_kernel: the branch at the end of the stage, the transpositions
+// through LDS), and with those fixed the fences only serialise the cross-lane reads (a refactor of 4096 x 1000 QPs at (12, 6): 21.8 ms
+// with them, 16.7 ms without).  -DADMM_WIDE_FENCES brings them back for experiments.
+#ifdef ADMM_WIDE_FENCES
 #define ADMM_PHASE() __builtin_amdgcn_sched_barrier(0)
+#define ADMM_STEP() __builtin_amdgcn_sched_barrier(0)
+#else
+#define ADMM_PHASE()
+#define ADMM_STEP()
+#endif
 
 // This lane's column `mine` of a matrix distributed by rows: out[r] = (reg[mine] as held by row-lane r), r < ROWS -- a transposition
 // across the lanes.  The register index differs from lane to lane, so a cross-lane read cannot fetch it (it names ONE register for
@@ -110,7 +118,7 @@ __global__ __launch_bounds__(PROWS_BLOCK) void pfactor_rows_kernel(
     for (int l = 0; l < NX; ++l) {
 #pragma unroll
       for (int t = 0; t < NU; ++t) F[t] = fma(Pi[l], X(Bi[t], l), F[t]);
-      ADMM_PHASE();
+      ADMM_STEP();
     }
     load_Bi(kn);
     ADMM_PHASE();
@@ -122,7 +130,7 @@ __global__ __launch_bounds__(PROWS_BLOCK) void pfactor_rows_kernel(
     for (int r = 0; r < NX; ++r) {
 #pragma unroll
       for (int t = 0; t < NU; ++t) S[t] = fma(Btj[r], X(F[t], r), S[t]);
-      ADMM_PHASE();
+      ADMM_STEP();
     }
     {
       double St[NU];
@@ -147,7 +155,7 @@ __global__ __launch_bounds__(PROWS_BLOCK) void pfactor_rows_kernel(
         W[t] = (j == cc) ? pw : fma(-f, pw, W[t]);
         Si[t] = (j == cc) ? ps : fma(-f, ps, Si[t]);
       }
-      ADMM_PHASE();
+      ADMM_STEP();
     }
     {
       double Sit[NU];
@@ -164,7 +172,7 @@ __global__ __launch_bounds__(PROWS_BLOCK) void pfactor_rows_kernel(
     for (int r = 0; r < NX; ++r) {
 #pragma unroll
       for (int l = 0; l < NX; ++l) G[l] = fma(Pi[r], X(Ai[l], r), G[l]);
-      ADMM_PHASE();
+      ADMM_STEP();
     }
     load_Ai(kn);
     ADMM_PHASE();
@@ -180,7 +188,7 @@ __global__ __launch_bounds__(PROWS_BLOCK) void pfactor_rows_kernel(
         H[l] = fma(Btj[r], g, H[l]);
         Pn[l] = fma(Ati[r], g, Pn[l]);
       }
-      ADMM_PHASE();
+      ADMM_STEP();
     }
     load_cols(kn);
     ADMM_PHASE();
@@ -192,7 +200,7 @@ __global__ __launch_bounds__(PROWS_BLOCK) void pfactor_rows_kernel(
     for (int t = 0; t < NU; ++t) {
 #pragma unroll
       for (int l = 0; l < NX; ++l) K[l] = fma(Si[t], X(H[l], t), K[l]);
-      ADMM_PHASE();
+      ADMM_STEP();
     }
     ADMM_PHASE();
     // SK = S K  (row j);   P+ -= K'(SK): lane i needs column i of K
@@ -203,7 +211,7 @@ __global__ __launch_bounds__(PROWS_BLOCK) void pfactor_rows_kernel(
     for (int t = 0; t < NU; ++t) {
 #pragma unroll
       for (int l = 0; l < NX; ++l) SK[l] = fma(S[t], X(K[l], t), SK[l]);
-      ADMM_PHASE();
+      ADMM_STEP();
     }
     double Kt[NU];
     column_of<NU, NX, LD>(Kt, K, i, board, ln.ir);
@@ -211,7 +219,7 @@ __global__ __launch_bounds__(PROWS_BLOCK) void pfactor_rows_kernel(
     for (int t = 0; t < NU; ++t) {
 #pragma unroll
       for (int l = 0; l < NX; ++l) Pn[l] = fma(-Kt[t], X(SK[l], t), Pn[l]);
-      ADMM_PHASE();
+      ADMM_STEP();
     }
     {
       double Pt[NX];

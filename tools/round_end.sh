@@ -34,4 +34,15 @@ MFMA=1 bash tools/gpu_profile.sh "${tag}_formation_mixed" --workload cw_formatio
 for cfg in "4096 1000" "64 200"; do set -- $cfg
   timeout -k 10 300 python bench.py --workload cw_perinstance --batch $1 --horizon $2 --no-cpu-baseline 2>/dev/null | tail -n1 > "$O/profiles_out/${tag}_perinstance_${1}x${2}_bench.json" || exit 1
 done
+# per-instance dynamics at n = 12 (the wide shapes' kernels): bench lines, then kernel stats + HBM PMC passes of the full-size case
+for cfg in "4096 1000" "1024 1000" "64 200"; do set -- $cfg
+  timeout -k 10 300 python bench.py --workload cw_formation_perinstance --batch $1 --horizon $2 --no-cpu-baseline 2>/dev/null | tail -n1 > "$O/profiles_out/${tag}_perinstance_n12_${1}x${2}_bench.json" || exit 1
+done
+bash tools/gpu_profile.sh "${tag}_perinstance_n12" --workload cw_formation_perinstance --batch 4096 --horizon 1000 || exit 1
+python - "$O/profiles_out" "$tag" <<'PY'
+import glob, json, sys
+for f in sorted(glob.glob(f"{sys.argv[1]}/{sys.argv[2]}_perinstance_*bench.json")):
+    d = json.load(open(f))
+    print(f.split("/")[-1], "%.1f batch-it/s, roofline %.3f, S %d" % (d["batch_iterations_per_s"], d["roofline"]["frac"], d["config"]["segments"]), d["roofline"]["avg_launch_ms"])
+PY
 ls -la "$O/profiles_out"
