@@ -29,7 +29,7 @@ void launch_dim(const XLaunch& l, XKernel k, bool a, bool b) {
   hipLaunchKernelGGL((xb_kernel<NX, NU, HQ, VF, SC>), grid, block, 0, l.stream, zin, l.y, l.q, l.recB,   \
                      l.seg_start, l.dbuf, l.tseg, l.eseg, l.rho, l.pitch)
 // the SOC form differs only where z is rebuilt from v (VFORM)
-#define XB(HQ, VF) do { if (VF && l.has_soc) XB1(HQ, VF, true); else XB1(HQ, VF, false); } while (0)
+#define XB(HQ, VF) do { if constexpr (VF) { if (l.has_soc) XB1(HQ, VF, true); else XB1(HQ, VF, false); } else XB1(HQ, VF, false); } while (0)
       if (l.has_q) { if (a) XB(true, true); else XB(true, false); }
       else         { if (a) XB(false, true); else XB(false, false); }
 #undef XB
@@ -46,7 +46,7 @@ void launch_dim(const XLaunch& l, XKernel k, bool a, bool b) {
   hipLaunchKernelGGL((xfz_kernel<NX, NU, RS, RX, VI, SC>), grid, block, 0, l.stream, l.dbuf, l.tin, l.xin,   \
                      l.recF, l.seg_start, l.z, l.y, l.v, l.part, l.alpha, l.pitch, l.nsplit, l.split_stride)
 // the SOC form matters where z is rebuilt from v (VIN) or z+ is formed (RESID)
-#define XFZ(RS, RX, VI) do { if ((RS || VI) && l.has_soc) XFZ1(RS, RX, VI, true); else XFZ1(RS, RX, VI, false); } while (0)
+#define XFZ(RS, RX, VI) do { if constexpr (RS || VI) { if (l.has_soc) XFZ1(RS, RX, VI, true); else XFZ1(RS, RX, VI, false); } else XFZ1(RS, RX, VI, false); } while (0)
 #define XFZ2(RS, RX) do { if (a) XFZ(RS, RX, true); else XFZ(RS, RX, false); } while (0)
       if (b) { if (relax) XFZ2(true, true); else XFZ2(true, false); }
       else   { if (relax) XFZ2(false, true); else XFZ2(false, false); }

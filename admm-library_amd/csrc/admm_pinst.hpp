@@ -618,7 +618,11 @@ __global__ __launch_bounds__(PI_THREADS) void pseg_kernel(
 // doing whole mat-vecs, 2.5 us per step; one wave per row with the vector in LDS and a barrier per step, 0.7 us per step
 // whatever was taken out of it -- the scan of 32 segments cost as much as a whole sweep.)  c(s) does not depend on the x chain:
 // it is formed in the t chain, at the step whose input is t_in(s), and overwrites eseg(s).
-constexpr int PSCAN_D = 8;        // steps whose operands are prefetched as one group
+constexpr int PSCAN_D = 8;        // steps whose operands are prefetched as one group ...
+#ifndef ADMM_PSCAN_WIDE_D
+#define ADMM_PSCAN_WIDE_D 2
+#endif
+template <int NX> struct PscanDepth { static constexpr int D = NX > 8 ? ADMM_PSCAN_WIDE_D : PSCAN_D; };   // ... (wide shapes: 2 n doubles per lane and step, a group of 8 steps is more loads than a wave keeps in flight -- measured at n = 12, 64 QPs, 64 segments: 118 us with groups of 8, 102 with 4, 93 with 2)
 template <int NX> struct PscanShape { static constexpr int QPW = NX <= 2 ? 32 : (NX <= 4 ? 16 : (NX <= 8 ? 8 : 4)); };
 
 // ---- operand layout of the rows-over-lanes kernels ----
@@ -703,7 +707,7 @@ __global__ __launch_bounds__(PI_THREADS) void pscan_kernel(
     const double* __restrict__ Segd, const double* __restrict__ tseg, double* __restrict__ eseg,
     const double* __restrict__ x0, double* __restrict__ tin, double* __restrict__ xin, int S, int pitch) {
   // (eseg and tin are each read and written here, through these pointers only; no two of the arrays overlap)
-  constexpr int D = PSCAN_D, QPW = PscanShape<NX>::QPW;
+  constexpr int D = PscanDepth<NX>::D, QPW = PscanShape<NX>::QPW;
   static_assert(QPW * NX <= PI_THREADS, "rows x QPs of a wave");
   const int lane = threadIdx.x;
   const int c = lane % QPW, ir = lane / QPW;
