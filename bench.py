@@ -554,10 +554,31 @@ def main():
     else:
         oracle_c = None
 
-    def to_eps(**adapt):
+    host_boundary = {}
+
+    def to_eps(whole_job=False, **adapt):
         base = dict(rho=0.05, eps_abs=1e-6, eps_rel=1e-6, max_iter=4000, check_interval=10)
+        t0 = time.perf_counter()
         with pkg.Solver(full, pkg.Options(segments=a.segments, zrows=a.zrows, device=dev_index, **base, **adapt)) as sv:
+            sv.sync()
+            t1 = time.perf_counter()
             info = sv.solve()
+            t2 = time.perf_counter()
+            if whole_job:
+                # The C ABI hands over HOST buffers (admm_setup in, admm_get out): one whole job through it, transfers and the host
+                # factorisation included -- reported beside `value`, never as `value` (which is timed with everything resident in HBM).
+                res = sv.get()
+                t3 = time.perf_counter()
+                qp_it = float(np.sum(info.iters))          # iterations each QP needed (the batch runs until its last QP converges)
+                host_boundary.update({
+                    "what": "admm_setup (host arrays in: host factorisation + H2D) + admm_solve to eps = 1e-6 + admm_get (w, z, y to "
+                            "host: %.0f MB D2H), wall clock from the Python wrapper" % (3 * res[0].nbytes / 1e6),
+                    "setup_ms": (t1 - t0) * 1e3, "solve_ms": (t2 - t1) * 1e3, "get_ms": (t3 - t2) * 1e3,
+                    "batch_iterations_run": int(info.iters_run),
+                    "QP_iterations_per_s_resident": full.batch * int(info.iters_run) / (t2 - t1),
+                    "QP_iterations_per_s_host_buffers_included": full.batch * int(info.iters_run) / (t3 - t0),
+                    "per_qp_iterations_total": qp_it, "options": {**base, **adapt}})
+                del res
             if adapt.get("precision_mode", 0) != 0:
                 z_mode = sv.get(False, True, False)[1]
         out = {**base, **adapt, "batch_iterations_run": int(info.iters_run), "converged": int(info.n_converged),
@@ -588,7 +609,7 @@ def main():
 
     iters_to_eps = to_eps()
     iters_to_eps_adaptive = to_eps(adapt_interval=50, adapt_mu=10.0, adapt_tau=2.0)
-    iters_to_eps_relaxed = to_eps(adapt_interval=50, adapt_mu=10.0, adapt_tau=2.0, alpha=1.6)   # + over-relaxation
+    iters_to_eps_relaxed = to_eps(whole_job=True, adapt_interval=50, adapt_mu=10.0, adapt_tau=2.0, alpha=1.6)   # + over-relaxation
     iters_to_eps_modes = None
     if precision_modes is not None:         # the reduced-precision mode is judged on iterations-to-eps vs the fp64 path
         iters_to_eps_modes = {name: to_eps(adapt_interval=50, adapt_mu=10.0, adapt_tau=2.0, alpha=1.6, precision_mode=pm)
@@ -646,6 +667,7 @@ def main():
             "iters_to_eps": iters_to_eps,
             "iters_to_eps_adaptive_rho": iters_to_eps_adaptive,
             "iters_to_eps_adaptive_rho_alpha_1p6": iters_to_eps_relaxed,
+            "host_boundary": host_boundary,
             "check_interval_10": {"batch_iterations_per_s": a.steps / dt10,
                                   "QP_iterations_per_s": gbatch * a.steps / dt10,
                                   "state_rows_unbounded_v_not_read": xfree,
