@@ -72,6 +72,7 @@ struct PLaunch {
 };
 enum class PKernel { FACTOR, XB, XF, XFZ, SEGMENTS, SCAN };
 bool launch_pinst(const PLaunch& l, PKernel k, bool query_only);
+size_t pinst_wide_lds_bytes(int n, int m);   // LDS per workgroup of the wide shapes' sweeps (0: not a wide shape)
 bool pinst_rows_only(int n, int m);   // a wide shape: rows-over-lanes kernels whatever the batch, no thrust-magnitude forms
 void launch_padapt(hipStream_t stream, const double* resid, const int* status, double* rhov, int* nupd, int* todo,
                    double* cscale, int* nchanged, double mu2, double tau, int adapt_max, int pitch, int batch, double* rho_prev);

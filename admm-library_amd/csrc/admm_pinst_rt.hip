@@ -157,6 +157,17 @@ int setup_pinst(admm_handle* h, const admm_problem* p) {
   h->pi_tiled = admm::pinst_rows_only(p->n, p->m);
   // wide shapes ((8, 4), (12, 6), ...; csrc/admm_pinst_wide.hpp): every kernel in its rows-over-lanes form, whatever the batch
   const bool wide = admm::pinst_rows_only(p->n, p->m);
+  if (wide) {        // the staged sweeps hold two stages of operand tiles per wave in LDS: more than the 64 KB default limit
+    hipDeviceProp_t prop;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    const size_t need = admm::pinst_wide_lds_bytes(p->n, p->m);
+    if (need > (size_t)prop.maxSharedMemoryPerMultiProcessor)
+      return fail(ADMM_ERR_UNSUPPORTED, "per-instance dynamics at (n, m) = (" + std::to_string(p->n) + ", " + std::to_string(p->m) + ") need " +
+                                            std::to_string(need) + " bytes of LDS per workgroup; this device offers " +
+                                            std::to_string((size_t)prop.maxSharedMemoryPerMultiProcessor));
+  }
   if (wide && h->has_soc)
     return fail(ADMM_ERR_UNSUPPORTED, "unorm (thrust-magnitude bound) with per-instance dynamics: not available for (n, m) = (" +
                                           std::to_string(p->n) + ", " + std::to_string(p->m) + ")");
