@@ -247,6 +247,7 @@ int enqueue_one(admm_handle* h, bool resid, bool use_graph, int remaining, int i
 
 // ---- host <-> device transfers, validation, uploads of the factor, handle lifetime (admm_hostio.hip)
 int upload_h2d(admm_handle* h, void* dst, const void* src, size_t bytes);
+int download_d2h(admm_handle* h, void* dst, const void* src, size_t bytes);   // ... and back; returns with the copy complete
 int upload_tiled(admm_handle* h, const double* src, double* dst, int E);   // per-instance operand (batch x N x E) -> tiled layout
 int upload_transposed(admm_handle* h, const double* src, double* dst, int rows);
 int download_transposed(admm_handle* h, const double* src, double* dst, int rows);
