@@ -12,7 +12,7 @@ import numpy as np
 
 from .problems import Problem
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 ADMM_OK = 0
 STATUS_NAMES = {0: "ADMM_OK", 1: "ADMM_ERR_INVALID", 2: "ADMM_ERR_UNSUPPORTED",
@@ -27,6 +27,7 @@ FLAG_NO_ALTERNATE = 8
 FLAG_GRAPH = 16
 FLAG_NO_MFMA = 32
 FLAG_HISTORY = 64
+FLAG_ROW_MAJOR = 128      # per-instance dynamics: A, B blocks row-major (NumPy order), transposed on the device (ABI v8)
 
 PRECISION_FP64 = 0
 PRECISION_MIXED = 1
@@ -102,11 +103,14 @@ def _colmajor(mat: np.ndarray) -> np.ndarray:
     return np.ascontiguousarray(np.swapaxes(a, -1, -2))
 
 
-def marshal_problem(p: Problem):
-    """Build a CProblem over freshly laid-out arrays.  Returns (cproblem, keepalive)."""
+def marshal_problem(p: Problem, row_major: bool = False):
+    """Build a CProblem over freshly laid-out arrays.  Returns (cproblem, keepalive).  row_major (a handle set up with
+    FLAG_ROW_MAJOR; per-instance dynamics): A and B are handed over as they are -- NumPy's own order -- instead of being
+    transposed block by block on the host (7 GB, ~2 s, at n = 12, 4096 x 1000)."""
     p.validate()
+    mat = (lambda m: np.ascontiguousarray(m, np.float64)) if (row_major and p.per_instance) else _colmajor
     keep = {
-        "A": _colmajor(p.A), "B": _colmajor(p.B), "Q": _colmajor(p.Q), "R": _colmajor(p.R),
+        "A": mat(p.A), "B": mat(p.B), "Q": _colmajor(p.Q), "R": _colmajor(p.R),
         "QN": _colmajor(p.QN),
         "x0": np.ascontiguousarray(p.x0, np.float64),
         "lo": np.ascontiguousarray(p.lo, np.float64),

@@ -177,6 +177,10 @@ static int setup_common(admm_handle** out, const admm_problem* p, const admm_opt
   h->pitch = ((p->batch + 63) / 64) * 64;
   h->has_q = p->q != nullptr;
   h->has_soc = problem_has_soc(p);
+  if ((h->opt.flags & ADMM_FLAG_ROW_MAJOR) && p->time_varying != 2) {
+    release(h);
+    return fail(ADMM_ERR_UNSUPPORTED, "ADMM_FLAG_ROW_MAJOR: per-instance dynamics only (time_varying = 2)");
+  }
   if (p->time_varying == 2) {                    // per-instance dynamics: its own set-up (device factorisation)
     rc = setup_pinst(h, p);
     if (rc) { std::string keep = g_err; release(h); g_err = keep; return rc; }

@@ -83,7 +83,8 @@ void launch_pv_to_zy(hipStream_t stream, const double* v, double* z, double* y, 
 void launch_pv_to_zy_soc(hipStream_t stream, const double* v, double* z, double* y, const double* lo, const double* hi,
                          const double* ub, int N, int nb, int m, int pitch);
 // QP-major staged operand (batch x N x E) -> the wide shapes' tiled layout (admm_pinst.hpp, Operand / to_tiled_kernel)
-void launch_to_tiled(hipStream_t stream, const double* src, double* dst, int batch, int N, int E, int n, int pitch);
+// (nr x nc > 0: the source blocks are row-major, ADMM_FLAG_ROW_MAJOR)
+void launch_to_tiled(hipStream_t stream, const double* src, double* dst, int batch, int N, int E, int n, int pitch, int nr, int nc);
 const char* dims_pinst();
 // " (n,m) (n,m) ..." of a group, for error messages
 const char* dims_group0();

@@ -66,7 +66,7 @@ int download_d2h(admm_handle* h, void* dst, const void* src, size_t bytes) {
 }
 
 // QP-major host array (batch x rows) -> batch-minor device array (rows x pitch)
-int upload_transposed(admm_handle* h, const double* src, double* dst, int rows) {
+int upload_transposed(admm_handle* h, const double* src, double* dst, int rows, int nr, int nc) {
   if (rows == h->L && windowed(h)) {
     // a state-sized array of a handle that holds a stage window only: rows [r0, r0 + Lw) of every QP's vector (a strided 2-D
     // copy out of the caller's L x batch array), transposed into the window (dst is the biased pointer)
@@ -74,7 +74,7 @@ int upload_transposed(admm_handle* h, const double* src, double* dst, int rows) 
     HIP_TRY(hipMemcpy2DAsync(h->stage, Lw * sizeof(double), src + r0, (size_t)h->L * sizeof(double), Lw * sizeof(double), h->batch,
                              hipMemcpyHostToDevice, h->stream));
     dim3 gridw(((int)Lw + admm::T_TILE - 1) / admm::T_TILE, (h->pitch + admm::T_TILE - 1) / admm::T_TILE), blockw(admm::T_TILE * 8);
-    hipLaunchKernelGGL(admm::to_batch_minor_kernel, gridw, blockw, 0, h->stream, h->stage, dst + win_bias(h), h->batch, (int)Lw, h->pitch);
+    hipLaunchKernelGGL(admm::to_batch_minor_kernel, gridw, blockw, 0, h->stream, h->stage, dst + win_bias(h), h->batch, (int)Lw, h->pitch, 0, 0);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(h->stream));
     return ADMM_OK;
@@ -83,19 +83,19 @@ int upload_transposed(admm_handle* h, const double* src, double* dst, int rows) 
   int rc_up;
   if ((rc_up = upload_h2d(h, h->stage, src, sizeof(double) * (size_t)rows * h->batch))) return rc_up;
   dim3 grid((rows + admm::T_TILE - 1) / admm::T_TILE, (h->pitch + admm::T_TILE - 1) / admm::T_TILE), block(admm::T_TILE * 8);
-  hipLaunchKernelGGL(admm::to_batch_minor_kernel, grid, block, 0, h->stream, h->stage, dst, h->batch, rows, h->pitch);
+  hipLaunchKernelGGL(admm::to_batch_minor_kernel, grid, block, 0, h->stream, h->stage, dst, h->batch, rows, h->pitch, nr, nc);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(h->stream));
   return ADMM_OK;
 }
 
 // QP-major host operand (batch x N x E) -> the wide shapes' tiled device layout
-int upload_tiled(admm_handle* h, const double* src, double* dst, int E) {
+int upload_tiled(admm_handle* h, const double* src, double* dst, int E, int nr, int nc) {
   const size_t rows = (size_t)h->N * E;
   if (rows > h->stage_rows) return fail(ADMM_ERR_INVALID, "internal: staging buffer too small");
   int rc_up;
   if ((rc_up = upload_h2d(h, h->stage, src, sizeof(double) * rows * h->batch))) return rc_up;
-  admm::launch_to_tiled(h->stream, h->stage, dst, h->batch, h->N, E, h->n, h->pitch);
+  admm::launch_to_tiled(h->stream, h->stage, dst, h->batch, h->N, E, h->n, h->pitch, nr, nc);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(h->stream));
   return ADMM_OK;

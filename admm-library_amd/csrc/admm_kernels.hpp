@@ -1562,8 +1562,10 @@ static __global__ __launch_bounds__(FIN_COLS * FIN_GROUPS) void resid_finalize_k
 // e < L) and the device's batch-minor  dst[e][col]  (col < pitch).  32x32 tiles
 // through padded LDS so both sides are coalesced.  Setup / read-out only.
 // ---------------------------------------------------------------------------
+// nr > 0: the source rows are stacks of ROW-major nr x nc blocks (ADMM_FLAG_ROW_MAJOR): source row e = k * nr * nc + i * nc + j goes
+// to destination row k * nr * nc + j * nr + i, the block's column-major place.
 static __global__ __launch_bounds__(T_TILE * 8) void to_batch_minor_kernel(
-    const double* __restrict__ src, double* __restrict__ dst, int batch, int L, int pitch) {
+    const double* __restrict__ src, double* __restrict__ dst, int batch, int L, int pitch, int nr = 0, int nc = 0) {
   __shared__ double tile[T_TILE][T_TILE + 1];
   const int e0 = blockIdx.x * T_TILE, b0 = blockIdx.y * T_TILE;
   const int tx = threadIdx.x & (T_TILE - 1), ty = threadIdx.x / T_TILE;
@@ -1573,8 +1575,15 @@ static __global__ __launch_bounds__(T_TILE * 8) void to_batch_minor_kernel(
   }
   __syncthreads();
   for (int j = ty; j < T_TILE; j += 8) {
-    const int e = e0 + j, b = b0 + tx;
-    if (e < L && b < pitch) dst[(size_t)e * pitch + b] = tile[tx][j];
+    int e = e0 + j;
+    const int b = b0 + tx;
+    if (e < L && b < pitch) {
+      if (nr > 0) {
+        const int E = nr * nc, kk = e / E, ee = e % E;
+        e = kk * E + (ee % nc) * nr + ee / nc;
+      }
+      dst[(size_t)e * pitch + b] = tile[tx][j];
+    }
   }
 }
 

@@ -59,10 +59,10 @@ void launch_pv_to_zy_soc(hipStream_t stream, const double* v, double* z, double*
   hipLaunchKernelGGL(pv_to_zy_soc_kernel, dim3((pitch + 255) / 256, 64), dim3(256), 0, stream, v, z, y, lo, hi, ub, N, nb, m, pitch);
 }
 
-void launch_to_tiled(hipStream_t stream, const double* src, double* dst, int batch, int N, int E, int n, int pitch) {
+void launch_to_tiled(hipStream_t stream, const double* src, double* dst, int batch, int N, int E, int n, int pitch, int nr, int nc) {
   const int qpw = n <= 2 ? 32 : (n <= 4 ? 16 : (n <= 8 ? 8 : 4));                 // PscanShape<n>::QPW
   const size_t tiles = (size_t)N * (pitch / qpw);
-  hipLaunchKernelGGL(to_tiled_kernel, dim3((unsigned)std::min<size_t>(tiles, 1u << 20)), dim3(256), 0, stream, src, dst, batch, N, E, qpw, pitch);
+  hipLaunchKernelGGL(to_tiled_kernel, dim3((unsigned)std::min<size_t>(tiles, 1u << 20)), dim3(256), 0, stream, src, dst, batch, N, E, qpw, pitch, nr, nc);
 }
 
 void launch_pv_to_zy(hipStream_t stream, const double* v, double* z, double* y, const double* lo, const double* hi, size_t count) {

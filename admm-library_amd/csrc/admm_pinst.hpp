@@ -810,15 +810,18 @@ __global__ __launch_bounds__(PI_THREADS) void pscan_kernel(
 // QP-major staged array src[b][rows] (rows = N * E) -> TILED operand array dst[k][g][e][c] (Operand<., true>); columns beyond the
 // batch are zero.  Thread t of block (k, g-chunk) moves element (e, c) = (t / QPW, t % QPW): contiguous stores, QPW interleaved
 // contiguous loads.
+// nr > 0: the source blocks are ROW-major nr x nc (ADMM_FLAG_ROW_MAJOR): element e = j * nr + i of the (column-major) tile is read from
+// i * nc + j.
 static __global__ __launch_bounds__(256) void to_tiled_kernel(const double* __restrict__ src, double* __restrict__ dst, int batch,
-                                                               int N, int E, int qpw, int pitch) {
+                                                               int N, int E, int qpw, int pitch, int nr, int nc) {
   const int G = pitch / qpw;
   const size_t tile = (size_t)E * qpw;
   for (size_t kg = blockIdx.x; kg < (size_t)N * G; kg += gridDim.x) {
     const int k = (int)(kg / G), g = (int)(kg % G);
     for (int t = threadIdx.x; t < (int)tile; t += 256) {
       const int e = t / qpw, c = t % qpw, b = g * qpw + c;
-      dst[kg * tile + t] = b < batch ? src[((size_t)b * N + k) * E + e] : 0.0;
+      const int es = nr > 0 ? (e % nr) * nc + e / nr : e;
+      dst[kg * tile + t] = b < batch ? src[((size_t)b * N + k) * E + es] : 0.0;
     }
   }
 }

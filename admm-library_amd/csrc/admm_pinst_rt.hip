@@ -51,13 +51,14 @@ int pinst_upload_dynamics(admm_handle* h, const admm_problem* p, double* Ad, dou
   HIP_TRY(hipMemcpy(Rd, R.data(), sizeof(double) * R.size(), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(QNd, QN.data(), sizeof(double) * QN.size(), hipMemcpyHostToDevice));
   int rc;
+  const bool rowmaj = (h->opt.flags & ADMM_FLAG_ROW_MAJOR) != 0;        // the caller's blocks are row-major: transposed on the device
   if (h->pi_tiled) {
-    if ((rc = upload_tiled(h, p->A, Ad, n * n))) return rc;
-    if ((rc = upload_tiled(h, p->B, Bd, n * m))) return rc;
+    if ((rc = upload_tiled(h, p->A, Ad, n * n, rowmaj ? n : 0, n))) return rc;
+    if ((rc = upload_tiled(h, p->B, Bd, n * m, rowmaj ? n : 0, m))) return rc;
     return ADMM_OK;
   }
-  if ((rc = upload_transposed(h, p->A, Ad, h->N * n * n))) return rc;
-  if ((rc = upload_transposed(h, p->B, Bd, h->N * n * m))) return rc;
+  if ((rc = upload_transposed(h, p->A, Ad, h->N * n * n, rowmaj ? n : 0, n))) return rc;
+  if ((rc = upload_transposed(h, p->B, Bd, h->N * n * m, rowmaj ? n : 0, m))) return rc;
   return ADMM_OK;
 }
 

@@ -248,8 +248,8 @@ int enqueue_one(admm_handle* h, bool resid, bool use_graph, int remaining, int i
 // ---- host <-> device transfers, validation, uploads of the factor, handle lifetime (admm_hostio.hip)
 int upload_h2d(admm_handle* h, void* dst, const void* src, size_t bytes);
 int download_d2h(admm_handle* h, void* dst, const void* src, size_t bytes);   // ... and back; returns with the copy complete
-int upload_tiled(admm_handle* h, const double* src, double* dst, int E);   // per-instance operand (batch x N x E) -> tiled layout
-int upload_transposed(admm_handle* h, const double* src, double* dst, int rows);
+int upload_tiled(admm_handle* h, const double* src, double* dst, int E, int nr = 0, int nc = 0);   // per-instance operand (batch x N x E) -> tiled layout; nr x nc: row-major source blocks
+int upload_transposed(admm_handle* h, const double* src, double* dst, int rows, int nr = 0, int nc = 0);   // nr x nc: the rows are stacks of row-major blocks
 int download_transposed(admm_handle* h, const double* src, double* dst, int rows);
 bool finite_all(const double* a, size_t cnt);
 int validate_options(const admm_options* o);

@@ -130,7 +130,9 @@ class Problem:
             if np.any(np.isfinite(lo_u[:, fin])) or np.any(np.isfinite(hi_u[:, fin])):
                 raise ValueError("control rows must be unbounded (-inf, inf) where unorm is finite")
         for a in (self.A, self.B, self.Q, self.R, self.QN, self.x0):
-            if not np.all(np.isfinite(a)):
+            # (stacks of hundreds of MB -- per-instance dynamics -- are left to the library's own threaded check at admm_setup /
+            #  admm_update_problem, which Solver reports as the same ValueError: NumPy's pass over 7 GB costs 0.4 s per call)
+            if a.nbytes <= (256 << 20) and not np.all(np.isfinite(a)):
                 raise ValueError("non-finite problem data")
 
 

@@ -112,7 +112,10 @@ def load_library(path: Optional[str] = None):
 
 def _check(lib, rc: int):
     if rc != 0:
-        raise AdmmError(rc, lib.admm_last_error().decode())
+        msg = lib.admm_last_error().decode()
+        if "non-finite entry in A, B" in msg or "non-finite entry in x0" in msg:    # what Problem.validate raises for small arrays (it leaves the large ones to the library)
+            raise ValueError("non-finite problem data: " + msg)
+        raise AdmmError(rc, msg)
 
 
 def last_warning() -> str:
@@ -173,8 +176,13 @@ class Solver:
         self._h = C.c_void_p()
         self.problem = problem
         self.options = options or Options()
-        cp, keep = _abi.marshal_problem(problem)
         co = self.options.to_c()
+        # per-instance dynamics: NumPy's row-major blocks go to the library as they are (ADMM_FLAG_ROW_MAJOR, transposed on the
+        # device); ADMM_PY_COLMAJOR=1 keeps the host transposition (the column-major path of the ABI)
+        self._row_major = bool(problem.per_instance and not os.environ.get("ADMM_PY_COLMAJOR"))
+        if self._row_major:
+            co.flags |= _abi.FLAG_ROW_MAJOR
+        cp, keep = _abi.marshal_problem(problem, self._row_major)
         if timeshard is None:
             _check(self._lib, self._lib.admm_setup(C.byref(self._h), C.byref(cp), C.byref(co)))
         else:
@@ -229,8 +237,7 @@ class Solver:
 
     def update_problem(self, problem: Problem):
         """New shared data (dynamics, weights, box, x0, q) on this handle; same N, n, m, batch."""
-        problem.validate()
-        cp, keep = _abi.marshal_problem(problem)
+        cp, keep = _abi.marshal_problem(problem, self._row_major)        # (validates)
         import time
         t0 = time.perf_counter()
         _check(self._lib, self._lib.admm_update_problem(self._h, C.byref(cp)))

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ADMM_HIP_ABI_VERSION 7
+#define ADMM_HIP_ABI_VERSION 8
 
 typedef enum admm_status {
   ADMM_OK = 0,
@@ -146,6 +146,12 @@ typedef struct admm_options {
 
 #define ADMM_FLAG_HISTORY 64     /* admm_solve records, at every stopping test, (iteration, converged QPs, max primal residual, max dual
                                    residual, rho in force) for admm_get_history; costs one read-back of the per-QP residuals per test */
+#define ADMM_FLAG_ROW_MAJOR 128   /* per-instance dynamics only (time_varying = 2; ABI v8): every n x n block of A and n x m block of B is
+                                   ROW-major (C / NumPy order) instead of column-major.  The caller's arrays are then uploaded as they
+                                   are and the blocks are transposed on the device on the way into the library's layout -- a NumPy or C
+                                   caller otherwise transposes 7 GB on the host per admm_update_problem at n = 12, 4096 x 1000.  Fixed at
+                                   admm_setup: admm_update_problem of the handle reads A, B the same way.  Q, R, QN are symmetric;
+                                   ADMM_ERR_UNSUPPORTED with batch-shared dynamics (their small A, B are cheap to transpose). */
 #define ADMM_FLAG_NO_ALTERNATE 8 /* always eliminate backward / substitute forward (xb + xfz kernels); by
                                   default (unless the forward form fails its host check for the problem),
                                   consecutive iterations alternate the elimination direction so that each

@@ -309,3 +309,33 @@ def test_wide_shape_failures_are_reported(gpu):
     with pytest.raises(pkg.AdmmError) as e:
         pkg.Solver(soc, pkg.Options(rho=0.3))
     assert e.value.code == inv["ADMM_ERR_UNSUPPORTED"]
+
+
+@pytest.mark.parametrize("shape", [(6, 3), (12, 6), (8, 4)], ids=["n6_batch_minor", "n12_tiled", "n8_tiled"])
+def test_row_major_blocks_are_the_column_major_blocks(gpu, shape, monkeypatch):
+    """ADMM_FLAG_ROW_MAJOR (ABI v8; what the Python wrapper uses for per-instance dynamics): A, B handed over in NumPy's own order and
+    transposed on the device on the way into the library's layout -- bit for bit the handle that received host-transposed, column-major
+    blocks (ADMM_PY_COLMAJOR=1), at set-up and through admm_update_problem."""
+    n, m = shape
+    p = pkg.random_instances(N=17, n=n, m=m, batch=70, seed=71)
+    p2 = pkg.random_instances(N=17, n=n, m=m, batch=70, seed=72)
+    out = {}
+    for colmajor in (False, True):
+        monkeypatch.delenv("ADMM_PY_COLMAJOR", raising=False)
+        if colmajor:
+            monkeypatch.setenv("ADMM_PY_COLMAJOR", "1")
+        with pkg.Solver(p, pkg.Options(rho=0.3)) as s:
+            assert s._row_major == (not colmajor)
+            s.run(6, residual_every=2)
+            a = s.get()
+            s.update_problem(p2)
+            s.run(5, residual_every=1)
+            out[colmajor] = a + s.get()
+    for x, y in zip(out[False], out[True]):
+        np.testing.assert_array_equal(x, y)
+    assert _close(out[False][:3], oc.solve(p, rho=0.3, max_iter=6, stop=False))
+    # the flag is for per-instance dynamics only
+    shared = pkg.random_ltv(N=10, n=6, m=3, batch=4, seed=1)
+    with pytest.raises(pkg.AdmmError) as e:
+        pkg.Solver(shared, pkg.Options(rho=0.3, flags=_abi.FLAG_ROW_MAJOR))
+    assert e.value.code == {v: k for k, v in _abi.STATUS_NAMES.items()}["ADMM_ERR_UNSUPPORTED"]
