@@ -191,7 +191,9 @@ int setup_pinst(admm_handle* h, const admm_problem* p) {
       const int waves = h->pitch / 64;
       // (measured, N = 1000, n = 6: 64 QPs 2.26 -> 0.27 ms per iteration, 4096 QPs 3.04 -> 1.60 ms; from 8192 QPs the batch
       //  alone reaches the HBM roofline and the segments' extra operands -- Omega_k, Psi_k: +16 % bytes -- only cost)
-      S = waves <= 64 ? (4 * h->num_cus) / std::max(1, waves) : 1;
+      // (round 3, 4096 QPs = 64 waves: the sweeps are flat from 4 segments on and the per-QP scan costs 3 + 1.8 S us -- N = 200:
+      //  3090 batch-iterations/s with 16 segments, 3376 with 8; N = 1000: 674 / 682.  1024 QPs still want their 32.)
+      S = waves <= 64 ? ((waves >= 16 ? 2 : 4) * h->num_cus) / std::max(1, waves) : 1;
       if (S > h->N / 8) S = h->N / 8;
       if (S > (waves <= 4 ? 64 : 32)) S = waves <= 4 ? 64 : 32;     // (from 512 QPs the sweeps stop gaining, the scan keeps growing)
       if (std::getenv("ADMM_PI_NO_SEGMENTS")) S = 1;
