@@ -10,6 +10,8 @@
 //   Ad [k][n*n] A_k and Bd [k][n*m] B_k, COLUMN-major per stage (the ABI's own order: the upload is one transposition
 //   of the caller's array)      Kd [k][m*n] row-major      Sd [k][m*m] = (R + rho I + B'PB)^-1
 //   lod / hid [k][m+n]  (stage_bounds = 2; otherwise the shared expanded arrays lo / hi [L])
+// (Wide shapes -- (8, 4), (12, 6), ...: one lane cannot hold a QP; admm_pinst_rows.hpp / admm_pinst_wide.hpp run every kernel with a QP's rows
+//  spread over the lanes of a wave, and keep these operand arrays TILED: see Operand / StageTile below.)
 // Iteration = the plain path: pxb_kernel  backward sweep (d rows -> dbuf)      pxfz_kernel  forward rollout + z-update + dual
 // + residuals; one lane sweeps one SEGMENT of one QP's horizon (pseg_kernel / pscan_kernel below: per-QP transfer matrices,
 // computed on the device), the whole horizon when the batch alone fills the chip.
