@@ -360,12 +360,14 @@ int upload_bounds(admm_handle* h, const admm_problem* p) {
     lo[e] = p->lo[(p->stage_bounds ? blk * h->nb : 0) + row];
     hi[e] = p->hi[(p->stage_bounds ? blk * h->nb : 0) + row];
   }
-  HIP_TRY(hipMemcpy(h->lo, lo.data(), sizeof(double) * L, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(h->hi, hi.data(), sizeof(double) * L, hipMemcpyHostToDevice));
+  // (on the handle's stream -- it is non-blocking, a null-stream copy would not be ordered with what is queued on it)
+  HIP_TRY(hipMemcpyAsync(h->lo, lo.data(), sizeof(double) * L, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(h->hi, hi.data(), sizeof(double) * L, hipMemcpyHostToDevice, h->stream));
   std::vector<double> ub(h->N, INFINITY);
   if (p->unorm)
     for (int k = 0; k < h->N; ++k) ub[k] = p->unorm[p->stage_bounds ? k : 0];
-  HIP_TRY(hipMemcpy(h->ub, ub.data(), sizeof(double) * h->N, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpyAsync(h->ub, ub.data(), sizeof(double) * h->N, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
   return ADMM_OK;
 }
 

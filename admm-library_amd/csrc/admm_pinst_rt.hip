@@ -47,9 +47,11 @@ int pinst_upload_dynamics(admm_handle* h, const admm_problem* p, double* Ad, dou
     for (int j = 0; j < n; ++j) { Q[(size_t)i * n + j] = 0.5 * (p->Q[(size_t)j * n + i] + p->Q[(size_t)i * n + j]); QN[(size_t)i * n + j] = 0.5 * (p->QN[(size_t)j * n + i] + p->QN[(size_t)i * n + j]); }
   for (int i = 0; i < m; ++i)
     for (int j = 0; j < m; ++j) R[(size_t)i * m + j] = 0.5 * (p->R[(size_t)j * m + i] + p->R[(size_t)i * m + j]);
-  HIP_TRY(hipMemcpy(Qd, Q.data(), sizeof(double) * Q.size(), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(Rd, R.data(), sizeof(double) * R.size(), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(QNd, QN.data(), sizeof(double) * QN.size(), hipMemcpyHostToDevice));
+  // (on the handle's stream, like everything else that touches its arrays; the vectors live until the synchronisation below)
+  HIP_TRY(hipMemcpyAsync(Qd, Q.data(), sizeof(double) * Q.size(), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(Rd, R.data(), sizeof(double) * R.size(), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(QNd, QN.data(), sizeof(double) * QN.size(), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
   int rc;
   const bool rowmaj = (h->opt.flags & ADMM_FLAG_ROW_MAJOR) != 0;        // the caller's blocks are row-major: transposed on the device
   if (h->pi_tiled) {
@@ -71,7 +73,8 @@ int pinst_upload_bounds(admm_handle* h, const admm_problem* p) {
     std::vector<double> ub(h->N, INFINITY);         // thrust-magnitude bound per stage (shared by the batch)
     if (p->unorm)
       for (int k = 0; k < h->N; ++k) ub[k] = p->unorm[k];
-    HIP_TRY(hipMemcpy(h->ub, ub.data(), sizeof(double) * h->N, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpyAsync(h->ub, ub.data(), sizeof(double) * h->N, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
   } else if ((rc = upload_bounds(h, p))) {
     return rc;
   }
@@ -265,6 +268,11 @@ int setup_pinst(admm_handle* h, const admm_problem* p) {
   h->stage_rows = std::max(L, (size_t)N * n * n);
   if ((rc = dalloc(&h->stage, h->stage_rows * (size_t)h->batch))) return rc;
 #undef PD
+  // The zero-fills above are asynchronous on the handle's NON-BLOCKING stream, and the small uploads below (weights, shared box, thrust
+  // bounds) are synchronous copies on the null stream, which does not wait for it: with GBs of fills queued (a wide shape's operand
+  // arrays) a copy could land first and be zeroed afterwards -- Q = R = 0, a factor of nonsense, every QP wrong from the first iteration
+  // (found by the full-horizon optimality certificate of round 3; the second large handle of a process, whose allocations are fast).
+  HIP_TRY(hipStreamSynchronize(h->stream));
   HIP_TRY(hipHostMalloc((void**)&h->h_nconv, sizeof(int), hipHostMallocDefault));
   if ((rc = pinst_upload(h, p))) return rc;
   if ((rc = upload_transposed(h, p->x0, h->x0, n))) return rc;

@@ -87,6 +87,33 @@ def test_optimality_of_every_qp_with_per_instance_dynamics(gpu, case):
     assert n_active > 10 * p.batch
 
 
+@pytest.mark.parametrize("case", ["rendezvous_n6_4096x1000", "formation_n12_1024x1000"])
+def test_optimality_with_per_instance_dynamics_at_full_horizon(gpu, case):
+    """The same certificate at BASELINE's horizon: 4096 QPs of N = 1000 at n = 6 (1.8 GB of per-instance A, B; one-lane kernels, 8
+    segments per QP) and 1024 QPs at n = 12 (1.8 GB; rows-over-lanes kernels, tiled operands, 4 segments) solved to eps = 1e-8 with the
+    per-QP adaptive rule; 96 QPs spread over the batch are checked against THEIR OWN optimality conditions on the host."""
+    import dataclasses
+    if case.startswith("rendezvous"):
+        p = pkg.cw_rendezvous_instances(N=1000, batch=4096)
+    else:
+        p = pkg.cw_formation_instances(N=1000, batch=1024)
+    opt = pkg.Options(rho=0.05, alpha=1.6, eps_abs=1e-8, eps_rel=1e-8, max_iter=30000, check_interval=10, adapt_interval=50)
+    with pkg.Solver(p, opt) as s:
+        info = s.solve()
+        _, z, y = s.get()
+        rho = s.rho_per_qp()
+        segs = s.geometry()["segments"]
+    assert int(info.n_converged) == p.batch and info.status.all()
+    idx = np.linspace(0, p.batch - 1, 96).astype(int)
+    sub = dataclasses.replace(p, A=p.A[idx], B=p.B[idx], x0=p.x0[idx], lo=p.lo[idx], hi=p.hi[idx], q=None if p.q is None else p.q[idx])
+    feas_dyn, feas_box, stat, comp, n_active = ind.kkt_certificate_instances(sub, z[idx], y[idx], rho[idx])
+    worst = dict(feas_dyn=feas_dyn.max(), feas_box=feas_box.max(), stat=stat.max(), comp=comp.max())
+    print(case, "iterations", info.iters_run, "segments", segs, "rho", rho.min(), rho.max(), worst, "active", n_active)
+    assert feas_box.max() == 0.0, worst
+    assert feas_dyn.max() < 1e-6 and stat.max() < 1e-6 and comp.max() < 1e-6, worst
+    assert n_active > 100 * len(idx)
+
+
 XCASES = {
     "n6": (lambda: pkg.cw_rendezvous(N=1000, batch=4096), _abi.PRECISION_FP64),
     "n12": (lambda: pkg.cw_formation(N=1000, batch=4096), _abi.PRECISION_FP64),

@@ -339,3 +339,20 @@ def test_row_major_blocks_are_the_column_major_blocks(gpu, shape, monkeypatch):
     with pytest.raises(pkg.AdmmError) as e:
         pkg.Solver(shared, pkg.Options(rho=0.3, flags=_abi.FLAG_ROW_MAJOR))
     assert e.value.code == {v: k for k, v in _abi.STATUS_NAMES.items()}["ADMM_ERR_UNSUPPORTED"]
+
+
+def test_large_wide_handles_one_after_another(gpu):
+    """Regression (round 3): set-up zero-filled every device array asynchronously on the handle's non-blocking stream and then copied
+    the weights / shared box with synchronous null-stream copies, which do not wait for it -- with GBs of fills queued (n = 12, 1024 x
+    1000: the second large handle of a process, whose allocations are fast) a copy landed first and was zeroed afterwards: Q = R = 0 and
+    every QP wrong from the first iteration.  Three handles in a row, different segment counts, against the oracle on 32 of the QPs."""
+    import dataclasses
+    p = pkg.cw_formation_instances(N=1000, batch=1024)
+    idx = np.concatenate([np.arange(0, 16), np.arange(p.batch - 16, p.batch)])
+    sub = dataclasses.replace(p, A=p.A[idx], B=p.B[idx], x0=p.x0[idx], lo=p.lo[idx], hi=p.hi[idx])
+    ref = oc.solve(sub, rho=0.05, max_iter=6, stop=False)
+    for segments in (0, 1, 2):
+        with pkg.Solver(p, pkg.Options(rho=0.05, segments=segments)) as s:
+            s.run(6, residual_every=2)
+            w, z, y = s.get()
+        assert _close((w[idx], z[idx], y[idx]), ref), segments
