@@ -82,6 +82,9 @@ CASES = {
     "ltv_q_bounds_alpha": (lambda: pkg.random_ltv(N=90, n=6, m=3, batch=67, seed=77), dict(rho=0.3, alpha=1.6, segments=6), 0),
     "formation_12_6_small_batch_mfma": (lambda: pkg.cw_formation(N=160, batch=40), dict(rho=0.05, segments=8), 0),
     "thrust_magnitude": (lambda: pkg.cw_rendezvous(N=96, batch=20, thrust_norm=True), dict(rho=0.05, segments=4), 0),
+    # BASELINE's horizon (round 3: every other case here is small, and a set-up race that needed large arrays went unseen elsewhere)
+    "cw_6_3_full_horizon_1024": (lambda: pkg.cw_rendezvous(N=1000, batch=1024), dict(rho=0.05), 0),
+    "formation_12_6_full_horizon_512": (lambda: pkg.cw_formation(N=1000, batch=512), dict(rho=0.05), 0),
 }
 
 
