@@ -57,6 +57,7 @@ struct PLaunch {
   int* fail;
   int* qflag;                          // FACTOR / SEGMENTS trial runs: per-QP verdict [pitch] (bit 0: S_k not PD, bit 1: conditioning bound), or NULL
   const double *lo, *hi;
+  const double *loT, *hiT;             // wide shapes with per-instance bounds: the box in the tiled layout, [k][g][n + m][c] (else NULL)
   const double *z, *y, *q, *x0;
   double *v, *w, *dbuf, *part;
   // segments in time (S > 1; admm_pinst.hpp, pseg_kernel): per-QP transfer matrices and the segment vectors

@@ -265,7 +265,7 @@ void release(admm_handle* h) {
   for (auto b : bufs)
     if (*b) { (void)hipFree(*b); *b = nullptr; }
   {
-    double** pb[] = {&h->Ad, &h->Bd, &h->Kd, &h->Sd, &h->lod, &h->hid, &h->Qd, &h->Rd, &h->QNd,
+    double** pb[] = {&h->Ad, &h->Bd, &h->Kd, &h->Sd, &h->lod, &h->hid, &h->lodT, &h->hidT, &h->Qd, &h->Rd, &h->QNd,
                      &h->Ad2, &h->Bd2, &h->Kd2, &h->Sd2, &h->Qd2, &h->Rd2, &h->QNd2, &h->rho2_d};
     if (h->qflag_d) { (void)hipFree(h->qflag_d); h->qflag_d = nullptr; }
     if (h->nveto_d) { (void)hipFree(h->nveto_d); h->nveto_d = nullptr; }

@@ -55,6 +55,7 @@ admm::PLaunch plaunch_of(const admm_handle* h) {
   l.Ad = h->Ad; l.Bd = h->Bd; l.Q = h->Qd; l.R = h->Rd; l.QN = h->QNd; l.Kd = h->Kd; l.Sd = h->Sd; l.fail = h->pfail;
   l.qflag = nullptr;
   l.lo = h->pbounds ? h->lod : h->lo; l.hi = h->pbounds ? h->hid : h->hi;
+  l.loT = h->lodT; l.hiT = h->hidT;
   l.z = h->z; l.y = h->y; l.q = h->q; l.x0 = h->x0; l.v = h->v; l.w = h->w; l.dbuf = h->dbuf; l.part = h->part;
   return l;
 }

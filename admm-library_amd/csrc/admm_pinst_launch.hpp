@@ -70,11 +70,11 @@ void launch_dim_wide(const PLaunch& l, PKernel k) {
   do {                                                                                                                           \
     if (seg)                                                                                                                     \
       launch_with_lds<pxb_rows_kernel<NX, NU, HQ, VF, PB_, true, TILED>>(rgrid, rblock, TILED ? rg.waves_per_block * pxb_rows_lds_words<NX, NU, true>() * sizeof(double) : 0, l.stream, l.vform ? l.v : l.z, l.y, l.q, \
-                         l.Ad, l.Bd, l.Kd, l.Sd, l.lo, l.hi, l.dbuf, l.rhov, l.N, l.pitch, l.Omd, l.seg_start, l.tseg, l.eseg);   \
+                         l.Ad, l.Bd, l.Kd, l.Sd, l.lo, l.hi, l.dbuf, l.rhov, l.N, l.pitch, l.Omd, l.seg_start, l.tseg, l.eseg, l.loT, l.hiT);   \
     else                                                                                                                         \
       launch_with_lds<pxb_rows_kernel<NX, NU, HQ, VF, PB_, false, TILED>>(rgrid, rblock, TILED ? rg.waves_per_block * pxb_rows_lds_words<NX, NU, false>() * sizeof(double) : 0, l.stream, l.vform ? l.v : l.z, l.y,    \
                          l.q, l.Ad, l.Bd, l.Kd, l.Sd, l.lo, l.hi, l.dbuf, l.rhov, l.N, l.pitch, nullptr, nullptr, nullptr,       \
-                         nullptr);                                                                                               \
+                         nullptr, l.loT, l.hiT);                                                                                               \
   } while (0)
 #define XB2(HQ, VF) do { if (l.pbounds) XB(HQ, VF, true); else XB(HQ, VF, false); } while (0)
       if (l.has_q) { if (l.vform) XB2(true, true); else XB2(true, false); }
@@ -87,11 +87,11 @@ void launch_dim_wide(const PLaunch& l, PKernel k) {
       if (seg)
         launch_with_lds<pxfz_rows_kernel<NX, NU, false, false, false, false, false, true, true, TILED>>(rgrid, rblock, TILED ? rg.waves_per_block * pxfz_rows_lds_words<NX, NU, true>() * sizeof(double) : 0, l.stream,
                            l.dbuf, l.x0, l.Ad, l.Bd, l.Kd, l.lo, l.hi, l.z, l.y, l.v, l.w, l.part, l.alpha, l.N, l.pitch, l.Psd,
-                           l.seg_start, l.tin, l.xin);
+                           l.seg_start, l.tin, l.xin, l.loT, l.hiT);
       else
         launch_with_lds<pxfz_rows_kernel<NX, NU, false, false, false, false, false, true, false, TILED>>(rgrid, rblock, TILED ? rg.waves_per_block * pxfz_rows_lds_words<NX, NU, false>() * sizeof(double) : 0, l.stream,
                            l.dbuf, l.x0, l.Ad, l.Bd, l.Kd, l.lo, l.hi, l.z, l.y, l.v, l.w, l.part, l.alpha, l.N, l.pitch, nullptr,
-                           nullptr, nullptr, nullptr);
+                           nullptr, nullptr, nullptr, l.loT, l.hiT);
       break;
     case PKernel::XFZ: {
 #define XFZ(RS, RX, VI, PB_)                                                                                                       \
@@ -99,11 +99,11 @@ void launch_dim_wide(const PLaunch& l, PKernel k) {
     if (seg)                                                                                                                       \
       launch_with_lds<pxfz_rows_kernel<NX, NU, true, RS, RX, VI, PB_, false, true, TILED>>(rgrid, rblock, TILED ? rg.waves_per_block * pxfz_rows_lds_words<NX, NU, true>() * sizeof(double) : 0, l.stream, l.dbuf, l.x0, \
                          l.Ad, l.Bd, l.Kd, l.lo, l.hi, l.z, l.y, l.v, l.w, l.part, l.alpha, l.N, l.pitch, l.Psd, l.seg_start,      \
-                         l.tin, l.xin);                                                                                            \
+                         l.tin, l.xin, l.loT, l.hiT);                                                                                            \
     else                                                                                                                           \
       launch_with_lds<pxfz_rows_kernel<NX, NU, true, RS, RX, VI, PB_, false, false, TILED>>(rgrid, rblock, TILED ? rg.waves_per_block * pxfz_rows_lds_words<NX, NU, false>() * sizeof(double) : 0, l.stream, l.dbuf,      \
                          l.x0, l.Ad, l.Bd, l.Kd, l.lo, l.hi, l.z, l.y, l.v, l.w, l.part, l.alpha, l.N, l.pitch, nullptr, nullptr,  \
-                         nullptr, nullptr);                                                                                        \
+                         nullptr, nullptr, l.loT, l.hiT);                                                                                        \
   } while (0)
 #define XFZ3(RS, RX, VI) do { if (l.pbounds) XFZ(RS, RX, VI, true); else XFZ(RS, RX, VI, false); } while (0)
 #define XFZ2(RS, RX) do { if (l.vform) XFZ3(RS, RX, true); else XFZ3(RS, RX, false); } while (0)
@@ -143,10 +143,10 @@ void launch_dim(const PLaunch& l, PKernel k) {
   do {                                                                                                                           \
     if (l.rows && seg)                                                                                                           \
       hipLaunchKernelGGL((pxb_rows_kernel<NX, NU, HQ, VF, PB_, true>), rgrid, rblock, 0, l.stream, l.vform ? l.v : l.z, l.y, l.q,  \
-                         l.Ad, l.Bd, l.Kd, l.Sd, l.lo, l.hi, l.dbuf, l.rhov, l.N, l.pitch, l.Omd, l.seg_start, l.tseg, l.eseg);   \
+                         l.Ad, l.Bd, l.Kd, l.Sd, l.lo, l.hi, l.dbuf, l.rhov, l.N, l.pitch, l.Omd, l.seg_start, l.tseg, l.eseg, nullptr, nullptr);   \
     else if (l.rows)                                                                                                             \
       hipLaunchKernelGGL((pxb_rows_kernel<NX, NU, HQ, VF, PB_, false>), rgrid, rblock, 0, l.stream, l.vform ? l.v : l.z, l.y, l.q, \
-                         l.Ad, l.Bd, l.Kd, l.Sd, l.lo, l.hi, l.dbuf, l.rhov, l.N, l.pitch, nullptr, nullptr, nullptr, nullptr);   \
+                         l.Ad, l.Bd, l.Kd, l.Sd, l.lo, l.hi, l.dbuf, l.rhov, l.N, l.pitch, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);   \
     else if (l.has_soc && (VF) && seg)                                                                                           \
       hipLaunchKernelGGL((pxb_kernel<NX, NU, HQ, VF, PB_, true, (VF)>), sgrid, block, 0, l.stream, l.vform ? l.v : l.z, l.y, l.q, \
                          l.Ad, l.Bd, l.Kd, l.Sd, l.lo, l.hi, l.dbuf, l.rhov, l.N, l.pitch, l.Omd, l.seg_start, l.tseg, l.eseg,    \
@@ -173,11 +173,11 @@ void launch_dim(const PLaunch& l, PKernel k) {
       if (l.rows && seg)
         hipLaunchKernelGGL((pxfz_rows_kernel<NX, NU, false, false, false, false, false, true, true>), rgrid, rblock, 0, l.stream,
                            l.dbuf, l.x0, l.Ad, l.Bd, l.Kd, l.lo, l.hi, l.z, l.y, l.v, l.w, l.part, l.alpha, l.N, l.pitch, l.Psd,
-                           l.seg_start, l.tin, l.xin);
+                           l.seg_start, l.tin, l.xin, nullptr, nullptr);
       else if (l.rows)
         hipLaunchKernelGGL((pxfz_rows_kernel<NX, NU, false, false, false, false, false, true, false>), rgrid, rblock, 0, l.stream,
                            l.dbuf, l.x0, l.Ad, l.Bd, l.Kd, l.lo, l.hi, l.z, l.y, l.v, l.w, l.part, l.alpha, l.N, l.pitch, nullptr,
-                           nullptr, nullptr, nullptr);
+                           nullptr, nullptr, nullptr, nullptr, nullptr);
       else if (seg)
         hipLaunchKernelGGL((pxfz_kernel<NX, NU, false, false, false, false, false, true, true>), sgrid, block, 0, l.stream, l.dbuf,
                            l.x0, l.Ad, l.Bd, l.Kd, l.lo, l.hi, l.z, l.y, l.v, l.w, l.part, l.alpha, l.N, l.pitch, l.Psd,
@@ -193,11 +193,11 @@ void launch_dim(const PLaunch& l, PKernel k) {
     if (l.rows && seg)                                                                                                             \
       hipLaunchKernelGGL((pxfz_rows_kernel<NX, NU, true, RS, RX, VI, PB_, false, true>), rgrid, rblock, 0, l.stream, l.dbuf, l.x0,  \
                          l.Ad, l.Bd, l.Kd, l.lo, l.hi, l.z, l.y, l.v, l.w, l.part, l.alpha, l.N, l.pitch, l.Psd, l.seg_start,      \
-                         l.tin, l.xin);                                                                                            \
+                         l.tin, l.xin, nullptr, nullptr);                                                                                            \
     else if (l.rows)                                                                                                               \
       hipLaunchKernelGGL((pxfz_rows_kernel<NX, NU, true, RS, RX, VI, PB_, false, false>), rgrid, rblock, 0, l.stream, l.dbuf, l.x0, \
                          l.Ad, l.Bd, l.Kd, l.lo, l.hi, l.z, l.y, l.v, l.w, l.part, l.alpha, l.N, l.pitch, nullptr, nullptr,        \
-                         nullptr, nullptr);                                                                                        \
+                         nullptr, nullptr, nullptr, nullptr);                                                                                        \
     else if (l.has_soc && seg)                                                                                                     \
       hipLaunchKernelGGL((pxfz_kernel<NX, NU, true, RS, RX, VI, PB_, false, true, true>), sgrid, block, 0, l.stream, l.dbuf, l.x0, \
                          l.Ad, l.Bd, l.Kd, l.lo, l.hi, l.z, l.y, l.v, l.w, l.part, l.alpha, l.N, l.pitch, l.Psd, l.seg_start,      \

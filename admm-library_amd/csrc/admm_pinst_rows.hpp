@@ -39,7 +39,8 @@ __global__ __launch_bounds__(PROWS_BLOCK) void pxb_rows_kernel(
     const double* __restrict__ Ad, const double* __restrict__ Bd, const double* __restrict__ Kd,
     const double* __restrict__ Sd, const double* __restrict__ lo, const double* __restrict__ hi,
     double* __restrict__ dbuf, const double* __restrict__ rhov, int N, int pitch,
-    const double* __restrict__ Omd, const int* __restrict__ seg_start, double* __restrict__ tseg, double* __restrict__ eseg) {
+    const double* __restrict__ Omd, const int* __restrict__ seg_start, double* __restrict__ tseg, double* __restrict__ eseg,
+    const double* __restrict__ loT = nullptr, const double* __restrict__ hiT = nullptr) {
   constexpr int NB = NX + NU, D = ProwsDepth<NX>::D, QPW = PscanShape<NX>::QPW;
   static_assert(NU <= NX && QPW * NX <= PI_THREADS, "rows over lanes: m <= n, n x QPW lanes");
   const RowsLane<NX> ln;
@@ -52,7 +53,8 @@ __global__ __launch_bounds__(PROWS_BLOCK) void pxb_rows_kernel(
   const int sg = SEG ? (int)blockIdx.y : 0;
   const int ka = SEG ? seg_start[sg] : 0, kb = SEG ? seg_start[sg + 1] : N;
   auto across = [&](double v, int l) { return ln.across(v, l); };   // row l's value of this QP
-  struct OpsM { double Acol[NX], Kcol[NU], Om[SEG ? NU : 1], Bcol[NX], Si[NU]; };      // matrix operands of a stage
+  constexpr bool TB_ = TILED && PB && VFORM;      // per-instance box read as staged tiles
+  struct OpsM { double Acol[NX], Kcol[NU], Om[SEG ? NU : 1], Bcol[NX], Si[NU], lox, hix, lou, hiu; };      // matrix operands of a stage (+ its box, TB_)
   struct OpsS { double x0, x1, u0, u1, qx, qu, lox, hix, lou, hiu; };                  // its state / bound scalars
   auto loadS = [&](OpsS& o, int k) {
     const size_t ox = ((size_t)k * NB + NU + i) * P_ + col, ou = ((size_t)k * NB + j) * P_ + col;
@@ -60,7 +62,8 @@ __global__ __launch_bounds__(PROWS_BLOCK) void pxb_rows_kernel(
     o.x1 = VFORM ? 0.0 : y[ox]; o.u1 = VFORM ? 0.0 : y[ou];
     o.qx = HASQ ? q[ox] : 0.0; o.qu = HASQ ? q[ou] : 0.0;
     if (VFORM) {
-      if (PB) { o.lox = lo[ox]; o.hix = hi[ox]; o.lou = lo[ou]; o.hiu = hi[ou]; }
+      if (PB && TILED) { }                       // (the box comes with the staged tiles: lread)
+      else if (PB) { o.lox = lo[ox]; o.hix = hi[ox]; o.lou = lo[ou]; o.hiu = hi[ou]; }
       else {
         o.lox = lo[(size_t)k * NB + NU + i]; o.hix = hi[(size_t)k * NB + NU + i];
         o.lou = lo[(size_t)k * NB + j]; o.hiu = hi[(size_t)k * NB + j];
@@ -78,7 +81,8 @@ __global__ __launch_bounds__(PROWS_BLOCK) void pxb_rows_kernel(
     return g;
   };
   auto body = [&](const OpsM& m, const OpsS& o, int k, bool valid) {
-    const double gx = gterm(o.x0, o.x1, o.lox, o.hix, o.qx), gu = gterm(o.u0, o.u1, o.lou, o.hiu, o.qu);
+    const double gx = gterm(o.x0, o.x1, TB_ ? m.lox : o.lox, TB_ ? m.hix : o.hix, o.qx);
+    const double gu = gterm(o.u0, o.u1, TB_ ? m.lou : o.lou, TB_ ? m.hiu : o.hiu, o.qu);
     const double p = gx + t;
     double pv[NX], hv[NU];
 #pragma unroll
@@ -152,14 +156,15 @@ __global__ __launch_bounds__(PROWS_BLOCK) void pxb_rows_kernel(
     typedef StageTile<NU * NX, NX, QPW> TK;
     typedef StageTile<NU * NU, NU, QPW> TS;
     typedef StageTile<NX * NU, NU, QPW> TO;
+    typedef StageTile<NB, NB, QPW> TX;             // the box: [n + m][c] per stage and QP group
     constexpr int offB = TA::LWORDS, offK = offB + TB::LWORDS, offS = offK + TK::LWORDS, offO = offS + TS::LWORDS,
-                  SLOT = offO + (SEG ? TO::LWORDS : 0);
+                  offL = offO + (SEG ? TO::LWORDS : 0), offH = offL + (TB_ ? TX::LWORDS : 0), SLOT = offH + (TB_ ? TX::LWORDS : 0);
     extern __shared__ pair_t prows_lds[];
     double* slot0 = reinterpret_cast<double*>(prows_lds) + (size_t)(threadIdx.x / PI_THREADS) * 2 * SLOT;
     double* slot1 = slot0 + SLOT;
     const int lane = threadIdx.x % PI_THREADS, c = ln.c;
     const size_t G = P_ / QPW, g = (size_t)(col / QPW);
-    struct Raw { pair_t a[TA::NLD], b[TB::NLD], kk[TK::NLD], s[TS::NLD], o[SEG ? TO::NLD : 1]; };
+    struct Raw { pair_t a[TA::NLD], b[TB::NLD], kk[TK::NLD], s[TS::NLD], o[SEG ? TO::NLD : 1], xl[TB_ ? TX::NLD : 1], xh[TB_ ? TX::NLD : 1]; };
     auto gload = [&](Raw& r, int k) {
       const size_t kg = ((size_t)k * G + g) * QPW;
       TA::gload(r.a, Ad + kg * (NX * NX), lane);
@@ -167,6 +172,7 @@ __global__ __launch_bounds__(PROWS_BLOCK) void pxb_rows_kernel(
       TK::gload(r.kk, Kd + kg * (NU * NX), lane);
       TS::gload(r.s, Sd + kg * (NU * NU), lane);
       if constexpr (SEG) TO::gload(r.o, Omd + kg * (NX * NU), lane);
+      if constexpr (TB_) { TX::gload(r.xl, loT + kg * NB, lane); TX::gload(r.xh, hiT + kg * NB, lane); }
     };
     auto lstore = [&](const Raw& r, double* slot) {
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -175,6 +181,7 @@ __global__ __launch_bounds__(PROWS_BLOCK) void pxb_rows_kernel(
       TK::lstore(r.kk, slot + offK, lane);
       TS::lstore(r.s, slot + offS, lane);
       if constexpr (SEG) TO::lstore(r.o, slot + offO, lane);
+      if constexpr (TB_) { TX::lstore(r.xl, slot + offL, lane); TX::lstore(r.xh, slot + offH, lane); }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     };
     auto lread = [&](OpsM& m, const double* slot) {
@@ -188,6 +195,10 @@ __global__ __launch_bounds__(PROWS_BLOCK) void pxb_rows_kernel(
         m.Kcol[l] = slot[offK + TK::at(l, i, c)];      // K[l][i]: element l * n + i
         m.Si[l] = slot[offS + TS::at(j, l, c)];
         if (SEG) m.Om[l] = slot[offO + TO::at(i, l, c)];
+      }
+      if constexpr (TB_) {
+        m.lox = slot[offL + TX::at(0, NU + i, c)]; m.hix = slot[offH + TX::at(0, NU + i, c)];
+        m.lou = slot[offL + TX::at(0, j, c)];      m.hiu = slot[offH + TX::at(0, j, c)];
       }
     };
     auto ku = [&](int u) { return u < len ? kb - 1 - u : ka; };
@@ -239,7 +250,7 @@ __global__ __launch_bounds__(PROWS_BLOCK) void pxfz_rows_kernel(
     const double* __restrict__ hi, const double* __restrict__ zin, const double* __restrict__ yin,
     double* __restrict__ v, double* __restrict__ w, double* __restrict__ part, double alpha, int N, int pitch,
     const double* __restrict__ Psd, const int* __restrict__ seg_start, const double* __restrict__ tin,
-    const double* __restrict__ xin) {
+    const double* __restrict__ xin, const double* __restrict__ loT = nullptr, const double* __restrict__ hiT = nullptr) {
   constexpr int NB = NX + NU, D = ProwsDepth<NX>::D, QPW = PscanShape<NX>::QPW;
   constexpr bool NEEDZ = RESID || RELAX;
   static_assert(NU <= NX && QPW * NX <= PI_THREADS, "rows over lanes: m <= n, n x QPW lanes");
@@ -258,7 +269,8 @@ __global__ __launch_bounds__(PROWS_BLOCK) void pxfz_rows_kernel(
   for (int l = 0; l < (SEG ? NX : 1); ++l) ti[l] = SEG ? tin[((size_t)sg * NX + l) * P_ + col] : 0.0;
   // state operands as in pxfz_kernel: VIN: s0 = v;  else s0 = y and (NEEDZ) s1 = z
   const double* st0 = ZUP ? (VIN ? v : yin) : dbuf;
-  struct OpsM { double Krow[NX], Ps[SEG ? NX : 1], Arow[NX], Brow[NU]; };      // matrix operands of a stage
+  constexpr bool TB_ = TILED && PB && ZUP;        // per-instance box read as staged tiles
+  struct OpsM { double Krow[NX], Ps[SEG ? NX : 1], Arow[NX], Brow[NU], lox, hix, lou, hiu; };      // matrix operands of a stage (+ its box, TB_)
   struct OpsS { double dj, x0, x1, u0, u1, lox, hix, lou, hiu; };               // its feed-forward / state / bound scalars
   auto loadS = [&](OpsS& o, int k) {
     o.dj = dbuf[((size_t)k * NU + j) * P_ + col];
@@ -267,7 +279,8 @@ __global__ __launch_bounds__(PROWS_BLOCK) void pxfz_rows_kernel(
       o.x0 = st0[ox]; o.u0 = st0[ou];
       const bool two = !VIN && NEEDZ;
       o.x1 = two ? zin[ox] : 0.0; o.u1 = two ? zin[ou] : 0.0;
-      if (PB) { o.lox = lo[ox]; o.hix = hi[ox]; o.lou = lo[ou]; o.hiu = hi[ou]; }
+      if (PB && TILED) { }                       // (the box comes with the staged tiles: lread)
+      else if (PB) { o.lox = lo[ox]; o.hix = hi[ox]; o.lou = lo[ou]; o.hiu = hi[ou]; }
       else {
         o.lox = lo[(size_t)k * NB + NU + i]; o.hix = hi[(size_t)k * NB + NU + i];
         o.lou = lo[(size_t)k * NB + j]; o.hiu = hi[(size_t)k * NB + j];
@@ -320,8 +333,8 @@ __global__ __launch_bounds__(PROWS_BLOCK) void pxfz_rows_kernel(
     for (int l = 0; l < NU; ++l) b = fma(m.Brow[l], uv[l], b);
     x = valid ? b : x;
     const size_t ox = ((size_t)k * NB + NU + i) * P_ + col, ou = ((size_t)k * NB + j) * P_ + col;
-    zrow(wu, o.u0, o.u1, o.lou, o.hiu, ou, valid && live_u, accu);
-    zrow(b, o.x0, o.x1, o.lox, o.hix, ox, valid && live_x, accx);
+    zrow(wu, o.u0, o.u1, TB_ ? m.lou : o.lou, TB_ ? m.hiu : o.hiu, ou, valid && live_u, accu);
+    zrow(b, o.x0, o.x1, TB_ ? m.lox : o.lox, TB_ ? m.hix : o.hix, ox, valid && live_x, accx);
   };
   const int len = kb - ka;                    // stage u of the segment is k = ka + u
   if constexpr (!TILED) {
@@ -363,19 +376,22 @@ __global__ __launch_bounds__(PROWS_BLOCK) void pxfz_rows_kernel(
     typedef StageTile<NX * NX, NX, QPW> TA;
     typedef StageTile<NX * NU, NX, QPW> TB;
     typedef StageTile<NU * NX, NX, QPW> TK;      // K and Psi: [m][n], row-major
-    constexpr int offB = TA::LWORDS, offK = offB + TB::LWORDS, offP = offK + TK::LWORDS, SLOT = offP + (SEG ? TK::LWORDS : 0);
+    typedef StageTile<NB, NB, QPW> TX;             // the box: [n + m][c] per stage and QP group
+    constexpr int offB = TA::LWORDS, offK = offB + TB::LWORDS, offP = offK + TK::LWORDS, offL = offP + (SEG ? TK::LWORDS : 0),
+                  offH = offL + (TB_ ? TX::LWORDS : 0), SLOT = offH + (TB_ ? TX::LWORDS : 0);
     extern __shared__ pair_t prows_lds[];
     double* slot0 = reinterpret_cast<double*>(prows_lds) + (size_t)(threadIdx.x / PI_THREADS) * 2 * SLOT;
     double* slot1 = slot0 + SLOT;
     const int lane = threadIdx.x % PI_THREADS, c = ln.c;
     const size_t G = P_ / QPW, g = (size_t)(col / QPW);
-    struct Raw { pair_t a[TA::NLD], b[TB::NLD], kk[TK::NLD], ps[SEG ? TK::NLD : 1]; };
+    struct Raw { pair_t a[TA::NLD], b[TB::NLD], kk[TK::NLD], ps[SEG ? TK::NLD : 1], xl[TB_ ? TX::NLD : 1], xh[TB_ ? TX::NLD : 1]; };
     auto gload = [&](Raw& r, int k) {
       const size_t kg = ((size_t)k * G + g) * QPW;
       TA::gload(r.a, Ad + kg * (NX * NX), lane);
       TB::gload(r.b, Bd + kg * (NX * NU), lane);
       TK::gload(r.kk, Kd + kg * (NU * NX), lane);
       if constexpr (SEG) TK::gload(r.ps, Psd + kg * (NU * NX), lane);
+      if constexpr (TB_) { TX::gload(r.xl, loT + kg * NB, lane); TX::gload(r.xh, hiT + kg * NB, lane); }
     };
     auto lstore = [&](const Raw& r, double* slot) {
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -383,6 +399,7 @@ __global__ __launch_bounds__(PROWS_BLOCK) void pxfz_rows_kernel(
       TB::lstore(r.b, slot + offB, lane);
       TK::lstore(r.kk, slot + offK, lane);
       if constexpr (SEG) TK::lstore(r.ps, slot + offP, lane);
+      if constexpr (TB_) { TX::lstore(r.xl, slot + offL, lane); TX::lstore(r.xh, slot + offH, lane); }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     };
     auto lread = [&](OpsM& m, const double* slot) {
@@ -394,6 +411,10 @@ __global__ __launch_bounds__(PROWS_BLOCK) void pxfz_rows_kernel(
       }
 #pragma unroll
       for (int l = 0; l < NU; ++l) m.Brow[l] = slot[offB + TB::at(l, i, c)];     // B[i][l]: element l * n + i
+      if constexpr (TB_) {
+        m.lox = slot[offL + TX::at(0, NU + i, c)]; m.hix = slot[offH + TX::at(0, NU + i, c)];
+        m.lou = slot[offL + TX::at(0, j, c)];      m.hiu = slot[offH + TX::at(0, j, c)];
+      }
     };
     auto ku = [&](int u) { return u < len ? ka + u : kb - 1; };
     Raw R0, R1;
@@ -447,12 +468,13 @@ template <int NX, int NU, bool SEG>
 constexpr int pxb_rows_lds_words() {
   constexpr int Q = PscanShape<NX>::QPW;
   return 2 * (StageTile<NX * NX, NX, Q>::LWORDS + StageTile<NX * NU, NX, Q>::LWORDS + StageTile<NU * NX, NX, Q>::LWORDS +
-              StageTile<NU * NU, NU, Q>::LWORDS + (SEG ? StageTile<NX * NU, NU, Q>::LWORDS : 0));
+              StageTile<NU * NU, NU, Q>::LWORDS + (SEG ? StageTile<NX * NU, NU, Q>::LWORDS : 0) + 2 * StageTile<NX + NU, NX + NU, Q>::LWORDS);
 }
 template <int NX, int NU, bool SEG>
 constexpr int pxfz_rows_lds_words() {
   constexpr int Q = PscanShape<NX>::QPW;
-  return 2 * (StageTile<NX * NX, NX, Q>::LWORDS + StageTile<NX * NU, NX, Q>::LWORDS + (SEG ? 2 : 1) * StageTile<NU * NX, NX, Q>::LWORDS);
+  return 2 * (StageTile<NX * NX, NX, Q>::LWORDS + StageTile<NX * NU, NX, Q>::LWORDS + (SEG ? 2 : 1) * StageTile<NU * NX, NX, Q>::LWORDS +
+              2 * StageTile<NX + NU, NX + NU, Q>::LWORDS);
 }
 
 }  // namespace admm

@@ -70,6 +70,10 @@ int pinst_upload_bounds(admm_handle* h, const admm_problem* p) {
   if (h->pbounds) {
     if ((rc = upload_transposed(h, p->lo, h->lod, h->L))) return rc;
     if ((rc = upload_transposed(h, p->hi, h->hid, h->L))) return rc;
+    if (h->lodT) {                                  // the sweeps of the wide shapes read the box as tiles, staged with the operands
+      if ((rc = upload_tiled(h, p->lo, h->lodT, h->nb))) return rc;
+      if ((rc = upload_tiled(h, p->hi, h->hidT, h->nb))) return rc;
+    }
     std::vector<double> ub(h->N, INFINITY);         // thrust-magnitude bound per stage (shared by the batch)
     if (p->unorm)
       for (int k = 0; k < h->N; ++k) ub[k] = p->unorm[k];
@@ -262,6 +266,7 @@ int setup_pinst(admm_handle* h, const admm_problem* p) {
   PD(h->Ad, (size_t)N * n * n * P); PD(h->Bd, (size_t)N * n * m * P);
   PD(h->Kd, (size_t)N * m * n * P); PD(h->Sd, (size_t)N * m * m * P);
   if (h->pbounds) { PD(h->lod, L * P); PD(h->hid, L * P); }
+  if (h->pbounds && h->pi_tiled) { PD(h->lodT, L * P); PD(h->hidT, L * P); }
   PD(h->Qd, (size_t)n * n); PD(h->Rd, (size_t)m * m); PD(h->QNd, (size_t)n * n);
   PD(h->pfail, 1); PD(h->status, P); PD(h->iters, P); PD(h->nconv, 1);
   PD(h->rho_d, P); PD(h->cscale_d, P); PD(h->nupd_d, P); PD(h->todo_d, P); PD(h->nchanged_d, 1);

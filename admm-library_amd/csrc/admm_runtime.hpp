@@ -106,6 +106,7 @@ struct admm_handle {
   // per-instance dynamics (csrc/admm_pinst.hpp): device-side factor, operands per QP in HBM
   bool pinst = false, pbounds = false;
   double *Ad = nullptr, *Bd = nullptr, *Kd = nullptr, *Sd = nullptr, *lod = nullptr, *hid = nullptr;
+  double *lodT = nullptr, *hidT = nullptr;   // wide shapes: a second, TILED copy of the per-instance box for the sweeps (csrc/admm_pinst.hpp, Operand)
   double *Qd = nullptr, *Rd = nullptr, *QNd = nullptr;
   int* pfail = nullptr;
   // TRIAL buffers of the per-instance path (allocated on first use): a change of rho or of the problem data is factorised
