@@ -53,7 +53,11 @@ __global__ __launch_bounds__(PROWS_BLOCK) void pxb_rows_kernel(
   const int sg = SEG ? (int)blockIdx.y : 0;
   const int ka = SEG ? seg_start[sg] : 0, kb = SEG ? seg_start[sg + 1] : N;
   auto across = [&](double v, int l) { return ln.across(v, l); };   // row l's value of this QP
+#ifdef ADMM_NO_TILED_BOUNDS
+  constexpr bool TB_ = false;
+#else
   constexpr bool TB_ = TILED && PB && VFORM;      // per-instance box read as staged tiles
+#endif
   struct OpsM { double Acol[NX], Kcol[NU], Om[SEG ? NU : 1], Bcol[NX], Si[NU], lox, hix, lou, hiu; };      // matrix operands of a stage (+ its box, TB_)
   struct OpsS { double x0, x1, u0, u1, qx, qu, lox, hix, lou, hiu; };                  // its state / bound scalars
   auto loadS = [&](OpsS& o, int k) {
@@ -62,7 +66,7 @@ __global__ __launch_bounds__(PROWS_BLOCK) void pxb_rows_kernel(
     o.x1 = VFORM ? 0.0 : y[ox]; o.u1 = VFORM ? 0.0 : y[ou];
     o.qx = HASQ ? q[ox] : 0.0; o.qu = HASQ ? q[ou] : 0.0;
     if (VFORM) {
-      if (PB && TILED) { }                       // (the box comes with the staged tiles: lread)
+      if (TB_) { }                               // (the box comes with the staged tiles: lread)
       else if (PB) { o.lox = lo[ox]; o.hix = hi[ox]; o.lou = lo[ou]; o.hiu = hi[ou]; }
       else {
         o.lox = lo[(size_t)k * NB + NU + i]; o.hix = hi[(size_t)k * NB + NU + i];
@@ -269,7 +273,11 @@ __global__ __launch_bounds__(PROWS_BLOCK) void pxfz_rows_kernel(
   for (int l = 0; l < (SEG ? NX : 1); ++l) ti[l] = SEG ? tin[((size_t)sg * NX + l) * P_ + col] : 0.0;
   // state operands as in pxfz_kernel: VIN: s0 = v;  else s0 = y and (NEEDZ) s1 = z
   const double* st0 = ZUP ? (VIN ? v : yin) : dbuf;
+#ifdef ADMM_NO_TILED_BOUNDS
+  constexpr bool TB_ = false;
+#else
   constexpr bool TB_ = TILED && PB && ZUP;        // per-instance box read as staged tiles
+#endif
   struct OpsM { double Krow[NX], Ps[SEG ? NX : 1], Arow[NX], Brow[NU], lox, hix, lou, hiu; };      // matrix operands of a stage (+ its box, TB_)
   struct OpsS { double dj, x0, x1, u0, u1, lox, hix, lou, hiu; };               // its feed-forward / state / bound scalars
   auto loadS = [&](OpsS& o, int k) {
@@ -279,7 +287,7 @@ __global__ __launch_bounds__(PROWS_BLOCK) void pxfz_rows_kernel(
       o.x0 = st0[ox]; o.u0 = st0[ou];
       const bool two = !VIN && NEEDZ;
       o.x1 = two ? zin[ox] : 0.0; o.u1 = two ? zin[ou] : 0.0;
-      if (PB && TILED) { }                       // (the box comes with the staged tiles: lread)
+      if (TB_) { }                               // (the box comes with the staged tiles: lread)
       else if (PB) { o.lox = lo[ox]; o.hix = hi[ox]; o.lou = lo[ou]; o.hiu = hi[ou]; }
       else {
         o.lox = lo[(size_t)k * NB + NU + i]; o.hix = hi[(size_t)k * NB + NU + i];
