@@ -68,13 +68,13 @@ struct PLaunch {
   int* grow;                           // SEGMENTS: set if a transfer matrix exceeds the conditioning bound
   bool rows;                           // small batches: the sweeps with a QP's rows spread over lanes (admm_pinst_rows.hpp)
   bool rows_factor;                    // (6, 3) only: FACTOR / SEGMENTS through the wide shapes' kernels (admm_pinst_wide.hpp)
-  bool has_soc;                        // thrust-magnitude bound ub [N] on the control rows (one-lane kernels only)
+  bool has_soc;                        // thrust-magnitude bound ub [N] on the control rows (one-lane kernels; rows-over-lanes kernels of the wide shapes)
   const double* ub;
 };
 enum class PKernel { FACTOR, XB, XF, XFZ, SEGMENTS, SCAN };
 bool launch_pinst(const PLaunch& l, PKernel k, bool query_only);
 size_t pinst_wide_lds_bytes(int n, int m);   // LDS per workgroup of the wide shapes' sweeps (0: not a wide shape)
-bool pinst_rows_only(int n, int m);   // a wide shape: rows-over-lanes kernels whatever the batch, no thrust-magnitude forms
+bool pinst_rows_only(int n, int m);   // a wide shape: rows-over-lanes kernels whatever the batch
 void launch_padapt(hipStream_t stream, const double* resid, const int* status, double* rhov, int* nupd, int* todo,
                    double* cscale, int* nchanged, double mu2, double tau, int adapt_max, int pitch, int batch, double* rho_prev);
 void launch_padapt_veto(hipStream_t stream, const int* qflag, const double* rho_prev, double* rhov, int* nupd, int* todo,

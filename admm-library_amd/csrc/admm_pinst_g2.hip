@@ -1,6 +1,6 @@
 // Per-instance dynamics: the WIDE shapes (admm_pinst_wide.hpp) -- every kernel with a QP's rows spread over the lanes of a wave,
 // whatever the batch: one lane cannot hold a stage's operands from n = 8 on; operand arrays TILED (admm_pinst.hpp, Operand).
-// No thrust-magnitude forms.
+// The thrust-magnitude forms project over a QP's control rows with cross-lane reads (admm_pinst_rows.hpp, SOC).
 #include "admm_pinst_launch.hpp"
 
 #define ADMM_PINST_DIMS_G2(X) X(12, 6) X(8, 4) X(12, 3) X(9, 3)

@@ -44,7 +44,7 @@ struct RowsGrid {
   }
 };
 
-// Wide shapes (admm_pinst_wide.hpp): every kernel in its rows-over-lanes form; no thrust-magnitude forms.  TILED: the operand
+// Wide shapes (admm_pinst_wide.hpp): every kernel in its rows-over-lanes form (SOC: the thrust-magnitude forms of the sweeps).  TILED: the operand
 // arrays in the tiled layout (admm_pinst.hpp, Operand) -- the wide shapes' handles; false = the twin at (6, 3) on a batch-minor handle.
 template <int NX, int NU, bool TILED>
 void launch_dim_wide(const PLaunch& l, PKernel k) {
@@ -66,20 +66,22 @@ void launch_dim_wide(const PLaunch& l, PKernel k) {
                          l.Kd, l.Sd, l.fail, l.N, l.pitch, l.batch, l.qflag);
       break;
     case PKernel::XB: {
-#define XB(HQ, VF, PB_)                                                                                                          \
+#define XB(HQ, VF, PB_, SC)                                                                                                        \
   do {                                                                                                                           \
     if (seg)                                                                                                                     \
-      launch_with_lds<pxb_rows_kernel<NX, NU, HQ, VF, PB_, true, TILED>>(rgrid, rblock, TILED ? rg.waves_per_block * pxb_rows_lds_words<NX, NU, true>() * sizeof(double) : 0, l.stream, l.vform ? l.v : l.z, l.y, l.q, \
-                         l.Ad, l.Bd, l.Kd, l.Sd, l.lo, l.hi, l.dbuf, l.rhov, l.N, l.pitch, l.Omd, l.seg_start, l.tseg, l.eseg, l.loT, l.hiT);   \
+      launch_with_lds<pxb_rows_kernel<NX, NU, HQ, VF, PB_, true, TILED, SC>>(rgrid, rblock, TILED ? rg.waves_per_block * pxb_rows_lds_words<NX, NU, true>() * sizeof(double) : 0, l.stream, l.vform ? l.v : l.z, l.y, l.q, \
+                         l.Ad, l.Bd, l.Kd, l.Sd, l.lo, l.hi, l.dbuf, l.rhov, l.N, l.pitch, l.Omd, l.seg_start, l.tseg, l.eseg, l.loT, l.hiT, l.ub);   \
     else                                                                                                                         \
-      launch_with_lds<pxb_rows_kernel<NX, NU, HQ, VF, PB_, false, TILED>>(rgrid, rblock, TILED ? rg.waves_per_block * pxb_rows_lds_words<NX, NU, false>() * sizeof(double) : 0, l.stream, l.vform ? l.v : l.z, l.y,    \
+      launch_with_lds<pxb_rows_kernel<NX, NU, HQ, VF, PB_, false, TILED, SC>>(rgrid, rblock, TILED ? rg.waves_per_block * pxb_rows_lds_words<NX, NU, false>() * sizeof(double) : 0, l.stream, l.vform ? l.v : l.z, l.y,    \
                          l.q, l.Ad, l.Bd, l.Kd, l.Sd, l.lo, l.hi, l.dbuf, l.rhov, l.N, l.pitch, nullptr, nullptr, nullptr,       \
-                         nullptr, l.loT, l.hiT);                                                                                               \
+                         nullptr, l.loT, l.hiT, l.ub);                                                                                               \
   } while (0)
-#define XB2(HQ, VF) do { if (l.pbounds) XB(HQ, VF, true); else XB(HQ, VF, false); } while (0)
+#define XB3(HQ, VF, PB_) do { if constexpr (VF && TILED) { if (l.has_soc) XB(HQ, VF, PB_, true); else XB(HQ, VF, PB_, false); } else XB(HQ, VF, PB_, false); } while (0)
+#define XB2(HQ, VF) do { if (l.pbounds) XB3(HQ, VF, true); else XB3(HQ, VF, false); } while (0)
       if (l.has_q) { if (l.vform) XB2(true, true); else XB2(true, false); }
       else         { if (l.vform) XB2(false, true); else XB2(false, false); }
 #undef XB2
+#undef XB3
 #undef XB
       break;
     }
@@ -87,30 +89,32 @@ void launch_dim_wide(const PLaunch& l, PKernel k) {
       if (seg)
         launch_with_lds<pxfz_rows_kernel<NX, NU, false, false, false, false, false, true, true, TILED>>(rgrid, rblock, TILED ? rg.waves_per_block * pxfz_rows_lds_words<NX, NU, true>() * sizeof(double) : 0, l.stream,
                            l.dbuf, l.x0, l.Ad, l.Bd, l.Kd, l.lo, l.hi, l.z, l.y, l.v, l.w, l.part, l.alpha, l.N, l.pitch, l.Psd,
-                           l.seg_start, l.tin, l.xin, l.loT, l.hiT);
+                           l.seg_start, l.tin, l.xin, l.loT, l.hiT, l.ub);
       else
         launch_with_lds<pxfz_rows_kernel<NX, NU, false, false, false, false, false, true, false, TILED>>(rgrid, rblock, TILED ? rg.waves_per_block * pxfz_rows_lds_words<NX, NU, false>() * sizeof(double) : 0, l.stream,
                            l.dbuf, l.x0, l.Ad, l.Bd, l.Kd, l.lo, l.hi, l.z, l.y, l.v, l.w, l.part, l.alpha, l.N, l.pitch, nullptr,
-                           nullptr, nullptr, nullptr, l.loT, l.hiT);
+                           nullptr, nullptr, nullptr, l.loT, l.hiT, l.ub);
       break;
     case PKernel::XFZ: {
-#define XFZ(RS, RX, VI, PB_)                                                                                                       \
+#define XFZ(RS, RX, VI, PB_, SC)                                                                                                     \
   do {                                                                                                                             \
     if (seg)                                                                                                                       \
-      launch_with_lds<pxfz_rows_kernel<NX, NU, true, RS, RX, VI, PB_, false, true, TILED>>(rgrid, rblock, TILED ? rg.waves_per_block * pxfz_rows_lds_words<NX, NU, true>() * sizeof(double) : 0, l.stream, l.dbuf, l.x0, \
+      launch_with_lds<pxfz_rows_kernel<NX, NU, true, RS, RX, VI, PB_, false, true, TILED, SC>>(rgrid, rblock, TILED ? rg.waves_per_block * pxfz_rows_lds_words<NX, NU, true>() * sizeof(double) : 0, l.stream, l.dbuf, l.x0, \
                          l.Ad, l.Bd, l.Kd, l.lo, l.hi, l.z, l.y, l.v, l.w, l.part, l.alpha, l.N, l.pitch, l.Psd, l.seg_start,      \
-                         l.tin, l.xin, l.loT, l.hiT);                                                                                            \
+                         l.tin, l.xin, l.loT, l.hiT, l.ub);                                                                                          \
     else                                                                                                                           \
-      launch_with_lds<pxfz_rows_kernel<NX, NU, true, RS, RX, VI, PB_, false, false, TILED>>(rgrid, rblock, TILED ? rg.waves_per_block * pxfz_rows_lds_words<NX, NU, false>() * sizeof(double) : 0, l.stream, l.dbuf,      \
+      launch_with_lds<pxfz_rows_kernel<NX, NU, true, RS, RX, VI, PB_, false, false, TILED, SC>>(rgrid, rblock, TILED ? rg.waves_per_block * pxfz_rows_lds_words<NX, NU, false>() * sizeof(double) : 0, l.stream, l.dbuf,      \
                          l.x0, l.Ad, l.Bd, l.Kd, l.lo, l.hi, l.z, l.y, l.v, l.w, l.part, l.alpha, l.N, l.pitch, nullptr, nullptr,  \
-                         nullptr, nullptr, l.loT, l.hiT);                                                                                        \
+                         nullptr, nullptr, l.loT, l.hiT, l.ub);                                                                                      \
   } while (0)
-#define XFZ3(RS, RX, VI) do { if (l.pbounds) XFZ(RS, RX, VI, true); else XFZ(RS, RX, VI, false); } while (0)
+#define XFZ4(RS, RX, VI, PB_) do { if constexpr ((RS || VI) && TILED) { if (l.has_soc) XFZ(RS, RX, VI, PB_, true); else XFZ(RS, RX, VI, PB_, false); } else XFZ(RS, RX, VI, PB_, false); } while (0)
+#define XFZ3(RS, RX, VI) do { if (l.pbounds) XFZ4(RS, RX, VI, true); else XFZ4(RS, RX, VI, false); } while (0)
 #define XFZ2(RS, RX) do { if (l.vform) XFZ3(RS, RX, true); else XFZ3(RS, RX, false); } while (0)
       if (l.resid) { if (relax) XFZ2(true, true); else XFZ2(true, false); }
       else         { if (relax) XFZ2(false, true); else XFZ2(false, false); }
 #undef XFZ2
 #undef XFZ3
+#undef XFZ4
 #undef XFZ
       break;
     }
@@ -143,10 +147,10 @@ void launch_dim(const PLaunch& l, PKernel k) {
   do {                                                                                                                           \
     if (l.rows && seg)                                                                                                           \
       hipLaunchKernelGGL((pxb_rows_kernel<NX, NU, HQ, VF, PB_, true>), rgrid, rblock, 0, l.stream, l.vform ? l.v : l.z, l.y, l.q,  \
-                         l.Ad, l.Bd, l.Kd, l.Sd, l.lo, l.hi, l.dbuf, l.rhov, l.N, l.pitch, l.Omd, l.seg_start, l.tseg, l.eseg, nullptr, nullptr);   \
+                         l.Ad, l.Bd, l.Kd, l.Sd, l.lo, l.hi, l.dbuf, l.rhov, l.N, l.pitch, l.Omd, l.seg_start, l.tseg, l.eseg, nullptr, nullptr, nullptr);   \
     else if (l.rows)                                                                                                             \
       hipLaunchKernelGGL((pxb_rows_kernel<NX, NU, HQ, VF, PB_, false>), rgrid, rblock, 0, l.stream, l.vform ? l.v : l.z, l.y, l.q, \
-                         l.Ad, l.Bd, l.Kd, l.Sd, l.lo, l.hi, l.dbuf, l.rhov, l.N, l.pitch, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);   \
+                         l.Ad, l.Bd, l.Kd, l.Sd, l.lo, l.hi, l.dbuf, l.rhov, l.N, l.pitch, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);   \
     else if (l.has_soc && (VF) && seg)                                                                                           \
       hipLaunchKernelGGL((pxb_kernel<NX, NU, HQ, VF, PB_, true, (VF)>), sgrid, block, 0, l.stream, l.vform ? l.v : l.z, l.y, l.q, \
                          l.Ad, l.Bd, l.Kd, l.Sd, l.lo, l.hi, l.dbuf, l.rhov, l.N, l.pitch, l.Omd, l.seg_start, l.tseg, l.eseg,    \
@@ -160,7 +164,7 @@ void launch_dim(const PLaunch& l, PKernel k) {
                          l.Bd, l.Kd, l.Sd, l.lo, l.hi, l.dbuf, l.rhov, l.N, l.pitch, l.Omd, l.seg_start, l.tseg, l.eseg);         \
     else                                                                                                                         \
       hipLaunchKernelGGL((pxb_kernel<NX, NU, HQ, VF, PB_, false>), grid, block, 0, l.stream, l.vform ? l.v : l.z, l.y, l.q, l.Ad, \
-                         l.Bd, l.Kd, l.Sd, l.lo, l.hi, l.dbuf, l.rhov, l.N, l.pitch, nullptr, nullptr, nullptr, nullptr);          \
+                         l.Bd, l.Kd, l.Sd, l.lo, l.hi, l.dbuf, l.rhov, l.N, l.pitch, nullptr, nullptr, nullptr, nullptr, nullptr);          \
   } while (0)
 #define XB2(HQ, VF) do { if (l.pbounds) XB(HQ, VF, true); else XB(HQ, VF, false); } while (0)
       if (l.has_q) { if (l.vform) XB2(true, true); else XB2(true, false); }
@@ -173,11 +177,11 @@ void launch_dim(const PLaunch& l, PKernel k) {
       if (l.rows && seg)
         hipLaunchKernelGGL((pxfz_rows_kernel<NX, NU, false, false, false, false, false, true, true>), rgrid, rblock, 0, l.stream,
                            l.dbuf, l.x0, l.Ad, l.Bd, l.Kd, l.lo, l.hi, l.z, l.y, l.v, l.w, l.part, l.alpha, l.N, l.pitch, l.Psd,
-                           l.seg_start, l.tin, l.xin, nullptr, nullptr);
+                           l.seg_start, l.tin, l.xin, nullptr, nullptr, nullptr);
       else if (l.rows)
         hipLaunchKernelGGL((pxfz_rows_kernel<NX, NU, false, false, false, false, false, true, false>), rgrid, rblock, 0, l.stream,
                            l.dbuf, l.x0, l.Ad, l.Bd, l.Kd, l.lo, l.hi, l.z, l.y, l.v, l.w, l.part, l.alpha, l.N, l.pitch, nullptr,
-                           nullptr, nullptr, nullptr, nullptr, nullptr);
+                           nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
       else if (seg)
         hipLaunchKernelGGL((pxfz_kernel<NX, NU, false, false, false, false, false, true, true>), sgrid, block, 0, l.stream, l.dbuf,
                            l.x0, l.Ad, l.Bd, l.Kd, l.lo, l.hi, l.z, l.y, l.v, l.w, l.part, l.alpha, l.N, l.pitch, l.Psd,
@@ -185,7 +189,7 @@ void launch_dim(const PLaunch& l, PKernel k) {
       else
         hipLaunchKernelGGL((pxfz_kernel<NX, NU, false, false, false, false, false, true>), grid, block, 0, l.stream, l.dbuf,
                            l.x0, l.Ad, l.Bd, l.Kd, l.lo, l.hi, l.z, l.y, l.v, l.w, l.part, l.alpha, l.N, l.pitch, nullptr,
-                           nullptr, nullptr, nullptr);
+                           nullptr, nullptr, nullptr, nullptr);
       break;
     case PKernel::XFZ: {
 #define XFZ(RS, RX, VI, PB_)                                                                                                       \
@@ -193,11 +197,11 @@ void launch_dim(const PLaunch& l, PKernel k) {
     if (l.rows && seg)                                                                                                             \
       hipLaunchKernelGGL((pxfz_rows_kernel<NX, NU, true, RS, RX, VI, PB_, false, true>), rgrid, rblock, 0, l.stream, l.dbuf, l.x0,  \
                          l.Ad, l.Bd, l.Kd, l.lo, l.hi, l.z, l.y, l.v, l.w, l.part, l.alpha, l.N, l.pitch, l.Psd, l.seg_start,      \
-                         l.tin, l.xin, nullptr, nullptr);                                                                                            \
+                         l.tin, l.xin, nullptr, nullptr, nullptr);                                                                                            \
     else if (l.rows)                                                                                                               \
       hipLaunchKernelGGL((pxfz_rows_kernel<NX, NU, true, RS, RX, VI, PB_, false, false>), rgrid, rblock, 0, l.stream, l.dbuf, l.x0, \
                          l.Ad, l.Bd, l.Kd, l.lo, l.hi, l.z, l.y, l.v, l.w, l.part, l.alpha, l.N, l.pitch, nullptr, nullptr,        \
-                         nullptr, nullptr, nullptr, nullptr);                                                                                        \
+                         nullptr, nullptr, nullptr, nullptr, nullptr);                                                                                        \
     else if (l.has_soc && seg)                                                                                                     \
       hipLaunchKernelGGL((pxfz_kernel<NX, NU, true, RS, RX, VI, PB_, false, true, true>), sgrid, block, 0, l.stream, l.dbuf, l.x0, \
                          l.Ad, l.Bd, l.Kd, l.lo, l.hi, l.z, l.y, l.v, l.w, l.part, l.alpha, l.N, l.pitch, l.Psd, l.seg_start,      \

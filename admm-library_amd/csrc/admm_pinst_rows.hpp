@@ -33,15 +33,16 @@ template <int NX> struct ProwsDepth { static constexpr int D = NX >= 8 ? 1 : ADM
 // Backward sweep, rows over lanes (the arithmetic of pxb_kernel):
 //     g = q - rho (z - y);  p = g^x + t;  h = B'p + g^u;  d_k = Si h -> dbuf;  t = A'p - K'h;   SEG: e += Omega_k d_k
 // ---------------------------------------------------------------------------
-template <int NX, int NU, bool HASQ, bool VFORM, bool PB, bool SEG, bool TILED = false>
+template <int NX, int NU, bool HASQ, bool VFORM, bool PB, bool SEG, bool TILED = false, bool SOC = false>
 __global__ __launch_bounds__(PROWS_BLOCK) void pxb_rows_kernel(
     const double* __restrict__ z, const double* __restrict__ y, const double* __restrict__ q,
     const double* __restrict__ Ad, const double* __restrict__ Bd, const double* __restrict__ Kd,
     const double* __restrict__ Sd, const double* __restrict__ lo, const double* __restrict__ hi,
     double* __restrict__ dbuf, const double* __restrict__ rhov, int N, int pitch,
     const double* __restrict__ Omd, const int* __restrict__ seg_start, double* __restrict__ tseg, double* __restrict__ eseg,
-    const double* __restrict__ loT = nullptr, const double* __restrict__ hiT = nullptr) {
+    const double* __restrict__ loT = nullptr, const double* __restrict__ hiT = nullptr, const double* __restrict__ ubd = nullptr) {
   constexpr int NB = NX + NU, D = ProwsDepth<NX>::D, QPW = PscanShape<NX>::QPW;
+  static_assert(!SOC || VFORM, "the (z, y) form carries the projected z: only the v-form projects");
   static_assert(NU <= NX && QPW * NX <= PI_THREADS, "rows over lanes: m <= n, n x QPW lanes");
   const RowsLane<NX> ln;
   const int ir = ln.ir, col = ln.col;
@@ -77,16 +78,27 @@ __global__ __launch_bounds__(PROWS_BLOCK) void pxb_rows_kernel(
     }
   };
   double t = 0.0, es = 0.0;
-  auto gterm = [&](double s0, double s1, double lo_, double hi_, double qv) {
+  // `pre`: the value that is clipped -- s0, or s0 scaled onto the thrust-magnitude ball (control rows, SOC)
+  auto gterm = [&](double s0, double pre, double s1, double lo_, double hi_, double qv) {
     double zz = s0, yy;
-    if (VFORM) { zz = fmin(fmax(s0, lo_), hi_); yy = s0 - zz; } else { yy = s1; }
+    if (VFORM) { zz = fmin(fmax(pre, lo_), hi_); yy = s0 - zz; } else { yy = s1; }
     double g = -rho * (zz - yy);
     if (HASQ) g += qv;
     return g;
   };
   auto body = [&](const OpsM& m, const OpsS& o, int k, bool valid) {
-    const double gx = gterm(o.x0, o.x1, TB_ ? m.lox : o.lox, TB_ ? m.hix : o.hix, o.qx);
-    const double gu = gterm(o.u0, o.u1, TB_ ? m.lou : o.lou, TB_ ? m.hiu : o.hiu, o.qu);
+    // thrust-magnitude bound of this stage (branch-free: ub = +inf gives exactly 1): ||v_u|| over the QP's control
+    // rows, read across the lanes and summed in row order -- the one-lane kernels' (and the oracle's) operations
+    double cs = 1.0;
+    if constexpr (SOC) {
+      double ss = 0.0;
+#pragma unroll
+      for (int l = 0; l < NU; ++l) { const double vu = across(o.u0, l); ss = fma(vu, vu, ss); }
+      const double nrm = sqrt(ss), ub = ubd[k];
+      cs = nrm > ub ? ub / nrm : 1.0;
+    }
+    const double gx = gterm(o.x0, o.x0, o.x1, TB_ ? m.lox : o.lox, TB_ ? m.hix : o.hix, o.qx);
+    const double gu = gterm(o.u0, SOC ? o.u0 * cs : o.u0, o.u1, TB_ ? m.lou : o.lou, TB_ ? m.hiu : o.hiu, o.qu);
     const double p = gx + t;
     double pv[NX], hv[NU];
 #pragma unroll
@@ -247,15 +259,17 @@ __global__ __launch_bounds__(PROWS_BLOCK) void pxb_rows_kernel(
 // Forward rollout (+ z-update, dual ascent, residual partials when ZUP; + w stored when STOREW), rows over lanes
 // (the arithmetic of pxfz_kernel):   u = -K x - d [- Psi t_in];  x <- A x + B u;   ZUP: v+ = wh + y_old -> v
 // ---------------------------------------------------------------------------
-template <int NX, int NU, bool ZUP, bool RESID, bool RELAX, bool VIN, bool PB, bool STOREW, bool SEG, bool TILED = false>
+template <int NX, int NU, bool ZUP, bool RESID, bool RELAX, bool VIN, bool PB, bool STOREW, bool SEG, bool TILED = false, bool SOC = false>
 __global__ __launch_bounds__(PROWS_BLOCK) void pxfz_rows_kernel(
     const double* __restrict__ dbuf, const double* __restrict__ x0, const double* __restrict__ Ad,
     const double* __restrict__ Bd, const double* __restrict__ Kd, const double* __restrict__ lo,
     const double* __restrict__ hi, const double* __restrict__ zin, const double* __restrict__ yin,
     double* __restrict__ v, double* __restrict__ w, double* __restrict__ part, double alpha, int N, int pitch,
     const double* __restrict__ Psd, const int* __restrict__ seg_start, const double* __restrict__ tin,
-    const double* __restrict__ xin, const double* __restrict__ loT = nullptr, const double* __restrict__ hiT = nullptr) {
+    const double* __restrict__ xin, const double* __restrict__ loT = nullptr, const double* __restrict__ hiT = nullptr,
+    const double* __restrict__ ubd = nullptr) {
   constexpr int NB = NX + NU, D = ProwsDepth<NX>::D, QPW = PscanShape<NX>::QPW;
+  static_assert(!SOC || ZUP, "the read-out form projects nothing");
   constexpr bool NEEDZ = RESID || RELAX;
   static_assert(NU <= NX && QPW * NX <= PI_THREADS, "rows over lanes: m <= n, n x QPW lanes");
   const RowsLane<NX> ln;
@@ -298,18 +312,19 @@ __global__ __launch_bounds__(PROWS_BLOCK) void pxfz_rows_kernel(
     }
   };
   double accx[5] = {0, 0, 0, 0, 0}, accu[5] = {0, 0, 0, 0, 0};
-  auto zrow = [&](double wv, double s0, double s1, double lo_, double hi_, size_t o, bool store, double (&acc)[5]) {
+  // cs_old / cs_new: the thrust-magnitude factors of the state before / after this z-update (1 unless SOC and a control row)
+  auto zrow = [&](double wv, double s0, double s1, double lo_, double hi_, size_t o, bool store, double (&acc)[5], double cs_old, double cs_new) {
     if (STOREW && store) w[o] = wv;
     if (ZUP) {
       double zo, yo;
-      if (VIN) { zo = fmin(fmax(s0, lo_), hi_); yo = s0 - zo; }
+      if (VIN) { zo = fmin(fmax(SOC ? s0 * cs_old : s0, lo_), hi_); yo = s0 - zo; }
       else { yo = s0; zo = NEEDZ ? s1 : 0.0; }
       double wh = wv;
       if (RELAX) wh = fma(alpha, wv, (1.0 - alpha) * zo);
       const double vn = wh + yo;
       if (store) v[o] = vn;
       if (RESID && store) {
-        const double zn = fmin(fmax(vn, lo_), hi_);
+        const double zn = fmin(fmax(SOC ? vn * cs_new : vn, lo_), hi_);
         const double yn = vn - zn;
         const double dr = wv - zn, ds = zn - zo;
         acc[0] = fma(dr, dr, acc[0]);
@@ -341,8 +356,35 @@ __global__ __launch_bounds__(PROWS_BLOCK) void pxfz_rows_kernel(
     for (int l = 0; l < NU; ++l) b = fma(m.Brow[l], uv[l], b);
     x = valid ? b : x;
     const size_t ox = ((size_t)k * NB + NU + i) * P_ + col, ou = ((size_t)k * NB + j) * P_ + col;
-    zrow(wu, o.u0, o.u1, TB_ ? m.lou : o.lou, TB_ ? m.hiu : o.hiu, ou, valid && live_u, accu);
-    zrow(b, o.x0, o.x1, TB_ ? m.lox : o.lox, TB_ ? m.hix : o.hix, ox, valid && live_x, accx);
+    const double lou_ = TB_ ? m.lou : o.lou, hiu_ = TB_ ? m.hiu : o.hiu;
+    // thrust-magnitude bound (as in pxfz_kernel): the factors of the state before and after this z-update, branch-free; the norms run
+    // over the QP's control rows, read across the lanes in row order
+    double cs_old = 1.0, cs_new = 1.0;
+    if constexpr (SOC) {
+      const double ub = ubd[k];
+      if (VIN) {
+        double ss = 0.0;
+#pragma unroll
+        for (int l = 0; l < NU; ++l) { const double vu = across(o.u0, l); ss = fma(vu, vu, ss); }
+        const double nrm = sqrt(ss);
+        cs_old = nrm > ub ? ub / nrm : 1.0;
+      }
+      if (RESID) {                                  // z+ needs ||v+_u||: this lane's control row of v+ first
+        double zo, yo;
+        if (VIN) { zo = fmin(fmax(o.u0 * cs_old, lou_), hiu_); yo = o.u0 - zo; }
+        else { yo = o.u0; zo = NEEDZ ? o.u1 : 0.0; }
+        double wh = wu;
+        if (RELAX) wh = fma(alpha, wu, (1.0 - alpha) * zo);
+        const double vnu = wh + yo;
+        double ss = 0.0;
+#pragma unroll
+        for (int l = 0; l < NU; ++l) { const double vu = across(vnu, l); ss = fma(vu, vu, ss); }
+        const double nrm = sqrt(ss);
+        cs_new = nrm > ub ? ub / nrm : 1.0;
+      }
+    }
+    zrow(wu, o.u0, o.u1, lou_, hiu_, ou, valid && live_u, accu, cs_old, cs_new);
+    zrow(b, o.x0, o.x1, TB_ ? m.lox : o.lox, TB_ ? m.hix : o.hix, ox, valid && live_x, accx, 1.0, 1.0);
   };
   const int len = kb - ka;                    // stage u of the segment is k = ka + u
   if constexpr (!TILED) {

@@ -176,9 +176,6 @@ int setup_pinst(admm_handle* h, const admm_problem* p) {
                                             std::to_string(need) + " bytes of LDS per workgroup; this device offers " +
                                             std::to_string((size_t)prop.maxSharedMemoryPerMultiProcessor));
   }
-  if (wide && h->has_soc)
-    return fail(ADMM_ERR_UNSUPPORTED, "unorm (thrust-magnitude bound) with per-instance dynamics: not available for (n, m) = (" +
-                                          std::to_string(p->n) + ", " + std::to_string(p->m) + ")");
   // Segments in time (csrc/admm_pinst.hpp): one lane sweeps one segment of one QP, so an iteration takes N / S dependent
   // stage round trips instead of N.  Automatic count: enough (64-QP wave, segment) pairs for one wave per SIMD, segments
   // of at least 8 stages, at most 64 (32 from 512 QPs: the scan is S sequential steps per QP); large batches fill the chip
@@ -213,7 +210,7 @@ int setup_pinst(admm_handle* h, const admm_problem* p) {
     // (measured, N = 1000: 64 QPs 29 -> 23 us per sweep, N = 200: 15 -> 9 us; from 128 QPs the 8-QP waves' 64-byte accesses lose:
     //  256 QPs 44 -> 86 us)
     h->pi_rows = h->pitch <= 64;
-    if (h->has_soc) h->pi_rows = false;          // the thrust-magnitude forms exist for the one-lane kernels only
+    if (h->has_soc) h->pi_rows = false;          // (narrow shapes: the thrust-magnitude forms exist for the one-lane kernels)
     if (std::getenv("ADMM_PI_LANE_PER_QP")) h->pi_rows = false;
     if (std::getenv("ADMM_PI_ROWS") && !h->has_soc) h->pi_rows = true;
     if (wide) h->pi_rows = true;

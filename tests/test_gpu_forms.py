@@ -81,8 +81,6 @@ def test_every_per_instance_form_combination_matches_the_oracle(gpu, shape, comb
     alpha = 1.6 if relaxed else 1.0
     rng = np.random.default_rng(5)
     for batch, soc in ((70, False), (9, False), (70, True)):
-        if soc and n > 6:
-            continue                               # (no thrust-magnitude forms at the wide shapes)
         p = pkg.random_instances(N=26, n=n, m=m, batch=batch, seed=300 + n + batch, with_q=with_q, instance_bounds=pbox, thrust_norm=soc)
         z0, y0 = 0.1 * rng.standard_normal((batch, p.L)), 0.1 * rng.standard_normal((batch, p.L))
         for segments in (1, 4):

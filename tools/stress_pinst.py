@@ -12,7 +12,7 @@ import oracle_c as oc
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 3)
 trials = int(sys.argv[2]) if len(sys.argv) > 2 else 120
 dims = [(6, 3), (2, 1), (4, 2), (3, 2), (1, 1), (2, 2), (4, 1), (6, 1), (6, 2), (6, 4)]
-wide = [(12, 6), (8, 4), (12, 3), (9, 3)]          # rows-over-lanes kernels only, no thrust-magnitude forms (csrc/admm_pinst_wide.hpp)
+wide = [(12, 6), (8, 4), (12, 3), (9, 3)]          # rows-over-lanes kernels only (csrc/admm_pinst_wide.hpp)
 only_wide = os.environ.get("STRESS_WIDE") == "1"
 worst, bad = 0.0, 0
 for trial in range(trials):
@@ -22,7 +22,7 @@ for trial in range(trials):
     segs = int(rng.choice([0, 0, 1, 2, 3, 7, 32]))
     alpha = float(rng.choice([1.0, 1.0, 1.6]))
     rho = float(rng.choice([0.05, 0.3, 1.0]))
-    soc = bool(rng.integers(3) == 0) and (n, m) not in wide    # thrust-magnitude bound on most stages (one-lane kernels)
+    soc = bool(rng.integers(3) == 0)                 # thrust-magnitude bound on most stages
     p = pkg.random_instances(N=N, n=n, m=m, batch=batch, seed=1000 + trial, with_q=bool(rng.integers(2)),
                              instance_bounds=bool(rng.integers(2)), thrust_norm=soc)
     form = str(rng.choice(["auto", "lane_per_qp", "rows"]))          # csrc/admm_pinst.hpp / admm_pinst_rows.hpp, forced either way
