@@ -19,7 +19,7 @@ worst, bad, n_mixed = 0.0, 0, 0
 for trial in range(trials):
     kind = str(rng.choice(["cw6", "cw12", "pinst6", "pinst12"]))
     batch = int(rng.choice([1024, 2048, 4096])) if kind != "pinst12" else int(rng.choice([512, 1024]))
-    soc = bool(rng.integers(3) == 0) and kind in ("cw6", "pinst6")
+    soc = bool(rng.integers(3) == 0) and kind in ("cw6", "pinst6", "pinst12")
     alpha = float(rng.choice([1.0, 1.6]))
     segs = int(rng.choice([0, 0, 4, 16])) if kind.startswith("pinst") else int(rng.choice([0, 0, 8, 32]))
     flags, pm = 0, 0
@@ -37,7 +37,7 @@ for trial in range(trials):
         p = (pkg.cw_rendezvous_instances if kind == "pinst6" else pkg.cw_formation_instances)(N=1000, batch=batch, seed0=1000 + trial)
         if soc:
             lo, hi = p.lo.copy(), p.hi.copy()
-            lo[..., :3], hi[..., :3] = -np.inf, np.inf
+            lo[..., :p.m], hi[..., :p.m] = -np.inf, np.inf
             p = dataclasses.replace(p, lo=lo, hi=hi, unorm=0.25)
     idx = np.linspace(0, batch - 1, 12).astype(int)
     kw = dict(x0=p.x0[idx])
