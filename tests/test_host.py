@@ -350,3 +350,20 @@ def test_timeshard_scan_layout_is_a_column_permutation(lib):
         assert sorted(np.abs(Wt).sum(axis=0).round(9)) == sorted(np.abs(W).sum(axis=0).round(9))      # the same columns, reordered
     del keep
     assert lib.admm_host_scan_matrices_timeshard(C.byref(cp), rho, 6, 4, None, None, None) != 0           # 6 segments on 4 ranks
+
+
+def test_python_constants_are_the_headers(lib):
+    """Every ADMM_FLAG_* / ADMM_PRECISION_* / ADMM_EXCHANGE_* / status code / ABI version the ctypes host uses equals include/admm_hip.h's."""
+    import re
+    text = open(os.path.join(ROOT, "include", "admm_hip.h")).read()
+    defs = {m.group(1): int(m.group(2)) for m in re.finditer(r"^#define\s+(ADMM_[A-Z0-9_]+)\s+(-?\d+)\b", text, re.M)}
+    enums = {m.group(1): int(m.group(2)) for m in re.finditer(r"\b(ADMM_(?:OK|ERR_[A-Z_]+))\s*=\s*(-?\d+)", text)}
+    for name, value in vars(_abi).items():
+        if name.startswith("FLAG_") or name.startswith("PRECISION_") or name.startswith("EXCHANGE_") and isinstance(value, int):
+            assert defs["ADMM_" + name] == value, name
+    assert defs["ADMM_HIP_ABI_VERSION"] == _abi.ABI_VERSION == lib.admm_abi_version()
+    flags = sorted(v for k, v in defs.items() if k.startswith("ADMM_FLAG_") and v)
+    assert len(flags) == len(set(flags)) and all(v & (v - 1) == 0 for v in flags)          # distinct single bits
+    if enums:
+        for code, name in _abi.STATUS_NAMES.items():
+            assert enums[name] == code, name
